@@ -1,0 +1,192 @@
+"""HomographyNet weight set: tensor inventory, deterministic synthetic generator, flat blob format.
+
+The reference keeps its parameters in a PyTorch ``state_dict`` of 54 tensors
+(reference: trace_pytorch_model/model_to_trace.py:88-115 blocks 1-3, :210-235 block 4;
+loaded with ``load_state_dict(strict=True)`` at :344).  The trained checkpoint is not shipped
+with the reference (``.MISSING_LARGE_BLOBS:2``), so parity is pinned with seeded synthetic
+weights produced here and fed identically to the reference model, the oracle and the HIP path.
+
+Blob format ``HNETW001`` (little endian), consumed by ``hnet_create`` (include/hnet.h):
+
+    char     magic[8]  = "HNETW001"
+    uint32   n_tensors
+    n_tensors x { uint32 name_len; char name[name_len]; uint32 ndim; uint32 dims[ndim];
+                  uint64 data_offset  (bytes, from start of the data section) }
+    padding to a multiple of 64 bytes
+    data section: float32 tensors in the reference's own layouts
+                  (conv [Cout,Cin,kh,kw], linear [out,in], bias [out])
+
+Names are the reference ``state_dict`` keys, so a real checkpoint converts 1:1
+(``pack_state_dict``).
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+MAGIC = b"HNETW001"
+
+# (name, cin, cout, k, stride) of every convolution, in execution order per block.
+# reference: model_to_trace.py:88-94 (block 1), :99-104 (block 2), :107-113 (block 3), :210-216 (block 4)
+CONV_LAYERS = [
+    ("block_1_1", 2, 128, 7, 2), ("block_1_2", 128, 128, 5, 2), ("block_1_3", 128, 256, 3, 2),
+    ("block_2_1", 2, 64, 7, 2), ("block_2_2", 64, 128, 5, 2), ("block_2_3", 128, 256, 3, 2),
+    ("block_2_4", 256, 256, 3, 2),
+    ("block_3_0", 2, 16, 7, 1), ("block_3_1", 16, 32, 5, 2), ("block_3_2", 32, 64, 3, 2),
+    ("block_3_3", 64, 128, 3, 2), ("block_3_4", 128, 256, 3, 2), ("block_3_5", 256, 256, 3, 2),
+    ("block_4_0", 2, 8, 7, 1), ("block_4_1", 8, 16, 5, 2), ("block_4_2", 16, 32, 3, 2),
+    ("block_4_3", 32, 64, 3, 2), ("block_4_4", 64, 128, 3, 2), ("block_4_5", 128, 256, 3, 2),
+    ("block_4_6", 256, 256, 3, 2),
+]
+FC_INPUT = 5120      # 256*4*5, reference model_to_trace.py:89
+FC_HIDDEN = 256      # reference model_to_trace.py:224
+
+
+def tensor_specs():
+    """Ordered (name, shape) list equal to the reference state_dict (54 tensors, 6 541 312 params)."""
+    specs = []
+
+    def conv(prefix, name):
+        for n, cin, cout, k, _s in CONV_LAYERS:
+            if n == name:
+                specs.append((f"{prefix}.{n}.0.weight", (cout, cin, k, k)))
+                specs.append((f"{prefix}.{n}.0.bias", (cout,)))
+
+    p1 = "model_part1"
+    for n in ("block_1_1", "block_1_2", "block_1_3"):
+        conv(p1, n)
+    specs += [(f"{p1}.fc_block_1.weight", (8, FC_INPUT)), (f"{p1}.fc_block_1.bias", (8,))]
+    for n in ("block_2_1", "block_2_2", "block_2_3", "block_2_4"):
+        conv(p1, n)
+    specs += [(f"{p1}.fc_block_2.weight", (8, FC_INPUT)), (f"{p1}.fc_block_2.bias", (8,))]
+    for n in ("block_3_0", "block_3_1", "block_3_2", "block_3_3", "block_3_4", "block_3_5"):
+        conv(p1, n)
+    specs += [(f"{p1}.fc_block_3.weight", (8, FC_INPUT)), (f"{p1}.fc_block_3.bias", (8,))]
+    lb = "model_last_block_list.0"
+    for n in ("block_4_0", "block_4_1", "block_4_2", "block_4_3", "block_4_4", "block_4_5", "block_4_6"):
+        conv(lb, n)
+    for head in ("fc_block_4_mean", "fc_block_4_uncertainty"):
+        specs += [(f"{lb}.{head}.1.weight", (FC_HIDDEN, FC_INPUT)), (f"{lb}.{head}.1.bias", (FC_HIDDEN,)),
+                  (f"{lb}.{head}.4.weight", (8, FC_HIDDEN)), (f"{lb}.{head}.4.bias", (8,))]
+    return specs
+
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser of counter array ``x`` (uint64, wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
+    """n reproducible U[0,1) values with 24 random bits each (exact in float32)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed], dtype=np.uint64) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03)))[0]
+        ctr = base + np.arange(n, dtype=np.uint64)
+    bits = _splitmix64(ctr) >> np.uint64(40)
+    return (bits.astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32)
+
+
+# the four layers whose outputs are corner offsets in pixels (SURVEY.md §8c "Weights")
+_OFFSET_FC = ("model_part1.fc_block_1", "model_part1.fc_block_2", "model_part1.fc_block_3",
+              "model_last_block_list.0.fc_block_4_mean.4")
+
+
+def synthetic_state(seed: int = 0, offset_gain: float = 30.0, offset_bias: float = 3.0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded synthetic weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like PyTorch's default init, with
+    the corner-offset FC layers scaled so every block moves the corners by O(1-10) px and the warp
+    between blocks is really exercised (with default init the offsets are ~0.05 px)."""
+    state = OrderedDict()
+    for idx, (name, shape) in enumerate(tensor_specs()):
+        n = int(np.prod(shape))
+        is_bias = name.endswith(".bias")
+        if is_bias:
+            wshape = dict(tensor_specs())[name[:-4] + "weight"]
+            fan_in = int(np.prod(wshape[1:]))
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        bound = 1.0 / np.sqrt(float(fan_in))
+        u = uniform01(seed, idx, n).astype(np.float64) * 2.0 - 1.0
+        layer = name.rsplit(".", 1)[0]
+        if layer in _OFFSET_FC:
+            if is_bias:
+                vals = u * offset_bias
+            else:
+                vals = u * bound * offset_gain
+        else:
+            vals = u * bound
+        state[name] = vals.astype(np.float32).reshape(shape)
+    return state
+
+
+def pack_state_dict(state) -> bytes:
+    """Serialise a name->array mapping (reference state_dict layouts) into the HNETW001 blob.
+    Accepts numpy arrays or anything with ``.numpy()`` / ``.detach()`` (torch tensors)."""
+    specs = tensor_specs()
+    arrays = []
+    for name, shape in specs:
+        if name not in state:
+            raise KeyError(f"state dict is missing tensor {name!r}")
+        a = state[name]
+        if hasattr(a, "detach"):
+            a = a.detach().cpu().numpy()
+        a = np.ascontiguousarray(np.asarray(a, dtype="<f4"))
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {a.shape} != expected {shape}")
+        arrays.append(a)
+    extra = set(state.keys()) - {n for n, _ in specs}
+    if extra:
+        raise KeyError(f"unexpected tensors in state dict: {sorted(extra)[:4]}")
+    head = bytearray(MAGIC + struct.pack("<I", len(specs)))
+    off = 0
+    for (name, shape), a in zip(specs, arrays):
+        nb = name.encode()
+        head += struct.pack("<I", len(nb)) + nb + struct.pack("<I", len(shape))
+        head += struct.pack(f"<{len(shape)}I", *shape) + struct.pack("<Q", off)
+        off += a.nbytes
+        off = (off + 63) // 64 * 64
+    head += b"\0" * ((-len(head)) % 64)
+    data = bytearray(off)
+    pos = 0
+    for a in arrays:
+        data[pos:pos + a.nbytes] = a.tobytes()
+        pos = (pos + a.nbytes + 63) // 64 * 64
+    return bytes(head) + bytes(data)
+
+
+def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
+    if blob[:8] != MAGIC:
+        raise ValueError("not an HNETW001 blob")
+    (n,) = struct.unpack_from("<I", blob, 8)
+    pos = 12
+    entries = []
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<I", blob, pos); pos += 4
+        name = blob[pos:pos + ln].decode(); pos += ln
+        (nd,) = struct.unpack_from("<I", blob, pos); pos += 4
+        dims = struct.unpack_from(f"<{nd}I", blob, pos); pos += 4 * nd
+        (off,) = struct.unpack_from("<Q", blob, pos); pos += 8
+        entries.append((name, dims, off))
+    data0 = (pos + 63) // 64 * 64
+    out = OrderedDict()
+    for name, dims, off in entries:
+        cnt = int(np.prod(dims))
+        out[name] = np.frombuffer(blob, dtype="<f4", count=cnt, offset=data0 + off).reshape(dims).copy()
+    return out
+
+
+def save_blob(path: str, state) -> None:
+    with open(path, "wb") as f:
+        f.write(pack_state_dict(state))
+
+
+def load_blob(path: str):
+    with open(path, "rb") as f:
+        return unpack_blob(f.read())

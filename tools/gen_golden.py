@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE Python model (imported from
+/root/reference/trace_pytorch_model, never copied) on seeded synthetic weights and inputs.
+
+Runs only in the build container (the reference is absent on the GPU box); the produced vectors are
+data: inputs are regenerated from seeds by cuahn_vio_amd.synth (their CRC is stored and checked),
+only outputs and per-layer statistics are stored.
+
+Recipe follows SURVEY.md Appendix B:
+  - model = combined_stu_model(Down_Net_3blocks, [HomoNet_last_block])   (model_to_trace.py:285-330)
+  - dropout_rate=0.0  -> deterministic cases
+  - explicit-mask cases: the four nn.Dropout children of the two heads (model_to_trace.py:222-235)
+    are replaced by a module multiplying with keep_mask/(1-p) from include/hnet_rng.h
+  - prior variants via `blocks_to_run` (model_to_trace.py:72,129-193)
+
+usage: python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference/trace_pytorch_model")
+
+import model_to_trace as M  # noqa: E402  (the reference)
+
+from cuahn_vio_amd import mcdrop, synth, weights  # noqa: E402
+
+MC_SEED = 0x5EED5EED12345678
+N_SAMP = 16  # sampled elements per layer
+
+
+class MaskMul(torch.nn.Module):
+    """stands in for nn.Dropout in train mode: out = x * noise, noise = keep/(1-p)  (PyTorch semantics)"""
+
+    def __init__(self, noise):
+        super().__init__()
+        self.noise = noise
+
+    def forward(self, x):
+        return x * self.noise
+
+
+def build_model(state, dropout_rate, n_mc, dtype=torch.float32):
+    p1 = M.Down_Net_3blocks(224, 320, "cpu")
+    lb = M.HomoNet_last_block(p1.img_warper_full_size, p1.conv_planes, p1.fc_input, p1.origin_4pt, "cpu",
+                              dropout_rate=dropout_rate)
+    lb.MC_dropout_num = n_mc
+    m = M.combined_stu_model(p1, torch.nn.ModuleList([lb]), "cpu", show_photometric_error=True).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    for p in m.parameters():
+        p.requires_grad = False
+    if dtype == torch.float64:
+        m = m.double()
+        w = p1.img_warper_full_size
+        w.grid_uv1 = w.grid_uv1.double()
+        w.sample_grid_factor = w.sample_grid_factor.double()
+        p1.origin_4pt = p1.origin_4pt.double()
+        lb.origin_4pt = lb.origin_4pt.double()
+        lb.batch_img1_4pt = lb.batch_img1_4pt.double()
+    return m, p1, lb
+
+
+def inject_masks(lb, pair_seq, n_mc, p):
+    sc = mcdrop.scale(p)
+    for head, s_in, s_hid in ((lb.fc_block_4_mean, mcdrop.STREAM_MEAN_IN, mcdrop.STREAM_MEAN_HID),
+                              (lb.fc_block_4_uncertainty, mcdrop.STREAM_UNC_IN, mcdrop.STREAM_UNC_HID)):
+        k_in = mcdrop.keep_mask(MC_SEED, pair_seq, s_in, n_mc, 5120, p)
+        k_hid = mcdrop.keep_mask(MC_SEED, pair_seq, s_hid, n_mc, 256, p)
+        head[0] = MaskMul(torch.from_numpy(k_in.astype(np.float32) * sc))
+        head[3] = MaskMul(torch.from_numpy(k_hid.astype(np.float32) * sc))
+
+
+def layer_stats(t):
+    a = t.detach().double().reshape(-1).numpy()
+    n = a.size
+    idx = (np.arange(N_SAMP, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(n)
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum()), float(n)], a[idx.astype(np.int64)]])
+
+
+def run_case(m, p1, lb, img1, img2, prior, blocks_to_run, dtype=torch.float32):
+    """returns dict of outputs + per-layer stats + recorded DLT calls"""
+    rec = {"dlt_dst": [], "dlt_H": []}
+    stats = {}
+    hooks = []
+    for name, mod in list(p1.named_children()) + list(lb.named_children()):
+        if name.startswith("block_") or name.startswith("fc_block_"):
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, name=name: stats.__setitem__(name, layer_stats(o))))
+    orig_dlt = M.DLT_solve
+
+    def dlt_rec(src, dst):
+        h = orig_dlt(src, dst)
+        rec["dlt_dst"].append(dst.detach().double().numpy().reshape(4, 2).copy())
+        rec["dlt_H"].append(h.detach().double().numpy().reshape(3, 3).copy())
+        return h
+
+    M.DLT_solve = dlt_rec
+    p1.blocks_to_run = blocks_to_run
+    try:
+        with torch.no_grad():
+            t1 = torch.from_numpy(img1).to(dtype).reshape(1, 1, 224, 320)
+            t2 = torch.from_numpy(img2).to(dtype).reshape(1, 1, 224, 320)
+            if prior is None:
+                mean, cov, err = m(t1, t2)
+                h1 = p1(t1, t2)
+            else:
+                tp = torch.from_numpy(np.asarray(prior)).to(dtype).reshape(1, 1, 4, 2)
+                mean, cov, err = m(t1, t2, tp)
+                h1 = p1(t1, t2, tp.reshape(1, 4, 2))
+    finally:
+        M.DLT_solve = orig_dlt
+        p1.blocks_to_run = 3
+        for h in hooks:
+            h.remove()
+    err = err.double().numpy().reshape(224, 320)
+    out = {
+        "mean": mean.double().numpy().reshape(8),
+        "cov": cov.double().numpy().reshape(8, 8),
+        "H_part1": h1.double().numpy().reshape(3, 3),
+        "err_stats": np.array([err.sum(), np.sqrt((err * err).sum())]),
+        "err_ds4": err[::4, ::4].astype(np.float32),
+        "dlt_dst": np.array(rec["dlt_dst"]),
+        "dlt_H": np.array(rec["dlt_H"]),
+    }
+    for k, v in stats.items():
+        out["L_" + k] = v
+    return out
+
+
+def u8_to_f32(a):
+    # HomographyNet.cpp:141,146: toType(kFloat) / 255.0   (float32 division)
+    return (a.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+WARP_H = {
+    "identity": np.eye(3),
+    "shift": np.array([[1, 0, 3.25], [0, 1, -2.5], [0, 0, 1.0]]),
+    "oob": np.array([[1, 0, 200.5], [0, 1, 150.25], [0, 0, 1.0]]),
+    "persp": np.array([[1.02, 0.03, -4.0], [-0.02, 0.97, 5.5], [1.5e-4, -2.0e-4, 1.0]]),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    state = weights.synthetic_state(0)
+
+    m0, p1_0, lb_0 = build_model(state, 0.0, 16)
+    cases = []
+    # --- deterministic (p = 0) cases on synthetic pairs
+    for seed in (1, 2, 3):
+        cases.append(dict(name=f"full_p0_s{seed}", kind="pair", seed=seed, variant="full", p=0.0, n_mc=16))
+    cases.append(dict(name="prior3_p0_s4", kind="pair", seed=4, variant="prior3", p=0.0, n_mc=16))
+    cases.append(dict(name="prior2_p0_s5", kind="pair", seed=5, variant="prior2", p=0.0, n_mc=16))
+    cases.append(dict(name="prior1_p0_s6", kind="pair", seed=6, variant="prior1", p=0.0, n_mc=16))
+    cases.append(dict(name="full_p0_noise7", kind="noise", seed=7, variant="full", p=0.0, n_mc=16))
+    # --- explicit-mask (p = 0.05) cases
+    cases.append(dict(name="full_mask16_s8", kind="pair", seed=8, variant="full", p=0.05, n_mc=16, pair_seq=8))
+    cases.append(dict(name="full_mask32_s9", kind="pair", seed=9, variant="full", p=0.05, n_mc=32, pair_seq=9))
+    cases.append(dict(name="prior3_mask16_s10", kind="pair", seed=10, variant="prior3", p=0.05, n_mc=16, pair_seq=10))
+    # --- the reference's own constant warm-up / trace inputs (HomographyNet.cpp:29-33, trace_model.py:20-22)
+    cases.append(dict(name="const_full", kind="const", variant="full", p=0.0, n_mc=16))
+    cases.append(dict(name="const_prior10", kind="const", variant="prior3", p=0.0, n_mc=16, prior_val=1.0))
+    cases.append(dict(name="const_prior09", kind="const", variant="prior3", p=0.0, n_mc=16, prior_val=0.9))
+
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}
+    floor = []
+    for c in cases:
+        if c["kind"] == "pair":
+            i1, i2, off = synth.make_pair(c["seed"])
+            prior = synth.make_prior(c["seed"], off) if c["variant"] != "full" else None
+            f1, f2 = u8_to_f32(i1), u8_to_f32(i2)
+            meta = dict(in_crc=synth.crc(i1, i2), true_offsets=off)
+        elif c["kind"] == "noise":
+            i1, i2 = synth.make_noise_pair(c["seed"])
+            prior = None
+            f1, f2 = u8_to_f32(i1), u8_to_f32(i2)
+            meta = dict(in_crc=synth.crc(i1, i2))
+        else:
+            f1 = np.full((224, 320), 0.2, np.float32)
+            f2 = np.full((224, 320), 0.5, np.float32)
+            prior = None if c["variant"] == "full" else np.full(8, c["prior_val"], np.float32)
+            meta = dict(in_crc=synth.crc(f1, f2))
+        if c["p"] > 0:
+            m, p1, lb = build_model(state, c["p"], c["n_mc"])
+            inject_masks(lb, c["pair_seq"], c["n_mc"], c["p"])
+            meta.update(mc_seed=np.uint64(MC_SEED), pair_seq=c["pair_seq"])
+        else:
+            m, p1, lb = m0, p1_0, lb_0
+            lb.MC_dropout_num = c["n_mc"]
+        out = run_case(m, p1, lb, f1, f2, prior, btr[c["variant"]])
+        out.update(meta)
+        out.update(variant=c["variant"], p=np.float32(c["p"]), n_mc=c["n_mc"], kind=c["kind"],
+                   seed=c.get("seed", -1), weights_seed=0)
+        if prior is not None:
+            out["prior"] = prior
+        np.savez_compressed(os.path.join(args.out, c["name"] + ".npz"), **out)
+        msg = f"{c['name']:>20}: mean={np.array2string(out['mean'], precision=3)} cov00={out['cov'][0,0]:.4g}"
+        # the same case evaluated by the reference in float64: the "exact math" anchor.  The reference's
+        # own fp32 run sits up to ~1.4e-4 px away from it (torch.inverse in DLT_solve, model_to_trace.py:57).
+        m64, p64, l64 = build_model(state, c["p"], c["n_mc"], torch.float64)
+        if c["p"] > 0:
+            inject_masks(l64, c["pair_seq"], c["n_mc"], c["p"])
+        o64 = run_case(m64, p64, l64, f1.astype(np.float64), f2.astype(np.float64),
+                       None if prior is None else prior.astype(np.float64), btr[c["variant"]], torch.float64)
+        d = np.abs(o64["mean"] - out["mean"]).max()
+        dc = np.abs(o64["cov"] - out["cov"]).max() / np.abs(o64["cov"]).max()
+        floor.append(d)
+        msg += f" | fp32-vs-fp64: mean {d:.2e} px, cov rel {dc:.2e}"
+        extra = {"mean64": o64["mean"], "cov64": o64["cov"], "H_part1_64": o64["H_part1"], "dlt_dst64": o64["dlt_dst"],
+                 "err_stats64": o64["err_stats"]}
+        np.savez_compressed(os.path.join(args.out, c["name"] + ".npz"), **out, **extra)
+        print(msg, flush=True)
+
+    # --- standalone warp vectors (warp.py:60-79)
+    i1, i2, _ = synth.make_pair(11)
+    f2 = u8_to_f32(i2)
+    wout = {"in_crc": synth.crc(i2), "seed": 11}
+    warper = p1_0.img_warper_full_size
+    for name, hm in WARP_H.items():
+        with torch.no_grad():
+            w = warper.warpSingleImage_H_Mtrx(torch.from_numpy(f2).reshape(1, 1, 224, 320),
+                                              torch.from_numpy(hm.astype(np.float32)).reshape(1, 3, 3))
+        w = w.numpy().reshape(224, 320)
+        wout["H_" + name] = hm.astype(np.float32)
+        wout["w_" + name] = w[::2, ::2].copy()           # every other pixel, float32
+        wout["s_" + name] = np.array([w.astype(np.float64).sum(), np.sqrt((w.astype(np.float64) ** 2).sum())])
+    np.savez_compressed(os.path.join(args.out, "warp_s11.npz"), **wout)
+    # --- DLT vectors (model_to_trace.py:42-61)
+    rng_off = (weights.uniform01(77, 0, 8 * 16).reshape(16, 4, 2).astype(np.float32) * 2 - 1) * 20.0
+    p4 = p1_0.origin_4pt.reshape(1, 4, 2)
+    hs = [M.DLT_solve(p4, p4 + torch.from_numpy(o).reshape(1, 4, 2)).numpy().reshape(3, 3) for o in rng_off]
+    np.savez_compressed(os.path.join(args.out, "dlt.npz"), offsets=rng_off, H=np.array(hs))
+    if floor:
+        print(f"reference fp32-vs-fp64 floor over deterministic cases: max {max(floor):.2e} px")
+
+
+if __name__ == "__main__":
+    main()
