@@ -1,0 +1,697 @@
+// hnet_capi.hip — context, weight packing, forward orchestration and the C ABI of include/hnet.h.
+//
+// Mirrors the behaviour of the reference runtime class pytorch::HomographyNet
+// (cuahn_ros/homography_network/src/HomographyNet.cpp) without libtorch: weights come from an HNETW001
+// blob, the forward is a fixed sequence of HIP kernel launches on one stream over persistent buffers.
+#include "../../include/hnet.h"
+#include "geom.h"
+#include "kernels.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hnet;
+
+namespace {
+
+struct Tensor { std::vector<uint32_t> dims; const float* data; size_t count; };
+
+struct Blob {
+    std::vector<std::pair<std::string, Tensor>> t;
+    const Tensor* find(const std::string& n, size_t expect) const {
+        for (auto& e : t)
+            if (e.first == n) return e.second.count == expect ? &e.second : nullptr;
+        return nullptr;
+    }
+};
+
+bool parse_blob(const uint8_t* p, size_t len, Blob& out) {
+    if (len < 12 || memcmp(p, "HNETW001", 8) != 0) return false;
+    uint32_t n; memcpy(&n, p + 8, 4);
+    if (n > 1024) return false;
+    size_t pos = 12;
+    struct Ent { std::string name; std::vector<uint32_t> dims; uint64_t off; size_t count; };
+    std::vector<Ent> ents;
+    size_t data_bytes = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (pos + 4 > len) return false;
+        uint32_t ln; memcpy(&ln, p + pos, 4); pos += 4;
+        if (ln > 512 || pos + ln + 4 > len) return false;
+        Ent e; e.name.assign((const char*)p + pos, ln); pos += ln;
+        uint32_t nd; memcpy(&nd, p + pos, 4); pos += 4;
+        if (nd > 8 || pos + 4 * nd + 8 > len) return false;
+        e.count = 1;
+        for (uint32_t d = 0; d < nd; d++) { uint32_t v; memcpy(&v, p + pos, 4); pos += 4; e.dims.push_back(v); e.count *= v; }
+        memcpy(&e.off, p + pos, 8); pos += 8;
+        if (e.off % 4) return false;
+        data_bytes = std::max(data_bytes, (size_t)e.off + e.count * 4);
+        ents.push_back(e);
+    }
+    size_t data0 = (pos + 63) / 64 * 64;
+    if (data0 + data_bytes > len) return false;
+    for (auto& e : ents) out.t.push_back({e.name, Tensor{e.dims, (const float*)(p + data0 + e.off), e.count}});
+    return true;
+}
+
+struct Stage { std::string name; double flops_per_pair; };
+
+}  // namespace
+
+struct hnet_ctx {
+    hnet_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // weights (device)
+    float* conv_w[20] = {};
+    float* conv_b[20] = {};
+    float* fc_w[3] = {};
+    float* fc_b[3] = {};
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    // activations (device), sized for cfg.max_batch
+    float* x_in[4] = {};
+    float* act[20] = {};
+    int act_c[20], act_h[20], act_w[20];
+    float *hidden = nullptr, *Hm = nullptr, *Htot = nullptr, *mean_s = nullptr, *logvar_s = nullptr;
+    float *d_mean = nullptr, *d_cov = nullptr, *d_err = nullptr, *d_prior = nullptr;
+    uint8_t* d_err_u8 = nullptr;
+    void *stage_prev = nullptr, *stage_curr = nullptr;    // batch staging for host-buffer entry points (f32 sized)
+    uint8_t* ring[2] = {};                                 // streaming prev / curr
+    int curr_slot = 0;
+    int img_counter = 0;
+    double latest_t = -1.0;
+    int n_local = 0, s_begin = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hnet_timing timing = {};
+    std::vector<Stage> stages;
+    std::vector<hipEvent_t> prof_ev;   // when non-empty: one event after every stage
+    size_t prof_pos = 0;
+    int last_batch = 0;
+};
+
+namespace {
+
+const char* kStatus[] = {"ok", "invalid argument", "bad weights", "device error", "not ready (need two images)",
+                         "batch exceeds max_batch", "unsupported"};
+
+int fail(hnet_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail((c), HNET_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template <typename T>
+hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+
+hipError_t upload(float** dst, const std::vector<float>& v) {
+    hipError_t e = dalloc(dst, v.size());
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+}
+
+// conv weight [Cout][Cin][KS][KS] -> [Cout][KS][SPR*SEG], inner index r = kw*Cin + ci, zero padded (igemm.h)
+std::vector<float> pack_conv(const float* w, const ConvDesc& d, int kp) {
+    const int rl = d.ks * d.cin, rlp = kp / d.ks;
+    std::vector<float> out((size_t)d.cout * kp, 0.0f);
+    for (int co = 0; co < d.cout; co++)
+        for (int ci = 0; ci < d.cin; ci++)
+            for (int kh = 0; kh < d.ks; kh++)
+                for (int kw = 0; kw < d.ks; kw++) {
+                    const int r = kw * d.cin + ci;
+                    (void)rl;
+                    out[(size_t)co * kp + kh * rlp + r] = w[(((size_t)co * d.cin + ci) * d.ks + kh) * d.ks + kw];
+                }
+    return out;
+}
+
+// linear weight [out][5120] with NCHW-flatten input index c*20+pix -> NHWC-flatten index pix*256+c
+std::vector<float> permute_fc(const float* w, int n_out) {
+    std::vector<float> out((size_t)n_out * 5120);
+    for (int o = 0; o < n_out; o++)
+        for (int c = 0; c < 256; c++)
+            for (int pix = 0; pix < 20; pix++) out[(size_t)o * 5120 + pix * 256 + c] = w[(size_t)o * 5120 + c * 20 + pix];
+    return out;
+}
+
+void build_stages(hnet_ctx* c) {
+    c->stages.clear();
+    const hnet_config& g = c->cfg;
+    auto conv_flops = [&](int l, int h, int w) {
+        const ConvDesc& d = kConvs[l];
+        return 2.0 * d.cout * d.cin * d.ks * d.ks * conv_out_dim(h, d.ks, d.stride) * conv_out_dim(w, d.ks, d.stride);
+    };
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    if (g.use_prior) c->stages.push_back({"prior_dlt", 0});
+    const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
+    for (int blk = fb; blk < 4; blk++) {
+        c->stages.push_back({"prep_b" + std::to_string(blk + 1), 0});
+        int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
+        for (int l = first[blk]; l <= last[blk]; l++) {
+            c->stages.push_back({kConvs[l].name, conv_flops(l, h, w)});
+            h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
+            w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
+        }
+        if (blk < 3) c->stages.push_back({"fc_dlt_b" + std::to_string(blk + 1), 2.0 * 8 * 5120});
+    }
+    c->stages.push_back({"heads_fc1", 2.0 * 512 * 5120 * c->n_local});
+    c->stages.push_back({"heads_fc2_finish", 2.0 * 16 * 256 * c->n_local});
+    if (g.emit_error_map) c->stages.push_back({"errmap", 0});
+}
+
+struct FwdArgs {
+    const void *prev, *curr;
+    int pix_fmt;
+    const float* prior;
+    int batch;
+    uint64_t seq0;
+    float *mean, *cov;        // device outputs (finish path)
+    float* err;               // device error map (float) or null
+    uint8_t* err_u8;
+    float *mean_s, *logvar_s, *h_part1;   // partial path outputs (device) or null
+    bool partial;
+};
+
+#define STAGE(call)                                                                                         \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail(c, HNET_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        if (!c->prof_ev.empty() && c->prof_pos < c->prof_ev.size()) {                                       \
+            e_ = hipEventRecord(c->prof_ev[c->prof_pos++], s);                                              \
+            if (e_ != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipEventRecord(stage)");                 \
+        }                                                                                                   \
+    } while (0)
+
+// The forward of combined_stu_model (model_to_trace.py:299-330) for `batch` independent frame pairs.
+int forward(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
+    const hnet_config& g = c->cfg;
+    const int B = a.batch;
+    if (B < 1) return fail(c, HNET_ERR_INVALID_ARG, "batch < 1");
+    if (B > g.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
+    if (g.use_prior && !a.prior) return fail(c, HNET_ERR_INVALID_ARG, "context uses a prior but none was given");
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    c->last_batch = B;
+    if (g.use_prior) STAGE(launch_prior_dlt(a.prior, c->Hm, B, s));                 // :129-130
+    const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
+    for (int blk = fb; blk < 4; blk++) {
+        const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
+        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? c->Hm : nullptr, 8 >> blk, c->x_in[blk], B, s));
+        const float* in = c->x_in[blk];
+        int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
+        for (int l = first[blk]; l <= last[blk]; l++) {
+            STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], c->act[l], s));
+            in = c->act[l];
+            h = c->act_h[l];
+            w = c->act_w[l];
+        }
+        if (blk < 3)                                                                  // :143-150, :163-168, :183-188
+            STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? c->Hm : nullptr, c->Hm, B, s));
+    }
+    // block 4 heads (:272-282) and output assembly (:310-317)
+    STAGE(launch_heads_fc1(c->act[19], B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, c->hidden, s));
+    if (a.partial) {
+        STAGE(launch_heads_fc2(c->hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, c->Hm,
+                               a.mean_s, a.logvar_s, 0, nullptr, nullptr, nullptr, s));
+        if (a.h_part1) {
+            hipError_t e = hipMemcpyAsync(a.h_part1, c->Hm, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return fail(c, HNET_ERR_DEVICE, "copy H_part1");
+        }
+        return HNET_OK;
+    }
+    STAGE(launch_heads_fc2(c->hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, c->Hm,
+                           c->mean_s, c->logvar_s, 1, a.mean, a.cov, c->Htot, s));
+    if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
+        STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, c->Htot, a.err, a.err_u8, B, s));
+    return HNET_OK;
+}
+
+int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet_ctx** out) {
+    if (!cfg_in || !out) return HNET_ERR_INVALID_ARG;
+    hnet_config g;
+    hnet_default_config(&g);
+    memcpy(&g, cfg_in, std::min<size_t>(cfg_in->struct_size ? cfg_in->struct_size : sizeof(g), sizeof(g)));
+    g.struct_size = sizeof(g);
+    if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
+        return HNET_ERR_INVALID_ARG;
+    if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
+    if (g.precision != HNET_PREC_FP32) return HNET_ERR_UNSUPPORTED;
+    if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
+    if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
+        return HNET_ERR_INVALID_ARG;
+    Blob b;
+    if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
+    hnet_ctx* c = new hnet_ctx();
+    c->cfg = g;
+    c->n_local = g.mc_sample_end - g.mc_sample_begin;
+    c->s_begin = g.mc_sample_begin;
+#define CK(expr)                                                                    \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "hnet_create: %s: %s\n", #expr, hipGetErrorString(e_)); \
+            hnet_destroy(c);                                                        \
+            return HNET_ERR_DEVICE;                                                 \
+        }                                                                           \
+    } while (0)
+    CK(hipSetDevice(g.device_id));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+
+    // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
+    for (int l = 0; l < 20; l++) {
+        const ConvDesc& d = kConvs[l];
+        const std::string pre = std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.";
+        const Tensor* w = b.find(pre + "weight", (size_t)d.cout * d.cin * d.ks * d.ks);
+        const Tensor* bi = b.find(pre + "bias", d.cout);
+        if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+        CK(upload(&c->conv_w[l], pack_conv(w->data, d, conv_padded_k(l))));
+        CK(upload(&c->conv_b[l], std::vector<float>(bi->data, bi->data + d.cout)));
+    }
+    for (int k = 0; k < 3; k++) {
+        const std::string pre = "model_part1.fc_block_" + std::to_string(k + 1) + ".";
+        const Tensor* w = b.find(pre + "weight", 8 * 5120);
+        const Tensor* bi = b.find(pre + "bias", 8);
+        if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+        CK(upload(&c->fc_w[k], permute_fc(w->data, 8)));
+        CK(upload(&c->fc_b[k], std::vector<float>(bi->data, bi->data + 8)));
+    }
+    {
+        static const char* heads[2] = {"fc_block_4_mean", "fc_block_4_uncertainty"};
+        std::vector<float> w1, b1, w2, b2;
+        for (int h = 0; h < 2; h++) {
+            const std::string pre = std::string("model_last_block_list.0.") + heads[h] + ".";
+            const Tensor* tw1 = b.find(pre + "1.weight", 256 * 5120);
+            const Tensor* tb1 = b.find(pre + "1.bias", 256);
+            const Tensor* tw2 = b.find(pre + "4.weight", 8 * 256);
+            const Tensor* tb2 = b.find(pre + "4.bias", 8);
+            if (!tw1 || !tb1 || !tw2 || !tb2) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+            std::vector<float> p = permute_fc(tw1->data, 256);
+            w1.insert(w1.end(), p.begin(), p.end());
+            b1.insert(b1.end(), tb1->data, tb1->data + 256);
+            w2.insert(w2.end(), tw2->data, tw2->data + 8 * 256);
+            b2.insert(b2.end(), tb2->data, tb2->data + 8);
+        }
+        CK(upload(&c->w1, w1)); CK(upload(&c->b1, b1)); CK(upload(&c->w2, w2)); CK(upload(&c->b2, b2));
+    }
+
+    // ---- persistent activation buffers (NHWC fp32), one per layer so every intermediate can be read back
+    const size_t MB = (size_t)g.max_batch;
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    for (int blk = 0; blk < 4; blk++) {
+        int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
+        CK(dalloc(&c->x_in[blk], MB * h * w * 2));
+        for (int l = first[blk]; l <= last[blk]; l++) {
+            h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
+            w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
+            c->act_c[l] = kConvs[l].cout; c->act_h[l] = h; c->act_w[l] = w;
+            CK(dalloc(&c->act[l], MB * h * w * kConvs[l].cout));
+        }
+    }
+    CK(dalloc(&c->hidden, MB * c->n_local * 512));
+    CK(dalloc(&c->Hm, MB * 9));
+    CK(dalloc(&c->Htot, MB * 9));
+    CK(dalloc(&c->mean_s, MB * c->n_local * 8));
+    CK(dalloc(&c->logvar_s, MB * c->n_local * 8));
+    CK(dalloc(&c->d_mean, MB * 8));
+    CK(dalloc(&c->d_cov, MB * 64));
+    CK(dalloc(&c->d_prior, MB * 8));
+    CK(hipMalloc(&c->stage_prev, MB * NPIX * sizeof(float)));
+    CK(hipMalloc(&c->stage_curr, MB * NPIX * sizeof(float)));
+    if (g.emit_error_map) {
+        CK(dalloc(&c->d_err, MB * NPIX));
+        CK(dalloc(&c->d_err_u8, MB * NPIX));
+    }
+    CK(dalloc(&c->ring[0], (size_t)NPIX));
+    CK(dalloc(&c->ring[1], (size_t)NPIX));
+    build_stages(c);
+
+    // ---- warm-up forward on the reference's constant inputs (HomographyNet.cpp:28-45): 0.2 / 0.5 / prior 1.0
+    {
+        std::vector<float> i1(NPIX, 0.2f), i2(NPIX, 0.5f), pr(8, 1.0f);
+        CK(hipMemcpy(c->stage_prev, i1.data(), NPIX * sizeof(float), hipMemcpyHostToDevice));
+        CK(hipMemcpy(c->stage_curr, i2.data(), NPIX * sizeof(float), hipMemcpyHostToDevice));
+        CK(hipMemcpy(c->d_prior, pr.data(), 8 * sizeof(float), hipMemcpyHostToDevice));
+        FwdArgs a = {c->stage_prev, c->stage_curr, HNET_PIX_F32, g.use_prior ? c->d_prior : nullptr, 1, 0,
+                     c->d_mean, c->d_cov, c->d_err, nullptr, nullptr, nullptr, nullptr, false};
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = forward(c, a, c->stream);
+        if (rc == HNET_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HNET_ERR_DEVICE;
+        if (rc != HNET_OK) {
+            fprintf(stderr, "hnet_create: warm-up forward failed: %s\n", c->err.c_str());
+            hnet_destroy(c);
+            return rc;
+        }
+        c->timing.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+#undef CK
+    *out = c;
+    return HNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void hnet_default_config(hnet_config* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(*cfg);
+    cfg->blocks_to_run = 3;
+    cfg->mc_samples = 16;        // model_to_trace.py:202
+    cfg->dropout_p = 0.05f;      // trace_model.py:16
+    cfg->precision = HNET_PREC_FP32;
+    cfg->max_batch = 1;
+}
+
+int hnet_create_from_memory(const hnet_config* cfg, const void* blob, size_t len, hnet_ctx** out) {
+    if (!blob) return HNET_ERR_INVALID_ARG;
+    return create_impl(cfg, (const uint8_t*)blob, len, out);
+}
+
+int hnet_create(const hnet_config* cfg, const char* weights_path, hnet_ctx** out) {
+    if (!weights_path) return HNET_ERR_INVALID_ARG;
+    FILE* f = fopen(weights_path, "rb");
+    if (!f) {   // the reference only prints on a load failure (HomographyNet.cpp:91-93); here it is an error code
+        fprintf(stderr, "hnet_create: cannot open weights file %s\n", weights_path);
+        return HNET_ERR_BAD_WEIGHTS;
+    }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf(n > 0 ? n : 0);
+    size_t got = n > 0 ? fread(buf.data(), 1, n, f) : 0;
+    fclose(f);
+    if ((long)got != n) return HNET_ERR_BAD_WEIGHTS;
+    return create_impl(cfg, buf.data(), buf.size(), out);
+}
+
+void hnet_destroy(hnet_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); }
+    for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
+    for (int k = 0; k < 4; k++) fr(c->x_in[k]);
+    fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
+    fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
+    fr(c->ring[0]); fr(c->ring[1]);
+    for (auto e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hnet_status_string(int s) { return (s >= 0 && s <= 6) ? kStatus[s] : "unknown status"; }
+const char* hnet_last_error(const hnet_ctx* c) { return c ? c->err.c_str() : ""; }
+const char* hnet_version(void) { return "hnet-hip 0.1.0 (gfx950)"; }
+
+int hnet_push_image(hnet_ctx* c, const uint8_t* data, int rows, int cols, int row_stride, double t) {
+    if (!c || !data) return HNET_ERR_INVALID_ARG;
+    if (rows != IMG_H || cols != IMG_W || row_stride < cols) return fail(c, HNET_ERR_INVALID_ARG, "image must be 224x320 8-bit");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    c->img_counter++;                                               // HomographyNet.cpp:134
+    const int slot = c->img_counter == 1 ? 0 : (c->curr_slot ^ 1);  // prev <- curr: flip the ring instead of cloning (:143)
+    HIPCHK(c, hipMemcpy2DAsync(c->ring[slot], IMG_W, data, row_stride, IMG_W, IMG_H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                     // `data` is not retained (cv::Mat may be reused)
+    c->curr_slot = slot;
+    if (c->img_counter >= 2) c->latest_t = t;                       // :148
+    return HNET_OK;
+}
+
+int hnet_image_count(const hnet_ctx* c) { return c ? c->img_counter : 0; }
+double hnet_latest_time(const hnet_ctx* c) { return c ? c->latest_t : -1.0; }
+
+static void note_timing(hnet_ctx* c, float dev_ms, double host_ms) {
+    c->timing.device_ms = dev_ms;
+    c->timing.host_ms = host_ms;
+    c->timing.n_inferences++;
+    if (c->timing.n_inferences > 100) c->timing.sum_device_ms_after_100 += dev_ms;   // HomographyNet.cpp:245-251
+}
+
+int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_out[8], float cov_out[64], uint8_t* err_map_out) {
+    (void)iteration;
+    if (!c || !mean_out || !cov_out) return HNET_ERR_INVALID_ARG;
+    if (c->img_counter < 2) return fail(c, HNET_ERR_NOT_READY, "HNet cannot inference! Only has one image!");   // :155-158
+    if (err_map_out && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    auto t0 = std::chrono::steady_clock::now();
+    if (c->cfg.use_prior) {
+        if (!prior_px) return fail(c, HNET_ERR_INVALID_ARG, "prior required");
+        float pf[8];
+        for (int i = 0; i < 8; i++) pf[i] = (float)prior_px[i];    // :160-165 toType(kFloat)
+        HIPCHK(c, hipMemcpyAsync(c->d_prior, pf, sizeof pf, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    FwdArgs a = {c->ring[c->curr_slot ^ 1], c->ring[c->curr_slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1,
+                 (uint64_t)c->timing.n_inferences, c->d_mean, c->d_cov, nullptr, err_map_out ? c->d_err_u8 : nullptr,
+                 nullptr, nullptr, nullptr, false};
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    int rc = forward(c, a, c->stream);
+    if (rc != HNET_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mean_out, c->d_mean, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (err_map_out) HIPCHK(c, hipMemcpyAsync(err_map_out, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return HNET_OK;
+}
+
+int hnet_infer_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                            uint64_t pair_seq0, float* d_mean, float* d_cov, float* d_err_map, void* stream) {
+    if (!c || !d_prev || !d_curr || !d_mean || !d_cov) return HNET_ERR_INVALID_ARG;
+    if (pix_fmt != HNET_PIX_U8 && pix_fmt != HNET_PIX_F32) return fail(c, HNET_ERR_INVALID_ARG, "pix_fmt");
+    if (d_err_map && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    FwdArgs a = {d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_mean, d_cov, d_err_map, nullptr, nullptr, nullptr, nullptr, false};
+    return forward(c, a, stream ? (hipStream_t)stream : c->stream);
+}
+
+int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fmt, const float* prior, int batch,
+                     uint64_t pair_seq0, float* mean, float* cov, float* err_map) {
+    if (!c || !prev || !curr || !mean || !cov) return HNET_ERR_INVALID_ARG;
+    if (pix_fmt != HNET_PIX_U8 && pix_fmt != HNET_PIX_F32) return fail(c, HNET_ERR_INVALID_ARG, "pix_fmt");
+    if (batch < 1) return fail(c, HNET_ERR_INVALID_ARG, "batch < 1");
+    if (batch > c->cfg.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
+    if (err_map && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
+    if (c->cfg.use_prior && !prior) return fail(c, HNET_ERR_INVALID_ARG, "prior required");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t px = pix_fmt == HNET_PIX_U8 ? 1 : 4;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->stage_prev, prev, (size_t)batch * NPIX * px, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->stage_curr, curr, (size_t)batch * NPIX * px, hipMemcpyHostToDevice, s));
+    if (prior) HIPCHK(c, hipMemcpyAsync(c->d_prior, prior, (size_t)batch * 8 * sizeof(float), hipMemcpyHostToDevice, s));
+    FwdArgs a = {c->stage_prev, c->stage_curr, pix_fmt, prior ? c->d_prior : nullptr, batch, pair_seq0, c->d_mean, c->d_cov,
+                 err_map ? c->d_err : nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    int rc = forward(c, a, s);
+    if (rc != HNET_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, s));
+    HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, (size_t)batch * 8 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(cov, c->d_cov, (size_t)batch * 64 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (err_map) HIPCHK(c, hipMemcpyAsync(err_map, c->d_err, (size_t)batch * NPIX * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return HNET_OK;
+}
+
+int hnet_infer_mc_partial_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior,
+                                 int batch, uint64_t pair_seq0, float* d_mean_s, float* d_logvar_s, float* d_h_part1, void* stream) {
+    if (!c || !d_prev || !d_curr || !d_mean_s || !d_logvar_s) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    FwdArgs a = {d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, nullptr, nullptr, nullptr, nullptr, d_mean_s, d_logvar_s, d_h_part1, true};
+    return forward(c, a, stream ? (hipStream_t)stream : c->stream);
+}
+
+int hnet_mc_finish_device(hnet_ctx* c, const float* d_mean_s, const float* d_logvar_s, int n_total, const float* d_h_part1,
+                          int batch, float* d_mean, float* d_cov, void* stream) {
+    if (!c || !d_mean_s || !d_logvar_s || !d_h_part1 || !d_mean || !d_cov || n_total < 1 || batch < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, launch_mc_finish(d_mean_s, d_logvar_s, n_total, d_h_part1, batch, d_mean, d_cov, nullptr,
+                               stream ? (hipStream_t)stream : c->stream));
+    return HNET_OK;
+}
+
+int hnet_synchronize(hnet_ctx* c, void* stream) {
+    if (!c) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+    return HNET_OK;
+}
+
+int hnet_last_timing(const hnet_ctx* c, hnet_timing* out) {
+    if (!c || !out) return HNET_ERR_INVALID_ARG;
+    *out = c->timing;
+    return HNET_OK;
+}
+
+int hnet_time_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                           uint64_t pair_seq0, float* d_mean, float* d_cov, int iters, float* per_iter_ms, float* total_ms) {
+    if (!c || iters < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    std::vector<hipEvent_t> ev(iters + 1);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    int rc = HNET_OK;
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    for (int i = 0; i < iters && rc == HNET_OK; i++) {
+        rc = hnet_infer_batch_device(c, d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0 + (uint64_t)i * batch, d_mean, d_cov, nullptr, nullptr);
+        if (rc == HNET_OK && hipEventRecord(ev[i + 1], c->stream) != hipSuccess) rc = fail(c, HNET_ERR_DEVICE, "hipEventRecord");
+    }
+    if (rc == HNET_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, HNET_ERR_DEVICE, "hipStreamSynchronize");
+    if (rc == HNET_OK) {
+        float tot = 0;
+        for (int i = 0; i < iters; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            if (per_iter_ms) per_iter_ms[i] = ms;
+            tot += ms;
+        }
+        if (total_ms) (void)hipEventElapsedTime(total_ms, ev[0], ev[iters]);
+        (void)tot;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+/* ---- per-stage (per kernel launch) device timing with HIP events on the context stream ---- */
+int hnet_stage_count(const hnet_ctx* c) { return c ? (int)c->stages.size() : 0; }
+const char* hnet_stage_name(const hnet_ctx* c, int i) { return (c && i >= 0 && i < (int)c->stages.size()) ? c->stages[i].name.c_str() : ""; }
+double hnet_stage_flops_per_pair(const hnet_ctx* c, int i) { return (c && i >= 0 && i < (int)c->stages.size()) ? c->stages[i].flops_per_pair : 0.0; }
+
+int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                              uint64_t pair_seq0, float* d_mean, float* d_cov, int iters, float* stage_ms_avg) {
+    if (!c || iters < 1 || !stage_ms_avg) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t ns = c->stages.size();
+    std::vector<double> acc(ns, 0.0);
+    c->prof_ev.resize(ns);
+    for (auto& e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
+    int rc = HNET_OK;
+    for (int it = 0; it < iters && rc == HNET_OK; it++) {
+        c->prof_pos = 0;
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        rc = hnet_infer_batch_device(c, d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
+                                     c->cfg.emit_error_map ? c->d_err : nullptr, nullptr);
+        if (rc != HNET_OK) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, HNET_ERR_DEVICE, "sync"); break; }
+        hipEvent_t prev = c->ev0;
+        for (size_t i = 0; i < c->prof_pos; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, prev, c->prof_ev[i]);
+            acc[i] += ms;
+            prev = c->prof_ev[i];
+        }
+    }
+    for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
+    c->prof_ev.clear();
+    c->prof_pos = 0;
+    for (size_t i = 0; i < ns; i++) stage_ms_avg[i] = (float)(acc[i] / iters);
+    return rc;
+}
+
+/* ---- operator-level entry points (host buffers) ---- */
+int hnet_op_warp(hnet_ctx* c, const float* img, const float* H, float* out) {
+    if (!c || !img || !H || !out) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    float *d_i = nullptr, *d_o = nullptr, *d_h = nullptr;
+    HIPCHK(c, dalloc(&d_i, (size_t)NPIX)); HIPCHK(c, dalloc(&d_o, (size_t)NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
+    HIPCHK(c, hipMemcpy(d_i, img, NPIX * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_warp_f32(d_i, d_h, d_o, 1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_o, NPIX * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_i); (void)hipFree(d_o); (void)hipFree(d_h);
+    return HNET_OK;
+}
+
+int hnet_op_dlt(hnet_ctx* c, const float* dst, int n, float* H) {
+    if (!c || !dst || !H || n < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    float *d_d = nullptr, *d_h = nullptr;
+    HIPCHK(c, dalloc(&d_d, (size_t)n * 8)); HIPCHK(c, dalloc(&d_h, (size_t)n * 9));
+    HIPCHK(c, hipMemcpy(d_d, dst, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_dlt(d_d, d_h, n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(H, d_h, (size_t)n * 36, hipMemcpyDeviceToHost));
+    (void)hipFree(d_d); (void)hipFree(d_h);
+    return HNET_OK;
+}
+
+int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int w, float* out) {
+    if (!c || !in || !out || layer < 0 || layer >= 20 || batch < 1 || h < 1 || w < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const ConvDesc& d = kConvs[layer];
+    const int ho = conv_out_dim(h, d.ks, d.stride), wo = conv_out_dim(w, d.ks, d.stride);
+    const size_t n_in = (size_t)batch * d.cin * h * w, n_out = (size_t)batch * d.cout * ho * wo;
+    float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
+    HIPCHK(c, dalloc(&d_a, n_in)); HIPCHK(c, dalloc(&d_b, n_in)); HIPCHK(c, dalloc(&d_c, n_out)); HIPCHK(c, dalloc(&d_d, n_out));
+    HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
+    HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], d_c, c->stream));
+    HIPCHK(c, launch_nhwc_to_nchw(d_c, d_d, batch, d.cout, ho, wo, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_c); (void)hipFree(d_d);
+    return HNET_OK;
+}
+
+int hnet_op_prep(hnet_ctx* c, const float* img1, const float* img2, const float* H, int k, float* out) {
+    if (!c || !img1 || !img2 || !out || (k != 1 && k != 2 && k != 4 && k != 8)) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int ho = IMG_H / k, wo = IMG_W / k;
+    float *d_1 = nullptr, *d_2 = nullptr, *d_h = nullptr, *d_o = nullptr, *d_t = nullptr;
+    HIPCHK(c, dalloc(&d_1, (size_t)NPIX)); HIPCHK(c, dalloc(&d_2, (size_t)NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
+    HIPCHK(c, dalloc(&d_o, (size_t)2 * ho * wo)); HIPCHK(c, dalloc(&d_t, (size_t)2 * ho * wo));
+    HIPCHK(c, hipMemcpy(d_1, img1, NPIX * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_2, img2, NPIX * 4, hipMemcpyHostToDevice));
+    if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_prep(d_1, d_2, HNET_PIX_F32, H ? d_h : nullptr, k, d_o, 1, c->stream));
+    HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_1); (void)hipFree(d_2); (void)hipFree(d_h); (void)hipFree(d_o); (void)hipFree(d_t);
+    return HNET_OK;
+}
+
+int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t cap) {
+    if (!c || !out || layer < 0 || layer >= 20 || pair < 0 || pair >= c->cfg.max_batch) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t n = (size_t)c->act_c[layer] * c->act_h[layer] * c->act_w[layer];
+    if (cap < n) return fail(c, HNET_ERR_INVALID_ARG, "buffer too small");
+    float* d_t = nullptr;
+    HIPCHK(c, dalloc(&d_t, n));
+    HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_t, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_t);
+    return HNET_OK;
+}
+
+int hnet_debug_h_part1(hnet_ctx* c, int pair, float* out9) {
+    if (!c || !out9 || pair < 0 || pair >= c->cfg.max_batch) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out9, c->Hm + (size_t)pair * 9, 36, hipMemcpyDeviceToHost));
+    return HNET_OK;
+}
+
+}  // extern "C"

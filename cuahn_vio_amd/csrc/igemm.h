@@ -1,0 +1,319 @@
+// igemm.h — implicit-GEMM convolution / masked-FC kernel on fp32 MFMA for gfx950 (CDNA4).
+//
+// C[M][N] = act(A[M][K] * W[N][K]^T + bias[N])
+//   conv : M = B*Ho*Wo output pixels, N = Cout, K = (kh, kw, ci) over an NHWC input; A is gathered on the fly
+//          (reference op: nn.Conv2d + LeakyReLU(0.1), trace_pytorch_model/model_to_trace.py:7-15)
+//   heads: M = B*n_mc (pair, MC sample), N = 512 (two heads x 256 hidden), K = 5120;
+//          A[m][k] = feat[b][k] * keep(mask)/(1-p) generated on the fly
+//          (reference op: Dropout -> Linear(5120,256) -> LeakyReLU, model_to_trace.py:222-225,229-232)
+//
+// Design for CDNA4:
+//   * 256 threads = 4 waves (one per SIMD); v_mfma_f32_32x32x2_f32 (or 16x16x4 for Cout <= 16): exact fp32
+//     fma chain, 64 FLOP/clk/SIMD.
+//   * both operand tiles live in LDS as [rows][BK+4] fp32 (K contiguous).  Staging is one global float4
+//     load + one ds_write_b128 per 4 K-values; fragments are read with ds_read_b128 using a K-permutation:
+//     lane half h of the wave reads K = 8q+4h .. 8q+4h+3 of its row and feeds element i to MFMA step 4q+i.
+//     Both operands use the same permutation so the contraction is unchanged; one LDS read serves 4 MFMAs and
+//     the 36-float row stride makes the b128 reads bank-conflict free.
+//   * register-prefetch double buffering: global loads of tile t+1 are issued before the MFMAs of tile t,
+//     written to the other LDS buffer afterwards; one barrier per K-tile.
+//   * K order of a conv is (kh, [kw, ci]) so that, in NHWC, every (kh) row is one contiguous run of KS*CIN
+//     floats: staging loads are 128-byte contiguous per 8 lanes.  Runs are cut into SEG-float segments
+//     (SEG | 32); weights are pre-packed [Cout][KS][SPR*SEG] with zero padding.
+//   * deterministic: fixed K order, no atomics, no split-K.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hnet_rng.h"
+
+namespace hnet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmParams {
+    const float* A;       // conv: NHWC input [B][H][W][CIN]; heads: feat [B][5120] (NHWC flatten)
+    const float* Wp;      // [N][Kp] packed weights (K contiguous)
+    const float* bias;    // [N]
+    float* out;           // [M][N]
+    int M, N, Kp;
+    int H, W, Ho, Wo;     // conv geometry (input H,W; output Ho,Wo)
+    // heads only
+    int n_local;          // MC samples evaluated by this context
+    int s_begin;          // global index of the first one
+    uint32_t thr;         // drop threshold (24 bit)
+    float scale;          // 1/(1-p)
+    uint64_t mc_seed, pair_seq0;
+};
+
+constexpr int IG_BK = 32;          // K-tile (floats)
+constexpr int IG_BKP = IG_BK + 4;  // LDS row stride (floats): 144 B, keeps ds_read_b128 conflict-free
+
+// ---------------------------------------------------------------------------------------------
+// A-operand loaders
+// ---------------------------------------------------------------------------------------------
+template <int CIN_, int KS_, int STRIDE_, int SEG_>
+struct ConvLoader {
+    static constexpr int CIN = CIN_, KS = KS_, STRIDE = STRIDE_, SEG = SEG_;
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int RL = KS * CIN;                 // floats per (kh) row of the receptive field
+    static constexpr int SPR = (RL + SEG - 1) / SEG;    // segments per row
+    static constexpr int TOTAL_SEGS = KS * SPR;
+    static constexpr int KP = TOTAL_SEGS * SEG;         // padded K
+    static_assert(IG_BK % SEG == 0 && SEG % 4 == 0, "segment must divide the K tile");
+    static_assert(CIN == 2 || CIN % 4 == 0, "CIN must be 2 or a multiple of 4");
+
+    struct Row {
+        int pix0;    // (b*H + iy0)*W + ix0   (may be negative; only used when in range)
+        int iy0, ix0;
+        bool valid;
+    };
+
+    __device__ static inline Row make_row(const IgemmParams& p, int m, int /*n0*/) {
+        Row r;
+        r.valid = m < p.M;
+        int mm = r.valid ? m : 0;
+        int hw = p.Ho * p.Wo;
+        int b = mm / hw;
+        int rem = mm - b * hw;
+        int oy = rem / p.Wo;
+        int ox = rem - oy * p.Wo;
+        r.iy0 = oy * STRIDE - PAD;
+        r.ix0 = ox * STRIDE - PAD;
+        r.pix0 = (b * p.H + r.iy0) * p.W + r.ix0;
+        return r;
+    }
+
+    // 4 consecutive K values starting at padded-K index kp (multiple of 4)
+    __device__ static inline f32x4 load(const IgemmParams& p, const Row& r, int kp) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int sg = kp / SEG;
+        const int within = kp % SEG;
+        const int kh = sg / SPR;
+        const int rr = (sg % SPR) * SEG + within;
+        const int iy = r.iy0 + kh;
+        if (!r.valid || sg >= TOTAL_SEGS || iy < 0 || iy >= p.H) return v;
+        if constexpr (CIN >= 4) {
+            if (RL % SEG != 0 && rr >= RL) return v;
+            const int kw = rr / CIN, ci = rr % CIN;
+            const int ix = r.ix0 + kw;
+            if (ix < 0 || ix >= p.W) return v;
+            const float* src = p.A + ((size_t)(r.pix0 + kh * p.W + kw)) * CIN + ci;
+            v = *reinterpret_cast<const f32x4*>(src);
+        } else {  // CIN == 2: the float4 spans two pixels, each float2 has its own bounds
+            const int kw = rr / 2;
+            const float* src = p.A + ((size_t)(r.pix0 + kh * p.W + kw)) * 2;
+            const int ix = r.ix0 + kw;
+            if (rr < RL && ix >= 0 && ix < p.W) {
+                float2 t = *reinterpret_cast<const float2*>(src);
+                v[0] = t.x; v[1] = t.y;
+            }
+            if (rr + 2 < RL && ix + 1 >= 0 && ix + 1 < p.W) {
+                float2 t = *reinterpret_cast<const float2*>(src + 2);
+                v[2] = t.x; v[3] = t.y;
+            }
+        }
+        return v;
+    }
+};
+
+// MC-dropout input of the heads: A[(b, s)][k] = feat[b][k] * keep(s, k) / (1 - p)
+// feat is the NHWC flatten of [4][5][256]; the mask element id is the reference's NCHW flatten index
+// c*20 + pix (model_to_trace.py:253 `.view(batch_size, -1)` of [256,4,5]).
+struct HeadLoader {
+    static constexpr int KP = 5120;
+    struct Row {
+        const float* feat;
+        uint32_t prefix;
+        bool valid;
+    };
+    __device__ static inline Row make_row(const IgemmParams& p, int m, int n0) {
+        Row r;
+        r.valid = m < p.M;
+        int mm = r.valid ? m : 0;
+        int b = mm / p.n_local;
+        int s = p.s_begin + (mm - b * p.n_local);
+        int head = n0 >> 8;     // columns 0..255 = mean head, 256..511 = uncertainty head
+        r.feat = p.A + (size_t)b * 5120;
+        r.prefix = hnet_mask_prefix(hnet_pair_key(p.mc_seed, p.pair_seq0 + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)s);
+        return r;
+    }
+    __device__ static inline f32x4 load(const IgemmParams& p, const Row& r, int kp) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!r.valid) return v;
+        f32x4 f = *reinterpret_cast<const f32x4*>(r.feat + kp);
+        const int pix = kp >> 8, c = kp & 255;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t e = (uint32_t)((c + i) * 20 + pix);
+            v[i] = hnet_mask_keep(r.prefix, e, p.thr) ? f[i] * p.scale : 0.0f;
+        }
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+template <int MF> struct AccT;
+template <> struct AccT<32> { typedef f32x16 type; };
+template <> struct AccT<16> { typedef f32x4 type; };
+
+template <class L, int BM, int BN, int WGM, int MF>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+    constexpr int BK = IG_BK, BKP = IG_BKP;
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / MF, TN = WN / MF;
+    static_assert(WM % MF == 0 && WN % MF == 0 && TM >= 1 && TN >= 1, "bad wave tile");
+    constexpr int A_ROWS = BM / 32;                  // rows staged per thread (256 threads x float4 = 32 rows x 32 K)
+    constexpr int B_ROWS = (BN + 31) / 32;
+    typedef typename AccT<MF>::type acc_t;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * BKP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int srow = tid >> 3;          // staging row within a 32-row slab
+    const int skk = (tid & 7) * 4;      // staging K offset within the tile
+
+    typename L::Row rows[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, m0 + srow + i * 32, n0);
+
+    const float* wsrc[B_ROWS];
+    bool wvalid[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) {
+        int n = srow + i * 32;
+        wvalid[i] = (n < BN) && (n0 + n < p.N);
+        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? (n0 + n) : 0) * p.Kp + skk;
+    }
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < (MF == 32 ? 16 : 4); r++) acc[i][j][r] = 0.0f;
+
+    f32x4 areg[A_ROWS], breg[B_ROWS];
+    const int n_iter = (p.Kp + BK - 1) / BK;
+
+    auto g_load = [&](int it) {
+        const int kp = it * BK + skk;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) areg[i] = L::load(p, rows[i], kp);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            breg[i] = (wvalid[i] && kp < p.Kp) ? *reinterpret_cast<const f32x4*>(wsrc[i] + it * BK) : z;
+        }
+    };
+    auto s_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++)
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + i * 32) * BKP + skk]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++)
+            if (srow + i * 32 < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + srow + i * 32) * BKP + skk]) = breg[i];
+    };
+
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; it++) {
+        const int buf = it & 1;
+        if (it + 1 < n_iter) g_load(it + 1);
+
+        if constexpr (MF == 32) {
+            const int frow = lane & 31, fk = (lane >> 5) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + wm * WM + i * 32 + frow) * BKP + q * 8 + fk]);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + wn * WN + j * 32 + frow) * BKP + q * 8 + fk]);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int frow = lane & 15, fk = (lane >> 4) * 4;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + wm * WM + i * 16 + frow) * BKP + q * 16 + fk]);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + wn * WN + j * 16 + frow) * BKP + q * 16 + fk]);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        if (it + 1 < n_iter) s_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + LeakyReLU(0.1), NHWC store (lanes run along N = channels)
+    if constexpr (MF == 32) {
+        const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + j * 32 + col;
+            const float bv = n < p.N ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m < p.M && n < p.N) {
+                        float v = acc[i][j][r] + bv;
+                        p.out[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                    }
+                }
+        }
+    } else {
+        const int col = lane & 15, rbase = 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + j * 16 + col;
+            const float bv = n < p.N ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = m0 + wm * WM + i * 16 + rbase + r;
+                    if (m < p.M && n < p.N) {
+                        float v = acc[i][j][r] + bv;
+                        p.out[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace hnet

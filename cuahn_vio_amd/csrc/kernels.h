@@ -1,0 +1,62 @@
+// kernels.h — launch wrappers of the HIP kernels (internal to libhnet_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hnet {
+
+struct ConvDesc {
+    const char* name;
+    int cin, cout, ks, stride;
+    int seg;     // K-segment length used by the packed weights (see igemm.h)
+    int block;   // 1..4
+};
+extern const ConvDesc kConvs[20];
+int conv_padded_k(int layer);    // Kp of the packed weight matrix [Cout][Kp]
+inline int conv_out_dim(int n, int ks, int stride) { return (n + 2 * ((ks - 1) / 2) - ks) / stride + 1; }
+
+// conv + bias + LeakyReLU on NHWC fp32: in [B][H][W][Cin] -> out [B][Ho][Wo][Cout]
+hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, const float* wpacked,
+                       const float* bias, float* out, hipStream_t s);
+
+// first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]
+hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
+                            uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s);
+
+// cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
+hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
+                       int batch, hipStream_t s);
+
+// |warp(img2,H) - img1| * 255 -> float [B][224][320]  (and optional u8 clamp copy)
+hipError_t launch_errmap(const void* img1, const void* img2, int pix_fmt, const float* H, float* out,
+                         uint8_t* out_u8, int batch, hipStream_t s);
+
+// plain warp of a float image (operator-level entry point)
+hipError_t launch_warp_f32(const float* img, const float* H, float* out, int batch, hipStream_t s);
+
+// H[b] = DLT(p4 + prior[b])
+hipError_t launch_prior_dlt(const float* prior, float* H, int batch, hipStream_t s);
+// H[b] = DLT(dst[b])
+hipError_t launch_dlt(const float* dst, float* H, int n, hipStream_t s);
+
+// fc (5120 -> 8) + DLT + compose: H_out = (H_in ? H_in : I) * DLT(p4 + fc)
+hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float* bfc, const float* H_in,
+                               float* H_out, int batch, hipStream_t s);
+
+// second FC of both heads (Dropout -> Linear(256,8)) -> per-sample outputs; optionally the ensemble/transfer
+//   hidden [B*n_local][512]; mean_s/logvar_s [B][n_local][8] (may be nullptr when finish != 0)
+//   finish: also writes mean [B][8], cov [B][64], Htot [B][9] from the n_local samples
+hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
+                            uint64_t pair_seq0, const float* w2, const float* b2, const float* H1,
+                            float* mean_s, float* logvar_s, int finish, float* mean, float* cov, float* Htot,
+                            hipStream_t s);
+
+// ensemble/transfer from gathered per-sample outputs [B][n][8]
+hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
+                            float* mean, float* cov, float* Htot, hipStream_t s);
+
+// layout helpers for the operator-level entry points
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s);
+
+}  // namespace hnet

@@ -1,0 +1,388 @@
+// kernels.hip — the HBM-bound / small kernels of the HomographyNet forward for gfx950:
+//   prep   : cat(img1, warp(img2, H)) -> AvgPool(k) -> NHWC   (fused; the concat is never materialised)
+//   errmap : |warp(img2, H_total) - img1| * 255
+//   block_fc_dlt : Linear(5120,8) + DLT + homography composition, one workgroup per frame pair
+//   heads_fc2    : Dropout -> Linear(256,8) of both heads, per-sample outputs, ensemble + transfer
+// Reference ops are cited at each kernel.
+#include "kernels.h"
+#include "geom.h"
+#include "../../include/hnet.h"
+#include "../../include/hnet_rng.h"
+
+namespace hnet {
+
+// ---------------------------------------------------------------------------------------------
+// pixel access: u8 -> float exactly as `toType(kFloat) / 255.0` (HomographyNet.cpp:141,146) through a
+// 256-entry table in LDS (one IEEE division per entry per workgroup instead of one per tap)
+// ---------------------------------------------------------------------------------------------
+template <typename PIX> struct PixRead;
+template <> struct PixRead<uint8_t> {
+    static constexpr bool kNeedLut = true;
+    __device__ static inline float get(const uint8_t* img, int idx, const float* lut) { return lut[img[idx]]; }
+};
+template <> struct PixRead<float> {
+    static constexpr bool kNeedLut = false;
+    __device__ static inline float get(const float* img, int idx, const float*) { return img[idx]; }
+};
+
+__device__ inline void fill_lut(float* lut) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lut[i] = (float)i / 255.0f;
+    __syncthreads();
+}
+
+// WarpImg.warpSingleImage_H_Mtrx (warp.py:60-79) for one output pixel (u, v):
+//   (X,Y,Z) = H (u,v,1); x = X/Z, y = Y/Z; g = x * 2/(W-1) - 1; grid_sample(bilinear, zeros,
+//   align_corners=True) un-normalises i = ((g+1)/2)*(W-1) and blends the 4 neighbours; taps outside the
+//   image contribute 0.  fp32 throughout like the reference; fp32 division is IEEE (hipcc default).
+template <typename PIX>
+__device__ inline float warp_sample(const PIX* img, const float* h, int u, int v, const float* lut) {
+    const float fu = (float)u, fv = (float)v;
+    const float X = fmaf(h[0], fu, fmaf(h[1], fv, h[2]));
+    const float Y = fmaf(h[3], fu, fmaf(h[4], fv, h[5]));
+    const float Z = fmaf(h[6], fu, fmaf(h[7], fv, h[8]));
+    const float gx = (X / Z) * (float)(2.0 / (IMG_W - 1)) - 1.0f;
+    const float gy = (Y / Z) * (float)(2.0 / (IMG_H - 1)) - 1.0f;
+    const float ix = ((gx + 1.0f) * 0.5f) * (float)(IMG_W - 1);
+    const float iy = ((gy + 1.0f) * 0.5f) * (float)(IMG_H - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    // NaN / far-out coordinates: all taps out of range -> 0 (comparisons with NaN are false)
+    if (!(x0f >= -1.0f && x0f <= (float)IMG_W && y0f >= -1.0f && y0f <= (float)IMG_H)) return 0.0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = ix - x0f, wx0 = 1.0f - wx1, wy1 = iy - y0f, wy0 = 1.0f - wy1;
+    const bool xin0 = x0 >= 0 && x0 < IMG_W, xin1 = x0 + 1 >= 0 && x0 + 1 < IMG_W;
+    const bool yin0 = y0 >= 0 && y0 < IMG_H, yin1 = y0 + 1 >= 0 && y0 + 1 < IMG_H;
+    float s = 0.0f;
+    if (yin0 && xin0) s = fmaf(PixRead<PIX>::get(img, y0 * IMG_W + x0, lut), wx0 * wy0, s);
+    if (yin0 && xin1) s = fmaf(PixRead<PIX>::get(img, y0 * IMG_W + x0 + 1, lut), wx1 * wy0, s);
+    if (yin1 && xin0) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0, lut), wx0 * wy1, s);
+    if (yin1 && xin1) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0 + 1, lut), wx1 * wy1, s);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep: block input = AvgPool_k(cat(img1, warp(img2, H)))   (model_to_trace.py:138-139,153-157,171-175,261-263)
+// K lanes cooperate on one output pixel: lane j sums row j of the k x k window, then a k-lane shuffle tree.
+// Output NHWC [B][224/k][320/k][2] — channel 0 = img1, channel 1 = (warped) img2.
+// ---------------------------------------------------------------------------------------------
+template <typename PIX, int K, bool WARP>
+__global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
+                                                   const float* __restrict__ H, float* __restrict__ out, int batch) {
+    __shared__ float lut[256];
+    if (PixRead<PIX>::kNeedLut) fill_lut(lut);
+    constexpr int HO = IMG_H / K, WO = IMG_W / K;
+    const long total = (long)batch * HO * WO * K;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = idx < total;
+    const long ii = active ? idx : 0;
+    const int j = (int)(ii % K);
+    const long opix = ii / K;
+    const int b = (int)(opix / (HO * WO));
+    const int rem = (int)(opix - (long)b * HO * WO);
+    const int oy = rem / WO, ox = rem - oy * WO;
+    const PIX* i1 = img1 + (size_t)b * NPIX;
+    const PIX* i2 = img2 + (size_t)b * NPIX;
+    float h[9];
+    if (WARP) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+    }
+    const int v = oy * K + j;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < K; a++) {
+        const int u = ox * K + a;
+        s1 += PixRead<PIX>::get(i1, v * IMG_W + u, lut);
+        s2 += WARP ? warp_sample<PIX>(i2, h, u, v, lut) : PixRead<PIX>::get(i2, v * IMG_W + u, lut);
+    }
+#pragma unroll
+    for (int m = 1; m < K; m <<= 1) {
+        s1 += __shfl_xor(s1, m);
+        s2 += __shfl_xor(s2, m);
+    }
+    if (active && j == 0) {
+        constexpr float inv = 1.0f / (float)(K * K);   // power of two: exact
+        float2 o = make_float2(s1 * inv, s2 * inv);
+        *reinterpret_cast<float2*>(out + (size_t)opix * 2) = o;
+    }
+}
+
+template <typename PIX>
+static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s) {
+    const long total = (long)batch * NPIX / k;   // (224/k)*(320/k)*k
+    const int blocks = (int)((total + 255) / 256);
+#define HNET_PREP(KK)                                                                                     \
+    if (H) hipLaunchKernelGGL((prep_kernel<PIX, KK, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, batch); \
+    else hipLaunchKernelGGL((prep_kernel<PIX, KK, false>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, batch);
+    switch (k) {
+        case 1: HNET_PREP(1); break;
+        case 2: HNET_PREP(2); break;
+        case 4: HNET_PREP(4); break;
+        case 8: HNET_PREP(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef HNET_PREP
+    return hipGetLastError();
+}
+
+hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
+                       int batch, hipStream_t s) {
+    if (pix_fmt == HNET_PIX_U8) return prep_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, H, k, out, batch, s);
+    return prep_dispatch<float>((const float*)img1, (const float*)img2, H, k, out, batch, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// error map: |warp(img2, H_total) - img1| * 255   (model_to_trace.py:324-327; u8 clamp HomographyNet.cpp:201)
+// ---------------------------------------------------------------------------------------------
+template <typename PIX>
+__global__ __launch_bounds__(256) void errmap_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
+                                                     const float* __restrict__ H, float* __restrict__ out,
+                                                     uint8_t* __restrict__ out_u8, int batch) {
+    __shared__ float lut[256];
+    if (PixRead<PIX>::kNeedLut) fill_lut(lut);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * NPIX) return;
+    const int b = (int)(idx / NPIX), pix = (int)(idx - (long)b * NPIX);
+    const int v = pix / IMG_W, u = pix - v * IMG_W;
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+    const float w = warp_sample<PIX>(img2 + (size_t)b * NPIX, h, u, v, lut);
+    const float e = fabsf(w - PixRead<PIX>::get(img1 + (size_t)b * NPIX, pix, lut)) * 255.0f;
+    if (out) out[idx] = e;
+    if (out_u8) out_u8[idx] = (uint8_t)fminf(fmaxf(e, 0.0f), 255.0f);   // clamp(0,255).to(kU8) truncates
+}
+
+hipError_t launch_errmap(const void* img1, const void* img2, int pix_fmt, const float* H, float* out,
+                         uint8_t* out_u8, int batch, hipStream_t s) {
+    const int blocks = (int)(((long)batch * NPIX + 255) / 256);
+    if (pix_fmt == HNET_PIX_U8)
+        hipLaunchKernelGGL(errmap_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)img1, (const uint8_t*)img2, H, out, out_u8, batch);
+    else
+        hipLaunchKernelGGL(errmap_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)img1, (const float*)img2, H, out, out_u8, batch);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void warp_f32_kernel(const float* __restrict__ img, const float* __restrict__ H,
+                                                       float* __restrict__ out, int batch) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * NPIX) return;
+    const int b = (int)(idx / NPIX), pix = (int)(idx - (long)b * NPIX);
+    const int v = pix / IMG_W, u = pix - v * IMG_W;
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+    out[idx] = warp_sample<float>(img + (size_t)b * NPIX, h, u, v, nullptr);
+}
+
+hipError_t launch_warp_f32(const float* img, const float* H, float* out, int batch, hipStream_t s) {
+    const int blocks = (int)(((long)batch * NPIX + 255) / 256);
+    hipLaunchKernelGGL(warp_f32_kernel, dim3(blocks), dim3(256), 0, s, img, H, out, batch);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DLT kernels (model_to_trace.py:42-61, :129-130)
+// ---------------------------------------------------------------------------------------------
+__global__ void dlt_kernel(const float* __restrict__ dst_or_prior, float* __restrict__ H, int n, int add_corners) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d[8], h[9];
+    for (int k = 0; k < 8; k++) {
+        const float x = dst_or_prior[i * 8 + k];
+        d[k] = add_corners ? (double)(float)(p4(k) + (double)x) : (double)x;   // p4 + prior is an fp32 tensor op
+    }
+    dlt_solve(d, h);
+    for (int k = 0; k < 9; k++) H[i * 9 + k] = (float)h[k];
+}
+
+hipError_t launch_prior_dlt(const float* prior, float* H, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(dlt_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, prior, H, batch, 1);
+    return hipGetLastError();
+}
+hipError_t launch_dlt(const float* dst, float* H, int n, hipStream_t s) {
+    hipLaunchKernelGGL(dlt_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, H, n, 0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// block tail: fc_block_k = Linear(5120, 8) on the flattened trunk output, corner update, DLT, compose
+//   (model_to_trace.py:143-150, :163-168, :183-188).  One 256-thread workgroup per frame pair; the 8 dot
+//   products are reduced in a fixed order (wave shuffle tree, then 4 partials summed by lane 0).
+//   feat: NHWC flatten [20][256]; wfc is pre-permuted to the same order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_fc_dlt_kernel(const float* __restrict__ feat, const float* __restrict__ wfc,
+                                                           const float* __restrict__ bfc, const float* __restrict__ H_in,
+                                                           float* __restrict__ H_out) {
+    __shared__ float part[4][8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* f = feat + (size_t)b * 5120;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < 20; i++) {
+        const int k = tid + 256 * i;
+        const float x = f[k];
+#pragma unroll
+        for (int o = 0; o < 8; o++) acc[o] = fmaf(x, wfc[o * 5120 + k], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        float v = acc[o];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) part[wave][o] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double dst[8], hb[9], hin[9], ho[9];
+        for (int o = 0; o < 8; o++) {
+            const float fc = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + bfc[o];
+            dst[o] = (double)(float)(p4(o) + (double)fc);
+        }
+        dlt_solve(dst, hb);
+        if (H_in) {
+            for (int i = 0; i < 9; i++) hin[i] = (double)H_in[b * 9 + i];
+            mat3_mul(hin, hb, ho);
+        } else {
+            for (int i = 0; i < 9; i++) ho[i] = hb[i];
+        }
+        for (int i = 0; i < 9; i++) H_out[b * 9 + i] = (float)ho[i];
+    }
+}
+
+hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float* bfc, const float* H_in,
+                               float* H_out, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(block_fc_dlt_kernel, dim3(batch), dim3(256), 0, s, feat, wfc, bfc, H_in, H_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// heads, second half: Dropout -> Linear(256, 8) for both heads and every local MC sample
+//   (model_to_trace.py:226-227,233-234; run_fc :252-256 scales the uncertainty head by 1e-3), then
+//   optionally the ensemble + transfer (geom.h finish_pair).  One workgroup per frame pair.
+//   hidden [B*n_local][512] holds LeakyReLU(Linear(5120,256)) of both heads (columns 0..255 mean head).
+// ---------------------------------------------------------------------------------------------
+constexpr int FC2_CHUNK = 8;   // samples staged in LDS per pass
+
+__global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
+                                                        uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ H1, float* __restrict__ mean_s,
+                                                        float* __restrict__ logvar_s, int finish,
+                                                        float* __restrict__ mean, float* __restrict__ cov,
+                                                        float* __restrict__ Htot) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* w2s = sm;                         // [2][8][256]
+    float* hid = sm + 4096;                  // [FC2_CHUNK][512] after dropout
+    float* outs = hid + FC2_CHUNK * 512;     // [n_local][16]  (8 mean, 8 logvar)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
+    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (uint64_t)b);
+    for (int c0 = 0; c0 < n_local; c0 += FC2_CHUNK) {
+        const int nc = min(FC2_CHUNK, n_local - c0);
+        __syncthreads();
+        for (int i = tid; i < nc * 512; i += 256) {
+            const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
+            const uint32_t pre = hnet_mask_prefix(key, (uint32_t)(2 * head + 1), (uint32_t)(s_begin + c0 + sl));
+            const float v = hidden[((size_t)b * n_local + c0 + sl) * 512 + col];
+            hid[i] = hnet_mask_keep(pre, (uint32_t)j, thr) ? v * scale : 0.0f;
+        }
+        __syncthreads();
+        // 8 samples x 16 outputs = 128 dots of length 256, two threads per dot
+        const int d = tid >> 1, half = tid & 1;
+        const int sl = d >> 4, o = d & 15, head = o >> 3, oi = o & 7;
+        float acc = 0.0f;
+        if (sl < nc) {
+            const float* hrow = hid + sl * 512 + head * 256 + half * 128;
+            const float* wrow = w2s + (head * 8 + oi) * 256 + half * 128;
+#pragma unroll 8
+            for (int j = 0; j < 128; j++) acc = fmaf(hrow[j], wrow[j], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        if (sl < nc && half == 0) {
+            float v = acc + b2[head * 8 + oi];
+            if (head == 1) v *= 1e-3f;
+            outs[(c0 + sl) * 16 + o] = v;
+        }
+    }
+    __syncthreads();
+    // per-sample outputs to global, [B][n_local][8] each
+    if (mean_s && logvar_s)
+        for (int i = tid; i < n_local * 16; i += 256) {
+            const int s = i >> 4, o = i & 15;
+            if (o < 8) mean_s[((size_t)b * n_local + s) * 8 + o] = outs[i];
+            else logvar_s[((size_t)b * n_local + s) * 8 + (o - 8)] = outs[i];
+        }
+    if (finish) {
+        // repack to the [n][8] layout finish_pair expects (in place is not possible: use the hid area)
+        float* ms = hid;                    // n_local*8 <= FC2_CHUNK*512 for n_local <= 512
+        float* ls = hid + n_local * 8;
+        __syncthreads();
+        for (int i = tid; i < n_local * 16; i += 256) {
+            const int s = i >> 4, o = i & 15;
+            if (o < 8) ms[s * 8 + o] = outs[i]; else ls[s * 8 + o - 8] = outs[i];
+        }
+        __syncthreads();
+        if (tid == 0) finish_pair(ms, ls, n_local, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
+    }
+}
+
+hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
+                            uint64_t pair_seq0, const float* w2, const float* b2, const float* H1,
+                            float* mean_s, float* logvar_s, int finish, float* mean, float* cov, float* Htot,
+                            hipStream_t s) {
+    if (n_local < 1 || n_local > 256) return hipErrorInvalidValue;
+    const size_t shmem = (4096 + FC2_CHUNK * 512 + (size_t)n_local * 16) * sizeof(float);
+    hipLaunchKernelGGL(heads_fc2_kernel, dim3(batch), dim3(256), shmem, s, hidden, n_local, s_begin,
+                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, w2, b2, H1, mean_s, logvar_s,
+                       finish, mean, cov, Htot);
+    return hipGetLastError();
+}
+
+__global__ void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
+                                 const float* __restrict__ H1, int batch, float* __restrict__ mean,
+                                 float* __restrict__ cov, float* __restrict__ Htot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    finish_pair(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + b * 8, cov + b * 64,
+                Htot ? Htot + b * 9 : nullptr);
+}
+
+hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
+                            float* mean, float* cov, float* Htot, hipStream_t s) {
+    hipLaunchKernelGGL(mc_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout helpers (operator-level entry points and debug read-back only)
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int c, int hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int ch = (int)(idx % c);
+    const long t = idx / c;
+    const int p = (int)(t % hw), b = (int)(t / hw);
+    out[idx] = in[((size_t)b * c + ch) * hw + p];
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int c, int hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int p = (int)(idx % hw);
+    const long t = idx / hw;
+    const int ch = (int)(t % c), b = (int)(t / c);
+    out[idx] = in[((size_t)b * hw + p) * c + ch];
+}
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s) {
+    const long n = (long)batch * c * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, batch, c, h * w);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s) {
+    const long n = (long)batch * c * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, batch, c, h * w);
+    return hipGetLastError();
+}
+
+}  // namespace hnet

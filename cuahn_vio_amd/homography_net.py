@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference runtime class ``pytorch::HomographyNet``
+(reference cuahn_ros/homography_network/src/HomographyNet.h:23-67, HomographyNet.cpp) and a batched engine,
+both thin wrappers over the C ABI of include/hnet.h (libhnet_hip.so).  No torch on this path.
+
+``HomographyNet`` keeps the reference's method names, argument meaning and "print and carry on" error
+behaviour so the parity tests read like a port of the reference's call sites
+(cuahn/src/core/VioManager.cpp:188,236,258-259).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import PIX_F32, PIX_U8, Config, HnetError, Timing, check, lib  # noqa: F401
+
+IMG_H, IMG_W = 224, 320
+VARIANTS = {"full": (0, 3), "prior3": (1, 3), "prior2": (1, 2), "prior1": (1, 1)}
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class HnetEngine:
+    """One hnet context (one GPU).  `weights` is an HNETW001 blob (bytes) or a path to one."""
+
+    def __init__(self, weights, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1,
+                 emit_error_map=False, device_id=0, mc_shard=None, precision=_capi.PREC_FP32):
+        L = lib()
+        cfg = Config()
+        L.hnet_default_config(C.byref(cfg))
+        cfg.device_id = device_id
+        cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant]
+        cfg.mc_samples, cfg.dropout_p, cfg.mc_seed = mc_samples, dropout_p, mc_seed
+        cfg.emit_error_map, cfg.precision, cfg.max_batch = int(emit_error_map), precision, max_batch
+        if mc_shard is not None:
+            cfg.mc_sample_begin, cfg.mc_sample_end = mc_shard
+        self.cfg, self.variant, self._L = cfg, variant, L
+        self._h = C.c_void_p()
+        if isinstance(weights, (bytes, bytearray)):
+            buf = (C.c_char * len(weights)).from_buffer_copy(weights)
+            rc = L.hnet_create_from_memory(C.byref(cfg), C.cast(buf, C.c_void_p), len(weights), C.byref(self._h))
+        else:
+            rc = L.hnet_create(C.byref(cfg), str(weights).encode(), C.byref(self._h))
+        check(None, rc)
+        self.n_local = (cfg.mc_sample_end - cfg.mc_sample_begin) if mc_shard else mc_samples
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hnet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- batched inference, host buffers -------------------------------------------------------
+    def infer_batch(self, prev, curr, prior=None, pair_seq0=0, want_err=False):
+        prev, curr = np.ascontiguousarray(prev), np.ascontiguousarray(curr)
+        if prev.dtype != curr.dtype or prev.dtype not in (np.uint8, np.float32):
+            raise TypeError("images must both be uint8 or float32")
+        fmt = PIX_U8 if prev.dtype == np.uint8 else PIX_F32
+        b = prev.reshape(-1, IMG_H, IMG_W).shape[0]
+        mean = np.zeros((b, 8), np.float32)
+        cov = np.zeros((b, 8, 8), np.float32)
+        err = np.zeros((b, IMG_H, IMG_W), np.float32) if want_err else None
+        pr = None if prior is None else np.ascontiguousarray(prior, dtype=np.float32).reshape(b, 8)
+        rc = self._L.hnet_infer_batch(self._h, prev.ctypes.data, curr.ctypes.data, fmt, _fp(pr) if pr is not None else None,
+                                      b, pair_seq0, _fp(mean), _fp(cov), _fp(err) if want_err else None)
+        check(self._h, rc)
+        return (mean, cov, err) if want_err else (mean, cov)
+
+    # ---- device-resident entry points (raw device pointers, e.g. torch tensors' data_ptr()) ------
+    def infer_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, d_err=None, stream=None):
+        check(self._h, self._L.hnet_infer_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
+                                                       d_err, stream))
+
+    def infer_mc_partial_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s, d_logvar_s, d_h1, stream=None):
+        check(self._h, self._L.hnet_infer_mc_partial_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s,
+                                                            d_logvar_s, d_h1, stream))
+
+    def mc_finish_device(self, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov, stream=None):
+        check(self._h, self._L.hnet_mc_finish_device(self._h, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov, stream))
+
+    def synchronize(self, stream=None):
+        check(self._h, self._L.hnet_synchronize(self._h, stream))
+
+    def time_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, iters):
+        per = np.zeros(iters, np.float32)
+        tot = C.c_float(0)
+        check(self._h, self._L.hnet_time_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
+                                                      iters, _fp(per), C.byref(tot)))
+        return per, float(tot.value)
+
+    def stages(self):
+        n = self._L.hnet_stage_count(self._h)
+        return [(self._L.hnet_stage_name(self._h, i).decode(), self._L.hnet_stage_flops_per_pair(self._h, i)) for i in range(n)]
+
+    def profile_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, iters):
+        ms = np.zeros(self._L.hnet_stage_count(self._h), np.float32)
+        check(self._h, self._L.hnet_profile_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
+                                                         iters, _fp(ms)))
+        return ms
+
+    def last_timing(self):
+        t = Timing()
+        check(self._h, self._L.hnet_last_timing(self._h, C.byref(t)))
+        return {"device_ms": t.device_ms, "host_ms": t.host_ms, "n_inferences": t.n_inferences,
+                "sum_device_ms_after_100": t.sum_device_ms_after_100}
+
+    # ---- operator-level entry points (NCHW host arrays, like the reference tensors) ---------------
+    def op_warp(self, img, h):
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(IMG_H, IMG_W)
+        hm = np.ascontiguousarray(h, dtype=np.float32).reshape(9)
+        out = np.zeros((IMG_H, IMG_W), np.float32)
+        check(self._h, self._L.hnet_op_warp(self._h, _fp(img), _fp(hm), _fp(out)))
+        return out
+
+    def op_dlt(self, dst):
+        d = np.ascontiguousarray(dst, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((d.shape[0], 3, 3), np.float32)
+        check(self._h, self._L.hnet_op_dlt(self._h, _fp(d), d.shape[0], _fp(out)))
+        return out
+
+    def op_conv(self, layer, x):
+        from .weights import CONV_LAYERS
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        b, cin, h, w = x.shape
+        _n, lcin, cout, k, s = CONV_LAYERS[layer]
+        assert cin == lcin
+        p = (k - 1) // 2
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        out = np.zeros((b, cout, ho, wo), np.float32)
+        check(self._h, self._L.hnet_op_conv(self._h, layer, _fp(x), b, h, w, _fp(out)))
+        return out
+
+    def op_prep(self, img1, img2, h, k):
+        i1 = np.ascontiguousarray(img1, dtype=np.float32).reshape(IMG_H, IMG_W)
+        i2 = np.ascontiguousarray(img2, dtype=np.float32).reshape(IMG_H, IMG_W)
+        hm = None if h is None else np.ascontiguousarray(h, dtype=np.float32).reshape(9)
+        out = np.zeros((2, IMG_H // k, IMG_W // k), np.float32)
+        check(self._h, self._L.hnet_op_prep(self._h, _fp(i1), _fp(i2), _fp(hm) if hm is not None else None, k, _fp(out)))
+        return out
+
+    def debug_layer_output(self, layer, pair=0):
+        """[Cout, Ho, Wo] output of conv layer `layer` from the last forward"""
+        from .weights import CONV_LAYERS
+        buf = np.zeros(8 * IMG_H * IMG_W, np.float32)
+        check(self._h, self._L.hnet_debug_layer_output(self._h, layer, pair, _fp(buf), buf.size))
+        h, w = {1: (28, 40), 2: (56, 80), 3: (112, 160), 4: (224, 320)}[int(CONV_LAYERS[layer][0][6])]
+        for name, _cin, cout, k, s in CONV_LAYERS:
+            if name[6] != CONV_LAYERS[layer][0][6]:
+                continue
+            p = (k - 1) // 2
+            h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+            if name == CONV_LAYERS[layer][0]:
+                return buf[: cout * h * w].reshape(cout, h, w).copy()
+        raise AssertionError
+
+    def debug_h_part1(self, pair=0):
+        out = np.zeros(9, np.float32)
+        check(self._h, self._L.hnet_debug_h_part1(self._h, pair, _fp(out)))
+        return out.reshape(3, 3)
+
+
+class HomographyNet:
+    """Mirror of ``pytorch::HomographyNet`` (HomographyNet.h:23-67).
+
+    HomographyNet(network_model_path, network_model_iterative_path, use_prior, num_of_iteration, show_imgs)
+    — the model path names an HNETW001 weight blob instead of a TorchScript file; as in the reference the
+    substring "_showError" in the path selects the variant that also produces the photometric error map
+    (HomographyNet.cpp:96-100).  The extra keyword arguments expose what the reference freezes at trace time.
+    """
+
+    def __init__(self, network_model_path, network_model_iterative_path="", use_prior=False, num_of_iteration=1,
+                 show_imgs=False, *, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=0, device_id=0,
+                 weights_blob=None):
+        self.use_prior_4pt_offset = bool(use_prior)
+        self.show_phtometric_error = "_showError" in str(network_model_path)
+        self.cv_imshow = bool(show_imgs)
+        self.iteration = num_of_iteration > 1
+        variant = {3: "prior3", 2: "prior2", 1: "prior1"}[blocks_to_run] if use_prior else "full"
+        print("Loading the Network Model (HNETW001 weights) ...")
+        self._eng = HnetEngine(weights_blob if weights_blob is not None else network_model_path, variant=variant,
+                               mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
+                               emit_error_map=self.show_phtometric_error, device_id=device_id)
+        t = self._eng.last_timing()
+        print(f"[TIME]: {t['host_ms']:.4f} milliseconds for the first network inference")
+        self._pred_mean = np.zeros((8, 1), np.float32)
+        self._pred_Cov = np.zeros((8, 8), np.float32)
+        self.last_error_map = None
+
+    @property
+    def img_counter(self):
+        return self._eng._L.hnet_image_count(self._eng.handle)
+
+    def load_current_img(self, img, time_stamp):
+        """HomographyNet.cpp:127-151 — img: 224x320 uint8 (a cv::Mat CV_8UC1 in the reference)"""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.shape != (IMG_H, IMG_W):
+            raise ValueError("expected a 224x320 uint8 image")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        if self.img_counter == 0:
+            print("First Image Comes into the Network Object!")
+        check(self._eng.handle, self._eng._L.hnet_push_image(self._eng.handle, img.ctypes.data, IMG_H, IMG_W,
+                                                              img.strides[0], float(time_stamp)))
+
+    def network_inference(self, prior_4pt_offset_vec, num_of_inference=0):
+        """HomographyNet.cpp:153-252"""
+        mean = np.zeros(8, np.float32)
+        cov = np.zeros((8, 8), np.float32)
+        err = np.zeros((IMG_H, IMG_W), np.uint8) if self.show_phtometric_error else None
+        pr = None
+        if self.use_prior_4pt_offset:
+            pr = np.ascontiguousarray(prior_4pt_offset_vec, dtype=np.float64).reshape(8)
+        rc = self._eng._L.hnet_infer(self._eng.handle, pr.ctypes.data_as(C.POINTER(C.c_double)) if pr is not None else None,
+                                     int(num_of_inference), _fp(mean), _fp(cov),
+                                     err.ctypes.data_as(C.POINTER(C.c_uint8)) if err is not None else None)
+        if rc == _capi.ERR_NOT_READY:   # :155-158 prints and returns with the previous outputs
+            print("HNet cannot inference! Only has one image!")
+            return
+        check(self._eng.handle, rc)
+        self._pred_mean = mean.reshape(8, 1)
+        self._pred_Cov = cov
+        self.last_error_map = err
+        if num_of_inference == 0:
+            t = self._eng.last_timing()
+            if t["n_inferences"] > 100:
+                avg = t["sum_device_ms_after_100"] / (t["n_inferences"] - 100)
+                print(f"[TIME]: {t['device_ms']:.3f} (avg. = {avg:.3f}) milliseconds for pure network inference")
+
+    def get_pred_mean(self):
+        return self._pred_mean.astype(np.float64)
+
+    def get_pred_Cov(self):
+        return self._pred_Cov.astype(np.float64)
+
+    def get_latest_inference_time(self):
+        return self._eng._L.hnet_latest_time(self._eng.handle)

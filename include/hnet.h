@@ -1,0 +1,163 @@
+/* hnet.h — C ABI of the MI355X-native HomographyNet inference path (libhnet_hip.so).
+ *
+ * Drop-in boundary for the reference class `pytorch::HomographyNet`
+ * (reference cuahn_ros/homography_network/src/HomographyNet.h:23-67).  The header-only adapter
+ * include/HomographyNet.h re-creates that class surface on top of these entry points; INTEGRATION.md shows
+ * the binding.  No C++ / torch types cross this boundary: plain pointers, sizes and status codes; every
+ * buffer is caller-owned.  One context per device; a context is NOT thread-safe (the reference object is
+ * driven by a single ROS spin thread, ros_subscribe_cuahn.cpp:123-135).
+ *
+ * Conventions (reference model_to_trace.py:79-83, HomographyNet.cpp:160-165):
+ *   images  : 224 rows x 320 cols, 8-bit gray (or float32 already scaled to [0,1])
+ *   corners : ul, bl, br, ur ; each (u = column, v = row) ; 8 floats in that order
+ *   mean    : total 4-corner offsets img1 -> img2 in pixels (includes the prior), float[8]
+ *   cov     : 8x8 row-major, block diagonal of four 2x2 blocks, symmetric, float[64]
+ *   err map : |warp(img2, H_total) - img1| * 255, clamped to [0,255] when emitted as u8
+ */
+#ifndef HNET_H
+#define HNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNET_IMG_ROWS 224
+#define HNET_IMG_COLS 320
+
+/* status codes */
+enum {
+    HNET_OK = 0,
+    HNET_ERR_INVALID_ARG = 1,
+    HNET_ERR_BAD_WEIGHTS = 2,     /* missing / malformed HNETW001 blob */
+    HNET_ERR_DEVICE = 3,          /* HIP runtime error (hnet_last_error has the text) */
+    HNET_ERR_NOT_READY = 4,       /* fewer than two images pushed (HomographyNet.cpp:155-158) */
+    HNET_ERR_CAPACITY = 5,        /* batch larger than max_batch */
+    HNET_ERR_UNSUPPORTED = 6
+};
+
+enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1 };   /* operand precision of conv / FC contractions */
+enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buffers */
+
+/* Replaces: the variant choice the reference bakes into the traced .pt file
+ * (trace_pytorch_model/trace_model.py:36-46; blocks_to_run model_to_trace.py:72; MC_dropout_num :202;
+ * dropout_rate trace_model.py:16; "_showError" HomographyNet.cpp:96-100). */
+typedef struct hnet_config {
+    uint32_t struct_size;      /* sizeof(hnet_config), for forward compatibility */
+    int32_t  device_id;        /* HIP device ordinal */
+    int32_t  use_prior;        /* 0: full 4-block model.  1: H0 = DLT(prior), then `blocks_to_run` part-1 blocks, then block 4 */
+    int32_t  blocks_to_run;    /* 1..3, the reference attribute (3 = "traced_model_3_blocks_using_prior"); used only with prior */
+    int32_t  mc_samples;       /* N of the MC-dropout ensemble (reference 16) */
+    float    dropout_p;        /* drop probability (reference 0.05); 0 = deterministic */
+    uint64_t mc_seed;          /* key of the mask function, include/hnet_rng.h */
+    int32_t  emit_error_map;   /* 1: "_showError" variant, the photometric error map is computed */
+    int32_t  precision;        /* HNET_PREC_* */
+    int32_t  max_batch;        /* capacity (frame pairs) of the persistent activation buffers, >= 1 */
+    int32_t  mc_sample_begin;  /* this context evaluates global samples [begin, end) in the *_partial entry points; */
+    int32_t  mc_sample_end;    /* 0,0 = all */
+} hnet_config;
+
+typedef struct hnet_ctx hnet_ctx;
+
+typedef struct hnet_timing {
+    double device_ms;          /* "pure network inference": device time of the last forward (HomographyNet.cpp:178-188) */
+    double host_ms;            /* wall time of the last hnet_infer / hnet_infer_batch call, incl. H2D and D2H */
+    int64_t n_inferences;
+    double sum_device_ms_after_100;   /* running sum that skips the first 100 calls (HomographyNet.cpp:245-251) */
+} hnet_timing;
+
+/* fills `cfg` with the reference's launch defaults: full model, N=16, p=0.05, fp32, max_batch 1 */
+void hnet_default_config(hnet_config* cfg);
+
+/* Replaces HomographyNet::load_network_model (HomographyNet.cpp:81-103): `weights_path` names an HNETW001
+ * blob (cuahn_vio_amd/weights.py) instead of a TorchScript .pt.  Also runs the warm-up forward the reference
+ * constructor does (HomographyNet.cpp:28-45). */
+int hnet_create(const hnet_config* cfg, const char* weights_path, hnet_ctx** out);
+int hnet_create_from_memory(const hnet_config* cfg, const void* blob, size_t len, hnet_ctx** out);
+void hnet_destroy(hnet_ctx* ctx);
+
+const char* hnet_status_string(int status);
+const char* hnet_last_error(const hnet_ctx* ctx);   /* text of the last HNET_ERR_DEVICE etc.; never NULL */
+const char* hnet_version(void);
+
+/* Replaces HomographyNet::load_current_img (HomographyNet.cpp:127-151): copies the 224x320 8-bit image
+ * (row_stride in bytes) to the device, prev <- curr, curr <- img; counts images; records `t` from the second
+ * image on. */
+int hnet_push_image(hnet_ctx* ctx, const uint8_t* data, int rows, int cols, int row_stride, double t);
+int hnet_image_count(const hnet_ctx* ctx);             /* the public `img_counter` (HomographyNet.h:33) */
+double hnet_latest_time(const hnet_ctx* ctx);          /* get_latest_inference_time() (HomographyNet.h:31) */
+
+/* Replaces HomographyNet::network_inference (HomographyNet.cpp:153-252) on (prev, curr).
+ * prior_px: 8 doubles (pixels) — required when the context was created with use_prior, else ignored/NULL.
+ * iteration: IEKF iteration index; >0 selects the reference's "iterative" model, which is the same network
+ *            run again with the updated prior, so it is accepted and otherwise ignored.
+ * err_map_out: NULL or 224*320 bytes (needs emit_error_map).  Returns HNET_ERR_NOT_READY before 2 images. */
+int hnet_infer(hnet_ctx* ctx, const double* prior_px, int iteration,
+               float mean_out[8], float cov_out[64], uint8_t* err_map_out);
+
+/* Batched frame pairs, host buffers: prev/curr [B][224][320] (pix_fmt), prior [B][8] floats or NULL,
+ * pair_seq0 = sequence number of pair 0 (pair b uses pair_seq0 + b in the mask key),
+ * mean [B][8], cov [B][64], err_map [B][224][320] float or NULL.  Semantics = the batch-1 reference applied
+ * independently to each pair (the reference itself is batch-1 only, warp.py:64). */
+int hnet_infer_batch(hnet_ctx* ctx, const void* prev, const void* curr, int pix_fmt, const float* prior,
+                     int batch, uint64_t pair_seq0, float* mean, float* cov, float* err_map);
+
+/* Same with every buffer resident in device memory; enqueues on `stream` (a hipStream_t, NULL = default
+ * stream of the context) and does not synchronise. */
+int hnet_infer_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
+                            const float* d_prior, int batch, uint64_t pair_seq0,
+                            float* d_mean, float* d_cov, float* d_err_map, void* stream);
+
+/* MC-dropout sharding: the trunk runs on every rank, the heads only for this context's
+ * global samples [mc_sample_begin, mc_sample_end).  Outputs per pair: mean_s / logvar_s
+ * [B][n_local][8] and H_part1 [B][9].  After gathering all N samples (rank order = sample order) the
+ * ensemble is finished with hnet_mc_finish_device in the reference's two-pass order
+ * (model_to_trace.py:274-280). */
+int hnet_infer_mc_partial_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
+                                 const float* d_prior, int batch, uint64_t pair_seq0,
+                                 float* d_mean_s, float* d_logvar_s, float* d_h_part1, void* stream);
+int hnet_mc_finish_device(hnet_ctx* ctx, const float* d_mean_s, const float* d_logvar_s, int n_total,
+                          const float* d_h_part1, int batch, float* d_mean, float* d_cov, void* stream);
+
+int hnet_synchronize(hnet_ctx* ctx, void* stream);
+int hnet_last_timing(const hnet_ctx* ctx, hnet_timing* out);
+
+/* Device-time measurement of `iters` back-to-back forwards on resident buffers (HIP events on the
+ * context's stream).  per_iter_ms may be NULL.  Used by bench.py for latency percentiles. */
+int hnet_time_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
+                           const float* d_prior, int batch, uint64_t pair_seq0, float* d_mean, float* d_cov,
+                           int iters, float* per_iter_ms, float* total_ms);
+
+/* Per-stage device timing: a "stage" is one kernel launch of the forward (prep / conv layer / fc+DLT / heads).
+ * hnet_profile_batch_device runs `iters` forwards with a HIP event after every launch on the context's stream
+ * and returns the average milliseconds per stage ([hnet_stage_count] floats).  flops_per_pair = 2 x MACs. */
+int hnet_stage_count(const hnet_ctx* ctx);
+const char* hnet_stage_name(const hnet_ctx* ctx, int i);
+double hnet_stage_flops_per_pair(const hnet_ctx* ctx, int i);
+int hnet_profile_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
+                              const float* d_prior, int batch, uint64_t pair_seq0, float* d_mean, float* d_cov,
+                              int iters, float* stage_ms_avg);
+
+/* ---- operator-level entry points (parity tests of single kernels; host buffers, NCHW like the reference) ---- */
+
+/* warp.py:60-79 — img [224][320] float32, H[9] -> out [224][320] */
+int hnet_op_warp(hnet_ctx* ctx, const float* img, const float* H, float* out);
+/* model_to_trace.py:42-61 — dst corners [n][8] -> H [n][9] */
+int hnet_op_dlt(hnet_ctx* ctx, const float* dst, int n, float* H);
+/* conv layer `layer` (0..19, execution order of cuahn_vio_amd/weights.py CONV_LAYERS) with its own weights:
+ * in [B][Cin][H][W] -> out [B][Cout][Ho][Wo], + bias + LeakyReLU(0.1)   (model_to_trace.py:7-15) */
+int hnet_op_conv(hnet_ctx* ctx, int layer, const float* in, int batch, int h, int w, float* out);
+/* cat(img1, warp(img2,H)) -> AvgPool(k): img1,img2 [224][320] f32, H[9] or NULL (no warp), k in {1,2,4,8}
+ * -> out [2][224/k][320/k]   (model_to_trace.py:153-157) */
+int hnet_op_prep(hnet_ctx* ctx, const float* img1, const float* img2, const float* H, int k, float* out);
+/* after a forward: copies the output of layer `layer` (0..19 convs) of pair `pair` as [Cout][Ho][Wo] */
+int hnet_debug_layer_output(hnet_ctx* ctx, int layer, int pair, float* out, size_t capacity_floats);
+/* after a forward: part-1 homography of pair `pair`, 9 floats */
+int hnet_debug_h_part1(hnet_ctx* ctx, int pair, float* out9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNET_H */

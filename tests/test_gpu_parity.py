@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/hnet.h) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors of the reference model, and through size-independent
+properties at full batch sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import (GOLDEN_DIR, TOL_COV_REL, TOL_PX_VS_ORACLE, TOL_PX_VS_REF32, TOL_PX_VS_REF64, golden_cases,
+                      load_case)
+
+pytestmark = pytest.mark.gpu
+
+MC_SEED = 0x5EED5EED12345678
+
+
+@pytest.fixture(scope="module")
+def eng_full(blob):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    e = HnetEngine(blob, variant="full", mc_samples=16, dropout_p=0.0, max_batch=8, emit_error_map=True)
+    yield e
+    e.close()
+
+
+def _engine_for(blob, g, max_batch=1):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    return HnetEngine(blob, variant=str(g["variant"]), mc_samples=int(g["n_mc"]), dropout_p=float(g["p"]),
+                      mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0, max_batch=max_batch, emit_error_map=True)
+
+
+# ---------------------------------------------------------------------------------------------- operators
+def test_op_dlt(eng_full):
+    from oracle import pyoracle
+    g = np.load(os.path.join(GOLDEN_DIR, "dlt.npz"))
+    p4 = np.array([0, 0, 0, 223, 319, 223, 319, 0], np.float32)
+    dst = p4[None] + g["offsets"].reshape(-1, 8)
+    h = eng_full.op_dlt(dst)
+    for i in range(dst.shape[0]):
+        ho = pyoracle.dlt(dst[i])
+        assert np.abs(h[i] - ho).max() / np.abs(ho).max() < 1e-6
+        assert np.abs(h[i] - g["H"][i]).max() / np.abs(g["H"][i]).max() < 1e-5
+        q = h[i].astype(np.float64) @ np.c_[p4.reshape(4, 2), np.ones(4)].T
+        assert np.abs((q[:2] / q[2]).T - dst[i].reshape(4, 2)).max() < 5e-5
+
+
+def test_op_warp_golden_and_oracle(eng_full):
+    from cuahn_vio_amd import synth
+    from oracle import pyoracle
+    g = np.load(os.path.join(GOLDEN_DIR, "warp_s11.npz"))
+    _i1, i2, _ = synth.make_pair(int(g["seed"]))
+    f2 = pyoracle.as_f32_image(i2)
+    for name in ("identity", "shift", "oob", "persp"):
+        w = eng_full.op_warp(f2, g["H_" + name])
+        assert np.abs(w[::2, ::2] - g["w_" + name]).max() < 2e-4, name       # reference grid_sample
+        assert np.abs(w - pyoracle.warp(f2, g["H_" + name])).max() < 2e-4, name
+    assert (eng_full.op_warp(f2, g["H_oob"])[:, 150:] == 0).all()            # zeros padding
+    # degenerate homography (Z = 0 everywhere): no NaN leaves the kernel... grid_sample yields 0 for NaN coords
+    hz = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)
+    assert np.isfinite(eng_full.op_warp(f2, hz)).all()
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_op_prep(eng_full, k):
+    from cuahn_vio_amd import synth
+    from oracle import pyoracle
+    i1, i2, off = synth.make_pair(12)
+    f1, f2 = pyoracle.as_f32_image(i1), pyoracle.as_f32_image(i2)
+    h = pyoracle.dlt(np.array([0, 0, 0, 223, 319, 223, 319, 0], np.float32) + off.astype(np.float32))
+    for hm in (None, h):
+        got = eng_full.op_prep(f1, f2, hm, k)
+        w = f2 if hm is None else pyoracle.warp(f2, hm)
+        ref = pyoracle.avgpool(np.stack([f1, w]), k)
+        assert np.abs(got - ref).max() < 2e-4 / k
+    assert np.abs(eng_full.op_prep(f1, f2, None, k)[0] - pyoracle.avgpool(f1[None], k)[0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("layer", list(range(20)))
+def test_op_conv_each_layer(eng_full, state, layer):
+    """every conv layer with its real geometry, batch 2 (ragged M: not a multiple of the tile), vs oracle conv"""
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    from oracle import pyoracle
+    name, cin, cout, k, s = CONV_LAYERS[layer]
+    blk = int(name[6])
+    h, w = {1: (28, 40), 2: (56, 80), 3: (112, 160), 4: (224, 320)}[blk]
+    for n2, _ci, _co, k2, s2 in CONV_LAYERS:
+        if n2 == name:
+            break
+        if n2[6] == name[6]:
+            p2 = (k2 - 1) // 2
+            h, w = (h + 2 * p2 - k2) // s2 + 1, (w + 2 * p2 - k2) // s2 + 1
+    rng = np.random.default_rng(layer)
+    x = rng.standard_normal((2, cin, h, w)).astype(np.float32)
+    prefix = "model_last_block_list.0." if blk == 4 else "model_part1."
+    wgt, bias = state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"]
+    got = eng_full.op_conv(layer, x)
+    for b in range(2):
+        ref = pyoracle.conv_lrelu(x[b], wgt, bias, s)
+        assert got[b].shape == ref.shape
+        err = np.abs(got[b] - ref).max()
+        assert err < 2e-5 * max(1.0, np.abs(ref).max()), f"{name}: {err}"
+
+
+def test_op_conv_small_ragged_shapes(eng_full, state):
+    """odd spatial sizes (7x10 -> 4x5 is the reference's own odd case) and tiny inputs"""
+    from oracle import pyoracle
+    rng = np.random.default_rng(99)
+    for layer, (h, w) in ((19, (7, 10)), (19, (1, 1)), (14, (5, 3)), (13, (9, 11)), (8, (6, 7))):
+        from cuahn_vio_amd.weights import CONV_LAYERS
+        name, cin, cout, k, s = CONV_LAYERS[layer]
+        x = rng.standard_normal((3, cin, h, w)).astype(np.float32)
+        prefix = "model_last_block_list.0." if name[6] == "4" else "model_part1."
+        got = eng_full.op_conv(layer, x)
+        for b in range(3):
+            ref = pyoracle.conv_lrelu(x[b], state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"], s)
+            assert np.abs(got[b] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------------- full forward
+@pytest.mark.parametrize("name", golden_cases())
+def test_forward_golden(blob, oracle, name):
+    g, i1, i2, prior, btr = load_case(name)
+    eng = _engine_for(blob, g)
+    seq = int(g["pair_seq"]) if "pair_seq" in g else 0
+    mean, cov, err = eng.infer_batch(i1[None], i2[None], None if prior is None else prior[None], pair_seq0=seq, want_err=True)
+    o = oracle.forward(i1, i2, prior, btr, int(g["n_mc"]), float(g["p"]), int(g["mc_seed"]) if "mc_seed" in g else 0, seq,
+                       want_err=True, want_trace=True)
+    d32 = np.abs(mean[0] - g["mean"]).max()
+    d64 = np.abs(mean[0] - g["mean64"]).max()
+    dor = np.abs(mean[0] - o["mean"]).max()
+    print(f"{name}: |hip-ref32|={d32:.2e} |hip-ref64|={d64:.2e} |hip-oracle|={dor:.2e} px")
+    assert d32 < TOL_PX_VS_REF32 and d64 < TOL_PX_VS_REF64 and dor < TOL_PX_VS_ORACLE
+    for ref in (g["cov"], g["cov64"], o["cov"]):
+        assert np.abs(cov[0] - ref).max() / np.abs(ref).max() < TOL_COV_REL
+    assert np.abs(eng.debug_h_part1(0) - g["H_part1_64"]).max() < 2e-5
+    # photometric error map
+    assert np.abs(err[0][::4, ::4] - g["err_ds4"]).max() < 0.1
+    assert abs(err[0].astype(np.float64).sum() - g["err_stats64"][0]) / g["err_stats64"][0] < 2e-5
+    # per-layer activations of the HIP path vs the reference's layer statistics
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    for li, (lname, *_r) in enumerate(CONV_LAYERS):
+        key = "L_" + lname
+        if key not in g:
+            continue
+        a = eng.debug_layer_output(li, 0).astype(np.float64).reshape(-1)
+        ref = g[key]
+        assert a.size == ref[2]
+        assert abs(np.sqrt((a * a).sum()) - ref[1]) / ref[1] < 2e-5, lname
+        idx = (np.arange(16, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(a.size)
+        assert np.abs(a[idx.astype(np.int64)] - ref[3:]).max() / (np.abs(ref[3:]).max() + 1e-20) < 2e-4, lname
+    eng.close()
+
+
+def test_batch_equals_per_pair_and_is_slot_invariant(blob, oracle):
+    """batched semantics = the batch-1 reference applied to each pair; a pair's result does not depend on its
+    slot or on its neighbours (bitwise)"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, prior, _ = synth.make_batch(20, 5)
+    eng = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=8)
+    mean, cov = eng.infer_batch(prev, curr, prior, pair_seq0=100)
+    for b in range(5):
+        o = oracle.forward(prev[b], curr[b], prior[b], 3, 16, 0.05, MC_SEED, 100 + b)
+        assert np.abs(mean[b] - o["mean"]).max() < TOL_PX_VS_ORACLE
+        assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL
+    # pair 3 alone, with its own sequence number, in slot 0
+    m1, c1 = eng.infer_batch(prev[3:4], curr[3:4], prior[3:4], pair_seq0=103)
+    assert np.array_equal(m1[0], mean[3]) and np.array_equal(c1[0], cov[3])
+    # reversed batch order (each pair keeps its pair_seq only if we pass them one by one)
+    for b in (0, 4):
+        mb, cb = eng.infer_batch(prev[b:b + 1], curr[b:b + 1], prior[b:b + 1], pair_seq0=100 + b)
+        assert np.array_equal(mb[0], mean[b]) and np.array_equal(cb[0], cov[b])
+    # run-to-run determinism
+    mean2, cov2 = eng.infer_batch(prev, curr, prior, pair_seq0=100)
+    assert np.array_equal(mean, mean2) and np.array_equal(cov, cov2)
+    eng.close()
+
+
+def test_streaming_class_matches_batch_api(blob, tmp_path):
+    """the HomographyNet mirror (load_current_img / network_inference / getters) against the batch entry point"""
+    from cuahn_vio_amd import synth, weights
+    from cuahn_vio_amd.homography_net import HnetEngine, HomographyNet
+    path = str(tmp_path / "weights_showError.hnw")
+    with open(path, "wb") as f:
+        f.write(blob)
+    net = HomographyNet(path, "", use_prior=True, num_of_iteration=1, show_imgs=False, dropout_p=0.05, mc_seed=MC_SEED)
+    assert net.show_phtometric_error
+    frames = [synth.make_pair(30 + i)[0] for i in range(3)]
+    prior = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.25, 2.0, -0.75])
+    net.network_inference(prior, 0)                       # no image yet: prints, leaves outputs untouched
+    assert net.img_counter == 0 and not net.get_pred_mean().any()
+    net.load_current_img(frames[0], 1.0)
+    net.network_inference(prior, 0)                       # one image: still not ready (HomographyNet.cpp:155-158)
+    assert net.get_latest_inference_time() == -1.0 and not net.get_pred_mean().any()
+    eng = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=1, emit_error_map=True)
+    for i in (1, 2):
+        net.load_current_img(frames[i], 1.0 + i)
+        net.network_inference(prior, 0)
+        assert net.img_counter == i + 1 and net.get_latest_inference_time() == 1.0 + i
+        m, c, e = eng.infer_batch(frames[i - 1][None], frames[i][None], prior[None].astype(np.float32), pair_seq0=i - 1, want_err=True)
+        assert net.get_pred_mean().shape == (8, 1) and net.get_pred_Cov().shape == (8, 8)
+        assert np.array_equal(net.get_pred_mean().reshape(8).astype(np.float32), m[0])
+        assert np.array_equal(net.get_pred_Cov().astype(np.float32), c[0])
+        assert np.array_equal(net.last_error_map, np.clip(e[0], 0, 255).astype(np.uint8))
+    # strided image rows (cv::Mat step > cols)
+    wide = np.zeros((224, 384), np.uint8)
+    wide[:, :320] = frames[0]
+    net.load_current_img(wide[:, :320], 9.0)
+    net.network_inference(prior, 0)
+    m, c = eng.infer_batch(frames[2][None], frames[0][None], prior[None].astype(np.float32), pair_seq0=2)
+    assert np.array_equal(net.get_pred_mean().reshape(8).astype(np.float32), m[0])
+    eng.close()
+
+
+def test_mc_sharding_is_rank_invariant(blob, oracle):
+    """N=32 samples split over 4 contexts (as 4 ranks would) + finish == one context with all 32, bitwise;
+    and both match the oracle"""
+    import torch
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
+    prev, curr, _prior, _ = synth.make_batch(40, 2)
+    n = 32
+    full = HnetEngine(blob, variant="full", mc_samples=n, dropout_p=0.05, mc_seed=MC_SEED, max_batch=2)
+    mean_ref, cov_ref = full.infer_batch(prev, curr, pair_seq0=7)
+    dev = torch.device("cuda:0")
+    tp, tc = torch.from_numpy(prev).to(dev), torch.from_numpy(curr).to(dev)
+    ms_all = torch.zeros(2, n, 8, device=dev)
+    lv_all = torch.zeros(2, n, 8, device=dev)
+    h1 = torch.zeros(2, 9, device=dev)
+    shards = []
+    for r in range(4):
+        e = HnetEngine(blob, variant="full", mc_samples=n, dropout_p=0.05, mc_seed=MC_SEED, max_batch=2, mc_shard=(8 * r, 8 * r + 8))
+        ms = torch.zeros(2, 8, 8, device=dev)
+        lv = torch.zeros(2, 8, 8, device=dev)
+        e.infer_mc_partial_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, None, 2, 7, ms.data_ptr(), lv.data_ptr(), h1.data_ptr())
+        e.synchronize()
+        ms_all[:, 8 * r:8 * r + 8] = ms
+        lv_all[:, 8 * r:8 * r + 8] = lv
+        shards.append(e)
+    mean = torch.zeros(2, 8, device=dev)
+    cov = torch.zeros(2, 64, device=dev)
+    full.mc_finish_device(ms_all.data_ptr(), lv_all.data_ptr(), n, h1.data_ptr(), 2, mean.data_ptr(), cov.data_ptr())
+    full.synchronize()
+    assert np.array_equal(mean.cpu().numpy(), mean_ref)
+    assert np.array_equal(cov.cpu().numpy().reshape(2, 8, 8), cov_ref)
+    for b in range(2):
+        o = oracle.forward(prev[b], curr[b], None, 3, n, 0.05, MC_SEED, 7 + b)
+        assert np.abs(mean_ref[b] - o["mean"]).max() < TOL_PX_VS_ORACLE
+    for e in shards:
+        e.close()
+    full.close()
+
+
+def test_device_resident_entry_point_and_timing(blob):
+    import torch
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
+    prev, curr, _p, _ = synth.make_batch(50, 4)
+    eng = HnetEngine(blob, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=1, max_batch=4)
+    mean_h, cov_h = eng.infer_batch(prev, curr, pair_seq0=0)
+    dev = torch.device("cuda:0")
+    tp, tc = torch.from_numpy(prev).to(dev), torch.from_numpy(curr).to(dev)
+    mean = torch.zeros(4, 8, device=dev)
+    cov = torch.zeros(4, 64, device=dev)
+    eng.infer_batch_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, None, 4, 0, mean.data_ptr(), cov.data_ptr())
+    eng.synchronize()
+    assert np.array_equal(mean.cpu().numpy(), mean_h) and np.array_equal(cov.cpu().numpy().reshape(4, 8, 8), cov_h)
+    per, tot = eng.time_batch_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, None, 4, 0, mean.data_ptr(), cov.data_ptr(), 3)
+    assert (per > 0).all() and tot >= per.sum() * 0.5
+    ms = eng.profile_batch_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, None, 4, 0, mean.data_ptr(), cov.data_ptr(), 2)
+    names = [n for n, _ in eng.stages()]
+    assert len(ms) == len(names) == 29 and (ms > 0).all()
+    assert abs(sum(f for _, f in eng.stages()) - 1.0882e9) < 2e6       # 1.0882 GFLOP per pair, N=16
+    eng.close()
+
+
+def test_error_behaviour(blob):
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine, HnetError
+    prev, curr, prior, _ = synth.make_batch(60, 3)
+    eng = HnetEngine(blob, variant="prior3", max_batch=2)
+    with pytest.raises(HnetError) as ei:
+        eng.infer_batch(prev, curr, prior)                 # 3 > max_batch
+    assert ei.value.status == 5
+    with pytest.raises(HnetError):
+        eng.infer_batch(prev[:2], curr[:2], None)          # prior missing
+    with pytest.raises(HnetError):
+        eng.infer_batch(prev[:1], curr[:1], prior[:1], want_err=True)   # no error map in this context
+    eng.close()
+    with pytest.raises(HnetError) as ei:
+        HnetEngine(b"not a blob at all", variant="full")
+    assert ei.value.status == 2
+
+
+def test_properties_at_full_batch(blob):
+    """size-independent properties at the benchmark batch: identical pairs give identical outputs in every
+    slot; identical frames with a zero prior and p=0 give a symmetric, finite, positive semi-definite cov"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    B = 64
+    i1, i2, off = synth.make_pair(70)
+    prev = np.repeat(i1[None], B, 0)
+    curr = np.repeat(i2[None], B, 0)
+    eng = HnetEngine(blob, variant="full", mc_samples=32, dropout_p=0.0, max_batch=B)
+    mean, cov = eng.infer_batch(prev, curr)
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    assert (mean == mean[0]).all() and (cov == cov[0]).all()
+    for b in (0, B - 1):
+        assert np.allclose(cov[b], cov[b].T, atol=1e-7)
+        assert np.linalg.eigvalsh(cov[b].astype(np.float64)).min() > -1e-7
+    eng.close()

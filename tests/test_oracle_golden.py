@@ -1,0 +1,126 @@
+"""CPU: the oracle (oracle/hnet_oracle.c) against every golden vector produced by the reference model
+(tools/gen_golden.py).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, TOL_COV_REL, golden_cases, load_case
+from oracle import pyoracle
+
+
+def _run(orc, name):
+    g, i1, i2, prior, btr = load_case(name)
+    o = orc.forward(i1, i2, prior, btr, int(g["n_mc"]), float(g["p"]),
+                    int(g["mc_seed"]) if "mc_seed" in g else 0, int(g["pair_seq"]) if "pair_seq" in g else 0,
+                    want_err=True, want_trace=True)
+    return g, o
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_matches_reference(oracle, name):
+    g, o = _run(oracle, name)
+    # offsets: the double-accumulating oracle tracks the reference's fp64 evaluation; the fp32 golden sits
+    # up to 1.4e-4 px from that (tools/gen_golden.py prints the floor)
+    assert np.abs(o["mean"] - g["mean64"]).max() < 1e-4
+    assert np.abs(o["mean"] - g["mean"]).max() < 2e-4
+    assert np.abs(o["cov"] - g["cov64"]).max() / np.abs(g["cov64"]).max() < TOL_COV_REL
+    assert np.abs(o["cov"] - g["cov"]).max() / np.abs(g["cov"]).max() < TOL_COV_REL
+    # block-diagonal structure, symmetric (model_to_trace.py:313-317)
+    c = o["cov"]
+    assert np.allclose(c, c.T, rtol=0, atol=1e-7)
+    mask = np.kron(np.eye(4), np.ones((2, 2))) == 0
+    assert (c[mask] == 0).all()
+    # part-1 homography
+    assert np.abs(o["H_part1"] - g["H_part1_64"]).max() < 2e-5
+    # every layer the reference ran: L2 norm and 16 sampled activations
+    n_checked = 0
+    for lname, st in o["layer_stats"].items():
+        key = "L_" + lname
+        if key not in g:
+            assert np.isnan(st[0]), f"{lname} ran in the oracle but not in the reference"
+            continue
+        ref = g[key]
+        assert st[2] == ref[2], f"{lname}: element count"
+        assert abs(st[1] - ref[1]) / ref[1] < 2e-5, f"{lname}: L2"
+        assert np.abs(st[3:] - ref[3:]).max() / (np.abs(ref[3:]).max() + 1e-20) < 1e-4, f"{lname}: samples"
+        n_checked += 1
+    assert n_checked == sum(1 for k in g if k.startswith("L_"))
+    # DLT destinations (p4 + fc) of each call
+    nd = o["dlt_dst"].shape[0]
+    assert np.abs(o["dlt_dst"] - g["dlt_dst64"][:nd]).max() < 1e-4
+    # photometric error map (x255 units): coordinates differ by ~1e-4 px, gradients reach 255 / px
+    assert np.abs(o["err"][::4, ::4] - g["err_ds4"]).max() < 0.08
+    assert abs(np.abs(o["err"]).sum() - g["err_stats64"][0]) / g["err_stats64"][0] < 1e-5
+
+
+@pytest.mark.parametrize("name", ["full_p0_s1", "prior3_mask16_s10", "const_prior10"])
+def test_oracle_f32_build_matches_reference(oracle_f32, name):
+    """the plain-fp32 build (the timed CPU port) stays within the reference's own fp32 noise"""
+    g, o = _run(oracle_f32, name)
+    assert np.abs(o["mean"] - g["mean"]).max() < 4e-4
+    assert np.abs(o["cov"] - g["cov"]).max() / np.abs(g["cov"]).max() < 1e-4
+
+
+def test_dlt_golden():
+    g = np.load(os.path.join(GOLDEN_DIR, "dlt.npz"))
+    p4 = np.array([0, 0, 0, 223, 319, 223, 319, 0], np.float32)
+    for off, href in zip(g["offsets"], g["H"]):
+        h = pyoracle.dlt(p4 + off.reshape(8))
+        # compare through the corner mapping (H entries span 1e-6 .. 1e2)
+        for hh in (h, href):
+            q = hh.astype(np.float64) @ np.c_[p4.reshape(4, 2), np.ones(4)].T
+            assert np.abs((q[:2] / q[2]).T - (p4 + off.reshape(8)).reshape(4, 2)).max() < 3e-4
+        assert np.abs(h - href).max() / np.abs(href).max() < 1e-5
+
+
+def test_warp_golden():
+    from cuahn_vio_amd import synth
+    g = np.load(os.path.join(GOLDEN_DIR, "warp_s11.npz"))
+    _i1, i2, _ = synth.make_pair(int(g["seed"]))
+    assert synth.crc(i2) == int(g["in_crc"])
+    for name in ("identity", "shift", "oob", "persp"):
+        w = pyoracle.warp(i2, g["H_" + name])
+        assert np.abs(w[::2, ::2] - g["w_" + name]).max() < 2e-4, name
+        assert abs(w.astype(np.float64).sum() - g["s_" + name][0]) <= 1e-5 * max(g["s_" + name][0], 1.0), name
+    # identity warp reproduces the image, out-of-bounds warp is mostly zero (padding_mode='zeros')
+    assert np.abs(pyoracle.warp(i2, np.eye(3)) - pyoracle.as_f32_image(i2)).max() < 1e-5
+    assert (pyoracle.warp(i2, g["H_oob"])[:, 150:] == 0).all()
+
+
+def test_heads_match_numpy_mask_function(oracle, state):
+    """oracle_heads (C mask function from include/hnet_rng.h) == numpy heads with cuahn_vio_amd.mcdrop masks"""
+    from cuahn_vio_amd import mcdrop
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal(5120).astype(np.float32)
+    seed, seq, p, n = 0xABCDEF0123, 42, 0.05, 6
+    m, lv = oracle.heads(feat, 0, n, p, seed, seq)
+    sc = float(mcdrop.scale(p))
+    lb = "model_last_block_list.0."
+    for h, (head, s_in, s_hid) in enumerate((("fc_block_4_mean", 0, 1), ("fc_block_4_uncertainty", 2, 3))):
+        k_in = mcdrop.keep_mask(seed, seq, s_in, n, 5120, p)
+        k_hid = mcdrop.keep_mask(seed, seq, s_hid, n, 256, p)
+        x = feat[None, :].astype(np.float64) * k_in * sc
+        hid = x @ state[lb + head + ".1.weight"].astype(np.float64).T + state[lb + head + ".1.bias"]
+        hid = np.where(hid > 0, hid, 0.1 * hid) * k_hid * sc
+        out = hid @ state[lb + head + ".4.weight"].astype(np.float64).T + state[lb + head + ".4.bias"]
+        ref = out if h == 0 else out * 1e-3
+        got = m if h == 0 else lv
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    # sharding invariance: samples [2,5) computed alone equal the slice of the full run
+    m2, lv2 = oracle.heads(feat, 2, 5, p, seed, seq)
+    assert np.array_equal(m2, m[2:5]) and np.array_equal(lv2, lv[2:5])
+    # drop rate is what the threshold says
+    assert abs(1.0 - k_in.mean() - 0.05) < 0.01
+
+
+def test_finish_two_pass_statistics(oracle):
+    """ensemble_var = mean_i (m_bar - m_i)^2 + mean_i exp(logvar_i)   (model_to_trace.py:274-280)"""
+    rng = np.random.default_rng(1)
+    ms = rng.standard_normal((16, 8)).astype(np.float32)
+    lv = (rng.standard_normal((16, 8)) * 0.01).astype(np.float32)
+    mean, cov, _ = oracle.finish(ms, lv, np.eye(3))
+    mbar = ms.astype(np.float64).mean(0)
+    ens = ((mbar - ms) ** 2).mean(0) + np.exp(lv.astype(np.float64)).mean(0)
+    assert np.abs(mean - mbar).max() < 1e-5          # identity H: offsets are the mean head output
+    assert np.abs(np.diag(cov) - ens).max() < 1e-5   # identity H: cov = diag(ensemble variance)
