@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — HomographyNet hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md §measurement).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one forward of the full 4-block HomographyNet (MC-dropout N=32) over one batch of synthetic
+320x224 frame pairs per GPU, inputs resident in HBM, outputs [B,8]+[B,64] left in HBM; with N>1 every rank
+processes its own shard of the pairs (weak scaling) and the per-pair outputs are all-gathered over RCCL
+(288 B per pair, the only exchange the path has).  `value` = frame-pair homography predictions per second over
+all GPUs.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
+    ap.add_argument("--mc", type=int, default=32, help="MC-dropout samples N")
+    ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, prev, curr, prior, variant, n_mc, budget_s):
+    """the oracle's plain-fp32 build (kind "port") timed on this box's host cores on a bounded sample"""
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    orc = pyoracle.Oracle(blob, f32=True, threads=cores)
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+
+    def one(i):
+        j = i % prev.shape[0]
+        orc.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
+
+    one(0)
+    t0 = time.perf_counter()
+    for i in range(2):
+        one(i)
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(4, min(400, budget_s / max(per, 1e-4))))
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(i)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frame pairs, {variant} model, N={n_mc}, one pair at a time (the reference is batch-1), "
+                      f"oracle/liboracle_f32.so with OpenMP on {cores} threads, {dt:.1f} s",
+            "ms_per_pair": round(1e3 * dt / n, 3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+
+    from cuahn_vio_amd import dist as hdist
+    from cuahn_vio_amd import synth, weights
+    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, n_mc = args.batch, args.mc
+    blob = weights.pack_state_dict(weights.synthetic_state(0))
+    n_distinct = min(B, 32)
+    prev_h, curr_h, prior_h, _ = synth.make_batch(1000 + rank * n_distinct, n_distinct)
+    reps = (B + n_distinct - 1) // n_distinct
+    prev = torch.from_numpy(np.tile(prev_h, (reps, 1, 1))[:B]).to(dev)
+    curr = torch.from_numpy(np.tile(curr_h, (reps, 1, 1))[:B]).to(dev)
+    prior = torch.from_numpy(np.tile(prior_h, (reps, 1))[:B]).to(dev)
+    d_prior = prior.data_ptr() if args.variant != "full" else None
+    out = torch.zeros(B, 72, device=dev)            # [mean8 | cov64] per pair
+    mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
+    gathered = torch.zeros(world * B, 72, device=dev) if world > 1 else None
+
+    eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
+
+    def step(i):
+        eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, (rank * 1000003 + i) * B,
+                               mean.data_ptr(), cov.data_ptr(), None, sp)
+        if world > 1:
+            hdist.gather_outputs(mean, cov, out, gathered)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    res = {
+        "metric": "homography preds/sec (frame pairs/s), full 4-block HomographyNet @ 320x224",
+        "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
+                               f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
+                   "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant,
+                   "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU",
+                   "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
+        "mc_preds_per_s": round(value * n_mc, 1),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on
+        stages = eng.stages()
+        ms = eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(), cov.data_ptr(), 5)
+        k = int(np.argmax(ms))
+        total_flops = sum(f for _, f in stages) * B
+        fl = stages[k][1] * B
+        ach = fl / (ms[k] * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                           "kernel": stages[k][0], "kernel_ms": round(float(ms[k]), 4),
+                           "flops_per_launch": fl}
+        res["forward"] = {"gflop_per_pair": round(total_flops / B / 1e9, 4),
+                          "tflops_whole_forward": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                          "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                          "stage_ms": {n: round(float(m), 4) for (n, _), m in zip(stages, ms)}}
+        if not args.no_latency:
+            e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank)
+            e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 20)
+            per, _tot = e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 200)
+            res["latency_batch1_ms"] = {"p50": round(float(np.percentile(per, 50)), 4), "p95": round(float(np.percentile(per, 95)), 4),
+                                        "definition": "device time of one pair, inputs/outputs resident (the reference's 'pure network inference')"}
+            e1.close()
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(blob, prev_h, curr_h, prior_h, args.variant, n_mc, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""CPU: host logic — weight blob format, mask function, synthetic data determinism, and that the C-ABI library
+loads and exports every symbol include/hnet.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_weight_inventory_matches_reference_counts():
+    from cuahn_vio_amd import weights
+    specs = weights.tensor_specs()
+    assert len(specs) == 54
+    assert sum(int(np.prod(s)) for _, s in specs) == 6_541_312
+    st = weights.synthetic_state(0)
+    assert list(st.keys()) == [n for n, _ in specs]
+    st2 = weights.synthetic_state(0)
+    assert all(np.array_equal(st[k], st2[k]) for k in st)           # deterministic
+    assert not np.array_equal(weights.synthetic_state(1)["model_part1.fc_block_1.bias"], st["model_part1.fc_block_1.bias"])
+
+
+def test_blob_roundtrip_and_errors(tmp_path):
+    from cuahn_vio_amd import weights
+    st = weights.synthetic_state(3)
+    blob = weights.pack_state_dict(st)
+    back = weights.unpack_blob(blob)
+    assert list(back.keys()) == list(st.keys())
+    assert all(np.array_equal(back[k], st[k]) for k in st)
+    p = tmp_path / "w.hnw"
+    weights.save_blob(str(p), st)
+    assert all(np.array_equal(v, st[k]) for k, v in weights.load_blob(str(p)).items())
+    bad = dict(st)
+    bad.pop("model_part1.fc_block_2.bias")
+    with pytest.raises(KeyError):
+        weights.pack_state_dict(bad)
+    bad = dict(st)
+    bad["model_part1.fc_block_2.bias"] = np.zeros(9, np.float32)
+    with pytest.raises(ValueError):
+        weights.pack_state_dict(bad)
+    with pytest.raises(ValueError):
+        weights.unpack_blob(b"garbage!" + blob[8:])
+
+
+def test_oracle_rejects_bad_blob(blob):
+    from oracle import pyoracle
+    with pytest.raises(ValueError):
+        pyoracle.Oracle(b"HNETW001" + b"\0" * 64)
+    with pytest.raises(ValueError):
+        pyoracle.Oracle(blob[: len(blob) // 2])
+
+
+def test_mask_function_properties():
+    from cuahn_vio_amd import mcdrop
+    a = mcdrop.keep_mask(1, 2, 0, 16, 5120, 0.05)
+    assert np.array_equal(a, mcdrop.keep_mask(1, 2, 0, 16, 5120, 0.05))
+    assert abs(1 - a.mean() - 0.05) < 0.005
+    assert mcdrop.keep_mask(1, 2, 0, 4, 256, 0.0).all()            # p = 0 keeps everything
+    # streams, pairs and seeds are decorrelated
+    for other in (mcdrop.keep_mask(1, 2, 1, 16, 5120, 0.05), mcdrop.keep_mask(1, 3, 0, 16, 5120, 0.05),
+                  mcdrop.keep_mask(2, 2, 0, 16, 5120, 0.05)):
+        both = (~a & ~other).mean()
+        assert abs(both - 0.0025) < 0.001
+    # sample_offset = global sample index: a shard sees the same rows
+    assert np.array_equal(mcdrop.keep_mask(9, 9, 2, 4, 256, 0.3, sample_offset=8), mcdrop.keep_mask(9, 9, 2, 12, 256, 0.3)[8:])
+    assert mcdrop.drop_threshold(0.05) == 838860 and abs(float(mcdrop.scale(0.05)) - 1 / 0.95) < 1e-7
+
+
+def test_synthetic_pairs_are_consistent_and_deterministic():
+    from cuahn_vio_amd import synth
+    a1, a2, off = synth.make_pair(5)
+    b1, b2, off2 = synth.make_pair(5)
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(off, off2)
+    assert a1.dtype == np.uint8 and a1.shape == (224, 320) and a1.max() > 200 and a1.std() > 20
+    assert np.abs(off).max() <= 12.0
+    # geometric consistency: warping img2 back with the true homography reproduces img1 in the interior
+    from oracle import pyoracle
+    w = pyoracle.warp(a2, synth.dlt_h(off))
+    d = np.abs(w - pyoracle.as_f32_image(a1))[30:-30, 30:-30]
+    assert np.median(d) < 0.02
+    pr = synth.make_prior(5, off)
+    assert np.abs(pr - off).max() < 2 * 1.8 and pr.dtype == np.float32
+
+
+def test_capi_library_exports_every_declared_symbol():
+    """the C-ABI .so loads on a box without a GPU and exports exactly what include/hnet.h declares"""
+    from cuahn_vio_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = _capi.lib()
+    header = open(os.path.join(ROOT, "include", "hnet.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(hnet_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_capi.SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.hnet_version()
+    cfg = _capi.Config()
+    L.hnet_default_config(ctypes.byref(cfg))
+    assert cfg.struct_size == ctypes.sizeof(_capi.Config) and cfg.mc_samples == 16 and abs(cfg.dropout_p - 0.05) < 1e-7
+    assert L.hnet_status_string(4) == b"not ready (need two images)"
+    # invalid arguments are rejected before any device work
+    assert L.hnet_create_from_memory(ctypes.byref(cfg), None, 0, None) == 1
+    assert L.hnet_image_count(None) == 0
+
+
+def test_product_path_never_touches_the_oracle():
+    """the shipped package must not import, link or call anything under oracle/ (no CPU fallback)"""
+    pkg = os.path.join(ROOT, "cuahn_vio_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "hnet_oracle" not in txt, f
+    for f in ("hnet.h", "hnet_rng.h"):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().replace("CPU oracle", "")
