@@ -41,14 +41,26 @@ def parse():
 def cpu_baseline(blob, prev, curr, prior, variant, n_mc, budget_s):
     """the oracle's plain-fp32 build (kind "port") timed on this box's host cores on a bounded sample"""
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
-    orc = pyoracle.Oracle(blob, f32=True, threads=cores)
     btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    orc = pyoracle.Oracle(blob, f32=True)
 
     def one(i):
         j = i % prev.shape[0]
         orc.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
 
+    # pick the OpenMP thread count that is fastest on this host (more threads than the small per-layer loops can
+    # feed only add fork/join cost: 256 threads ran 60x slower than 8 on the GPU box)
+    avail = os.cpu_count() or 1
+    best, cores = None, 1
+    for th in [t for t in (4, 8, 16, 32, 64) if t <= avail] or [1]:
+        orc.lib.oracle_set_threads(th)
+        one(0)
+        t0 = time.perf_counter()
+        one(1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, th
+    orc.lib.oracle_set_threads(cores)
     one(0)
     t0 = time.perf_counter()
     for i in range(2):
@@ -150,6 +162,7 @@ def main():
         k = int(np.argmax(ms))
         total_flops = sum(f for _, f in stages) * B
         fl = stages[k][1] * B
+        ms = [float(x) for x in ms]
         ach = fl / (ms[k] * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,

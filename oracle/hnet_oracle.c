@@ -180,7 +180,9 @@ void oracle_conv_lrelu(const float* in, int Cin, int H, int W, const float* w, c
                     for (int kw = 0; kw < k; kw++) {
                         int lo = p - kw;                 /* need ox*stride >= p - kw */
                         int ox0 = lo <= 0 ? 0 : (lo + stride - 1) / stride;
-                        int ox1 = (W - 1 + p - kw) / stride;         /* ox*stride <= W-1+p-kw */
+                        int hi = W - 1 + p - kw;                     /* ox*stride <= W-1+p-kw */
+                        if (hi < 0) continue;
+                        int ox1 = hi / stride;
                         if (ox1 > Wo - 1) ox1 = Wo - 1;
                         const acc_t wv = (acc_t)wrow[kw];
                         const float* ip = irow + (kw - p);

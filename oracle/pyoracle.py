@@ -81,8 +81,8 @@ class Oracle:
         rc = self.lib.oracle_load(C.cast(buf, C.c_void_p), len(blob), C.byref(self._h))
         if rc != 0:
             raise ValueError(f"oracle_load failed: {rc}")
-        if threads:
-            self.lib.oracle_set_threads(threads)
+        # default: a modest team — the per-layer loops are small and a 256-thread team (GPU box) is far slower
+        self.lib.oracle_set_threads(threads if threads else min(16, os.cpu_count() or 1))
 
     def __del__(self):
         if getattr(self, "_h", None):
