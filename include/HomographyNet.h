@@ -1,0 +1,162 @@
+// HomographyNet.h — header-only C++ adapter with the class surface of the reference runtime
+// `pytorch::HomographyNet` (reference cuahn_ros/homography_network/src/HomographyNet.h:23-67), implemented on
+// the C ABI of hnet.h (libhnet_hip.so, hand-written HIP kernels for gfx950) instead of libtorch.
+//
+// Drop-in use: put this header in place of the reference's HomographyNet.h, drop HomographyNet.cpp from
+// `network_lib`, link libhnet_hip.so.  The two call sites in cuahn::VioManager
+// (VioManager.cpp:107,188,236,257-259,288) compile unchanged:
+//
+//     HNet = std::shared_ptr<pytorch::HomographyNet>(new pytorch::HomographyNet(model_path, iter_path,
+//                                                     use_prior, max_IEKF_iteration, show_img));
+//     HNet->load_current_img(standard_img, t);                       // cv::Mat 224x320 CV_8UC1
+//     HNet->network_inference(propagated_4pt_offset_pixel, iteration);
+//     if (HNet->get_latest_inference_time() == t && HNet->img_counter > 10) { HNet->get_pred_mean(); HNet->get_pred_Cov(); }
+//
+// Differences to the reference, all at construction:
+//   * `network_model_path` names an HNETW001 weight blob (cuahn_vio_amd/weights.py) instead of a TorchScript
+//     .pt.  As in the reference, "_showError" in the file name selects the variant that also emits the
+//     photometric error map (HomographyNet.cpp:96-100).
+//   * what the reference freezes into the traced file is read from optional environment variables:
+//     HNET_BLOCKS_TO_RUN (1..3, default 3 = "3_blocks_using_prior"), HNET_MC_SAMPLES (default 16),
+//     HNET_DROPOUT_P (default 0.05), HNET_MC_SEED (default 0), HNET_DEVICE (default 0).
+//   * the IEKF "iterative" model of the reference is the same network traced a second time; here one context
+//     serves every iteration (`network_model_iterative_path` is accepted and ignored).
+//   * a failed load throws std::runtime_error instead of printing and crashing at the first forward
+//     (HomographyNet.cpp:91-93).
+//
+// OpenCV / Eigen types appear only in this header; the shared library has none of them in its ABI.
+#ifndef PYTORCH_HNet_H
+#define PYTORCH_HNet_H
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifndef HNET_ADAPTER_NO_THIRD_PARTY_INCLUDES
+#include <Eigen/Eigen>
+#include <opencv2/core/core.hpp>
+#include <opencv2/highgui/highgui.hpp>
+#endif
+
+#include "hnet.h"
+
+#define HNET_BLUE "\033[34m"
+#define HNET_RESET "\033[0m"
+
+namespace pytorch {
+
+class HomographyNet {
+public:
+    HomographyNet(std::string& network_model_path, std::string& network_model_iterative_path, bool use_prior,
+                  int num_of_iteration, bool show_imgs) {
+        (void)network_model_iterative_path;
+        use_prior_4pt_offset = use_prior;
+        iteration = num_of_iteration > 1;
+        cv_imshow = show_imgs;
+        show_phtometric_error = network_model_path.find("_showError") != std::string::npos;   // HomographyNet.cpp:96-100
+        hnet_config cfg;
+        hnet_default_config(&cfg);
+        cfg.device_id = env_int("HNET_DEVICE", 0);
+        cfg.use_prior = use_prior ? 1 : 0;
+        cfg.blocks_to_run = env_int("HNET_BLOCKS_TO_RUN", 3);
+        cfg.mc_samples = env_int("HNET_MC_SAMPLES", 16);
+        cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", 0.05);
+        cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);
+        cfg.emit_error_map = show_phtometric_error ? 1 : 0;
+        cfg.max_batch = 1;
+        std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());
+        const int rc = hnet_create(&cfg, network_model_path.c_str(), &ctx_);   // also runs the warm-up forward (:28-45)
+        if (rc != HNET_OK)
+            throw std::runtime_error(std::string("error loading the model !!! (") + hnet_status_string(rc) + ")");
+        hnet_timing t;
+        hnet_last_timing(ctx_, &t);
+        std::printf(HNET_BLUE "[TIME]: %.4f milliseconds for the first network inference\n" HNET_RESET, t.host_ms);
+        if (show_phtometric_error) err_map_.resize(HNET_IMG_ROWS * HNET_IMG_COLS);
+        _pred_mean.setZero();
+        _pred_Cov.setZero();
+#ifndef HNET_ADAPTER_NO_THIRD_PARTY_INCLUDES
+        if (cv_imshow) {
+            cv::namedWindow("Image", cv::WINDOW_KEEPRATIO);
+            cv::namedWindow("Photometric Error", cv::WINDOW_KEEPRATIO);
+        }
+#endif
+    }
+
+    ~HomographyNet() {
+        hnet_destroy(ctx_);
+        std::printf("HomographyNet Object is being deleted! End of this run ...\n");
+    }
+    HomographyNet(const HomographyNet&) = delete;
+    HomographyNet& operator=(const HomographyNet&) = delete;
+
+    // HomographyNet.cpp:127-151
+    void load_current_img(const cv::Mat& img, const double& time_stamp) {
+#ifndef HNET_ADAPTER_NO_THIRD_PARTY_INCLUDES
+        if (cv_imshow) { cv::imshow("Image", img); cv::waitKey(1); }
+#endif
+        if (img_counter == 0) std::printf("First Image Comes into the Network Object!\n");
+        const int rc = hnet_push_image(ctx_, img.data, img.rows, img.cols, (int)img.step, time_stamp);
+        if (rc != HNET_OK) { std::fprintf(stderr, "load_current_img: %s (%s)\n", hnet_status_string(rc), hnet_last_error(ctx_)); return; }
+        img_counter = hnet_image_count(ctx_);
+    }
+
+    Eigen::Matrix<double, 8, 1> get_pred_mean() { return _pred_mean.template cast<double>(); }
+    Eigen::Matrix<double, 8, 8> get_pred_Cov() { return _pred_Cov.template cast<double>(); }
+    double get_latest_inference_time() { return hnet_latest_time(ctx_); }
+
+    // HomographyNet.cpp:153-252
+    void network_inference(Eigen::Matrix<double, 8, 1>& prior_4pt_offset_vec, int num_of_inference) {
+        if (img_counter < 2) { std::printf("HNet cannot inference! Only has one image!\n"); return; }   // :155-158
+        double prior[8];
+        for (int i = 0; i < 8; i++) prior[i] = prior_4pt_offset_vec[i];
+        float mean[8], cov[64];
+        const bool want_err = cv_imshow && show_phtometric_error;
+        const int rc = hnet_infer(ctx_, use_prior_4pt_offset ? prior : nullptr, num_of_inference, mean, cov,
+                                  show_phtometric_error ? err_map_.data() : nullptr);
+        if (rc != HNET_OK) { std::fprintf(stderr, "network_inference: %s (%s)\n", hnet_status_string(rc), hnet_last_error(ctx_)); return; }
+        for (int i = 0; i < 8; i++) {
+            _pred_mean(i, 0) = mean[i];
+            for (int j = 0; j < 8; j++) _pred_Cov(i, j) = cov[i * 8 + j];   // symmetric: the reference's column-major Map of row-major data is the same matrix
+        }
+#ifndef HNET_ADAPTER_NO_THIRD_PARTY_INCLUDES
+        if (want_err && !(num_of_inference == 0 && iteration)) {            // :199, :222
+            cv::Mat resultImg(HNET_IMG_ROWS, HNET_IMG_COLS, CV_8UC1, err_map_.data());
+            cv::imshow("Photometric Error", resultImg);
+            cv::waitKey(1);
+        }
+#else
+        (void)want_err;
+#endif
+        if (num_of_inference == 0) {                                        // :245-251
+            hnet_timing t;
+            hnet_last_timing(ctx_, &t);
+            if (t.n_inferences > 100)
+                std::printf(HNET_BLUE "[TIME]: %.3f (avg. = %.3f) milliseconds for pure network inference\n" HNET_RESET,
+                            t.device_ms, t.sum_device_ms_after_100 / (double)(t.n_inferences - 100));
+        }
+    }
+
+    const std::vector<uint8_t>& last_error_map() const { return err_map_; }   // extension: the u8 map the reference only displays
+
+    int img_counter = 0;   // public in the reference (HomographyNet.h:33), read by VioManager.cpp:257,288
+
+private:
+    static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+    static double env_double(const char* name, double dflt) { const char* v = std::getenv(name); return v ? std::atof(v) : dflt; }
+
+    hnet_ctx* ctx_ = nullptr;
+    bool cv_imshow = false;
+    bool use_prior_4pt_offset = false;
+    bool show_phtometric_error = false;
+    bool iteration = false;
+    std::vector<uint8_t> err_map_;
+    Eigen::Matrix<float, 8, 1> _pred_mean;
+    Eigen::Matrix<float, 8, 8> _pred_Cov;
+};
+
+}  // namespace pytorch
+
+#endif  // PYTORCH_HNet_H
