@@ -84,35 +84,41 @@ struct ConvLoader {
         return r;
     }
 
-    // 4 consecutive K values starting at padded-K index kp (multiple of 4)
-    __device__ static inline f32x4 load(const IgemmParams& p, const Row& r, int kp) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // 4 consecutive K values starting at padded-K index kp (multiple of 4).
+    // The global loads are UNCONDITIONAL (the address is redirected to element 0 of the input when the tap is
+    // padding / out of range); `mask` says which elements are real and is applied by finalize() when the
+    // registers are written to LDS, after the MFMAs of the current tile: a load under a runtime condition makes
+    // hipcc branch around it and wait vmcnt(0) right there, which serialises the whole staging.
+    __device__ static inline void load(const IgemmParams& p, const Row& r, int kp, f32x4& raw, uint32_t& mask) {
         const int sg = kp / SEG;
         const int within = kp % SEG;
         const int kh = sg / SPR;
         const int rr = (sg % SPR) * SEG + within;
         const int iy = r.iy0 + kh;
-        if (!r.valid || sg >= TOTAL_SEGS || iy < 0 || iy >= p.H) return v;
+        const bool row_ok = r.valid && sg < TOTAL_SEGS && iy >= 0 && iy < p.H;
         if constexpr (CIN >= 4) {
-            if (RL % SEG != 0 && rr >= RL) return v;
             const int kw = rr / CIN, ci = rr % CIN;
             const int ix = r.ix0 + kw;
-            if (ix < 0 || ix >= p.W) return v;
-            const float* src = p.A + ((size_t)(r.pix0 + kh * p.W + kw)) * CIN + ci;
-            v = *reinterpret_cast<const f32x4*>(src);
+            const bool ok = row_ok && (RL % SEG == 0 || rr < RL) && ix >= 0 && ix < p.W;
+            const size_t off = ok ? ((size_t)(r.pix0 + kh * p.W + kw)) * CIN + ci : 0;
+            raw = *reinterpret_cast<const f32x4*>(p.A + off);
+            mask = ok ? 0xFu : 0u;
         } else {  // CIN == 2: the float4 spans two pixels, each float2 has its own bounds
             const int kw = rr / 2;
-            const float* src = p.A + ((size_t)(r.pix0 + kh * p.W + kw)) * 2;
             const int ix = r.ix0 + kw;
-            if (rr < RL && ix >= 0 && ix < p.W) {
-                float2 t = *reinterpret_cast<const float2*>(src);
-                v[0] = t.x; v[1] = t.y;
-            }
-            if (rr + 2 < RL && ix + 1 >= 0 && ix + 1 < p.W) {
-                float2 t = *reinterpret_cast<const float2*>(src + 2);
-                v[2] = t.x; v[3] = t.y;
-            }
+            const bool ok0 = row_ok && rr < RL && ix >= 0 && ix < p.W;
+            const bool ok1 = row_ok && rr + 2 < RL && ix + 1 >= 0 && ix + 1 < p.W;
+            const size_t base = ((size_t)(r.pix0 + kh * p.W + kw)) * 2;
+            const float2 t0 = *reinterpret_cast<const float2*>(p.A + (ok0 ? base : 0));
+            const float2 t1 = *reinterpret_cast<const float2*>(p.A + (ok1 ? base + 2 : 0));
+            raw[0] = t0.x; raw[1] = t0.y; raw[2] = t1.x; raw[3] = t1.y;
+            mask = (ok0 ? 0x3u : 0u) | (ok1 ? 0xCu : 0u);
         }
+    }
+    __device__ static inline f32x4 finalize(const IgemmParams&, const f32x4& raw, uint32_t mask) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = (mask >> i) & 1u ? raw[i] : 0.0f;
         return v;
     }
 };
@@ -138,16 +144,20 @@ struct HeadLoader {
         r.prefix = hnet_mask_prefix(hnet_pair_key(p.mc_seed, p.pair_seq0 + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)s);
         return r;
     }
-    __device__ static inline f32x4 load(const IgemmParams& p, const Row& r, int kp) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!r.valid) return v;
-        f32x4 f = *reinterpret_cast<const f32x4*>(r.feat + kp);
+    __device__ static inline void load(const IgemmParams& p, const Row& r, int kp, f32x4& raw, uint32_t& mask) {
+        raw = *reinterpret_cast<const f32x4*>(r.feat + kp);    // unconditional (row 0 when invalid)
         const int pix = kp >> 8, c = kp & 255;
+        mask = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t e = (uint32_t)((c + i) * 20 + pix);
-            v[i] = hnet_mask_keep(r.prefix, e, p.thr) ? f[i] * p.scale : 0.0f;
+            const uint32_t e = (uint32_t)((c + i) * 20 + pix);
+            mask |= (r.valid && hnet_mask_keep(r.prefix, e, p.thr)) ? (1u << i) : 0u;
         }
+    }
+    __device__ static inline f32x4 finalize(const IgemmParams& p, const f32x4& raw, uint32_t mask) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = (mask >> i) & 1u ? raw[i] * p.scale : 0.0f;
         return v;
     }
 };
@@ -205,25 +215,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             for (int r = 0; r < (MF == 32 ? 16 : 4); r++) acc[i][j][r] = 0.0f;
 
     f32x4 areg[A_ROWS], breg[B_ROWS];
+    uint32_t amask[A_ROWS];
+    bool bok[B_ROWS];
     const int n_iter = (p.Kp + BK - 1) / BK;
 
+    // raw, unconditional global loads of K-tile `it` into registers (masks computed, not yet applied)
     auto g_load = [&](int it) {
         const int kp = it * BK + skk;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; i++) areg[i] = L::load(p, rows[i], kp);
+        for (int i = 0; i < A_ROWS; i++) L::load(p, rows[i], kp, areg[i], amask[i]);
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            breg[i] = (wvalid[i] && kp < p.Kp) ? *reinterpret_cast<const f32x4*>(wsrc[i] + it * BK) : z;
+            bok[i] = wvalid[i] && kp < p.Kp;
+            breg[i] = *reinterpret_cast<const f32x4*>(bok[i] ? wsrc[i] + it * BK : p.Wp);
         }
     };
+    // apply the masks and write the registers to LDS buffer `buf` (first consumer of the loaded data)
     auto s_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; i++)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + i * 32) * BKP + skk]) = areg[i];
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + i * 32) * BKP + skk]) = L::finalize(p, areg[i], amask[i]);
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++)
-            if (srow + i * 32 < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + srow + i * 32) * BKP + skk]) = breg[i];
+            if (srow + i * 32 < BN) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = bok[i] ? breg[i][e] : 0.0f;
+                *reinterpret_cast<f32x4*>(&Bs[(buf * BN + srow + i * 32) * BKP + skk]) = v;
+            }
     };
 
     g_load(0);
@@ -274,6 +293,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         }
 
+        // keep the consumers of the prefetched registers (mask select + ds_write) behind the MFMAs: without this
+        // fence the scheduler hoists the selects next to the loads and the s_waitcnt vmcnt lands before the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < n_iter) s_store(buf ^ 1);
         __syncthreads();
     }
