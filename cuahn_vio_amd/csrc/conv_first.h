@@ -1,0 +1,127 @@
+// conv_first.h — direct 7x7 / stride-1 / Cin = 2 convolution on fp32 MFMA for the two full-resolution first
+// layers (block_4_0: 2->8 @224x320, block_3_0: 2->16 @112x160; reference model_to_trace.py:107,210 via conv() :7-15).
+//
+// Why not the generic implicit GEMM: with Cin = 2 its im2col staging is address-arithmetic bound (12 % of the MFMA
+// peak measured) and Cout = 8 wastes half of a 16-wide MFMA.  Here instead:
+//   * the workgroup stages its input patch (tile + 3-pixel halo) ONCE in LDS, NHWC, zero filled outside the image;
+//   * GEMM view: M = pairs of horizontally adjacent output pixels, N = (pixel-in-pair dx, cout) = 2*Cout,
+//     K = (kh, kw', ci) with kw' in 0..7: the 8-tap window both pixels of a pair need.  W'[kh][kw'][ci][(dx,co)] =
+//     W[co][ci][kh][kw'-dx] (zero outside 0..6).  N is exactly 16 (Cout 8, v_mfma_f32_16x16x4_f32) or 32 (Cout 16,
+//     v_mfma_f32_32x32x2_f32) and 7 of 8 taps are useful: 87.5 % MFMA efficiency instead of 43.75 %;
+//   * for a fixed kh the 16 K-values of a pair are 16 CONTIGUOUS floats of the patch row: one ds_read_b128 per lane
+//     feeds 4 MFMAs (K-permutation as in igemm.h: lane group g reads floats 4g..4g+3, element i goes to step i);
+//   * the whole W' (28 resp. 56 fragment registers per lane) lives in VGPRs for the lifetime of the workgroup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm.h"
+
+namespace hnet {
+
+template <int COUT> struct FirstCfg;
+template <> struct FirstCfg<8> {
+    static constexpr int TH = 16, TW = 64;          // output tile
+    static constexpr int NFRAG = 28;                // 7 rows x 4 k-steps (16x16x4)
+};
+template <> struct FirstCfg<16> {
+    static constexpr int TH = 16, TW = 32;
+    static constexpr int NFRAG = 56;                // 7 rows x 8 k-steps (32x32x2)
+};
+
+// wfrag: [NFRAG][64] floats, fragment t of lane l (host-packed, see pack_first_weights in hnet_capi.hip)
+template <int COUT>
+__global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restrict__ in, const float* __restrict__ wfrag,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int H, int W, int tiles_x, int tiles_y) {
+    typedef FirstCfg<COUT> C;
+    constexpr int TH = C::TH, TW = C::TW, PH = TH + 6, PW = TW + 8;   // patch: 3-px halo + 2 columns for kw' = 7 / padding
+    constexpr int PROW = PW * 2;                                       // floats per patch row
+    __shared__ __attribute__((aligned(16))) float patch[PH * PROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- weights fragments -> registers (coalesced: 64 consecutive floats per fragment)
+    float wreg[C::NFRAG];
+#pragma unroll
+    for (int t = 0; t < C::NFRAG; t++) wreg[t] = wfrag[t * 64 + lane];
+
+    // ---- stage the patch: unconditional float2 loads from a clamped address, zero selected afterwards
+    const float* inb = in + (size_t)b * H * W * 2;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int pr = i / PW, pc = i - pr * PW;
+        const int iy = y0 - 3 + pr, ix = x0 - 3 + pc;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float2 v = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
+        *reinterpret_cast<float2*>(&patch[pr * PROW + pc * 2]) = ok ? v : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+
+    if constexpr (COUT == 8) {
+        // M-tile = 16 pixel pairs of one output row; 2 M-tiles per row, TH rows -> 32 M-tiles, 8 per wave
+        const int m = lane & 15, g = lane >> 4;
+        const float bv = bias[lane & 7];
+#pragma unroll 2
+        for (int j = 0; j < (TH * (TW / 32)) / 4; j++) {
+            const int mt = wave + 4 * j;
+            const int row = mt / (TW / 32), half = mt % (TW / 32);
+            const int pm = half * 16 + m;                       // pixel-pair index within the tile row
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 7; kh++) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&patch[(row + kh) * PROW + pm * 4 + 4 * g]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wreg[kh * 4 + e], acc, 0, 0, 0);
+            }
+            // D: col n = lane&15 = (dx, co); row = 4*(lane>>4) + r = pixel pair
+            const int y = y0 + row;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pp = half * 16 + 4 * g + r;
+                const int x = x0 + 2 * pp + (m >> 3);
+                if (y < H && x < W) {
+                    const float v = acc[r] + bv;
+                    out[(((size_t)b * H + y) * W + x) * 8 + (m & 7)] = v > 0.f ? v : v * 0.1f;
+                }
+            }
+        }
+    } else {
+        // COUT == 16: M-tile = 2 output rows x 16 pixel pairs (32 px wide tile); TH/2 = 8 M-tiles, 2 per wave
+        const int m = lane & 31, h = lane >> 5;
+        const int mrow = m >> 4, mp = m & 15;
+        const float bv = bias[lane & 15];
+#pragma unroll 1
+        for (int j = 0; j < (TH / 2) / 4; j++) {
+            const int mt = wave + 4 * j;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 7; kh++) {
+                const float* prow = &patch[(mt * 2 + mrow + kh) * PROW + mp * 4 + 4 * h];
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(prow);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(prow + 8);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], wreg[kh * 8 + e], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], wreg[kh * 8 + 4 + e], acc, 0, 0, 0);
+            }
+            // D: col n = lane&31 = (dx, co); row = (r&3) + 8*(r>>2) + 4*(lane>>5) = (row-in-pair-of-rows, pixel pair)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int y = y0 + mt * 2 + (mr >> 4);
+                const int x = x0 + 2 * (mr & 15) + (m >> 4);
+                if (y < H && x < W) {
+                    const float v = acc[r] + bv;
+                    out[(((size_t)b * H + y) * W + x) * 16 + (m & 15)] = v > 0.f ? v : v * 0.1f;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace hnet

@@ -22,40 +22,26 @@ HNET_HD double p4(int i) {
     return (c >= 2) ? (double)(IMG_W - 1) : 0.0;
 }
 
-// DLT_solve (model_to_trace.py:42-61) for src = image corners: rows
-//   [x y 1 0 0 0 -u'x -u'y | u'] and [0 0 0 x y 1 -v'x -v'y | v'];  solved by Gaussian elimination with
-// partial pivoting instead of an explicit inverse; H = [h8, 1].
+// DLT_solve (model_to_trace.py:42-61) for src = image corners.  The reference builds the 8x8 system
+//   [x y 1 0 0 0 -u'x -u'y | u'], [0 0 0 x y 1 -v'x -v'y | v']  and multiplies inverse(A) by b.
+// The 4-point homography with h33 = 1 is unique, so it is evaluated here in closed form (Heckbert's
+// square-to-quadrilateral mapping composed with the scaling of the source rectangle), in double: ~40 flops, no
+// pivoting, no local arrays (the elimination loop's dynamically indexed scratch cost ~10 us on one lane).
+//   unit square (s,t): (0,0)->ul', (1,0)->ur', (1,1)->br', (0,1)->bl';  s = u/(W-1), t = v/(H-1)
 HNET_HD void dlt_solve(const double dst[8], double H[9]) {
-    double A[8][9];
-    for (int i = 0; i < 4; i++) {
-        const double x = p4(2 * i), y = p4(2 * i + 1), u = dst[2 * i], v = dst[2 * i + 1];
-        double* r0 = A[2 * i];
-        double* r1 = A[2 * i + 1];
-        r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * x; r0[7] = -u * y; r0[8] = u;
-        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
-    }
-    for (int c = 0; c < 8; c++) {
-        int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 8; r++) {
-            double a = fabs(A[r][c]);
-            if (a > best) { best = a; piv = r; }
-        }
-        if (piv != c)
-            for (int j = c; j < 9; j++) { double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
-        const double inv = 1.0 / A[c][c];
-        for (int r = c + 1; r < 8; r++) {
-            const double f = A[r][c] * inv;
-            if (f != 0.0)
-                for (int j = c; j < 9; j++) A[r][j] -= f * A[c][j];
-        }
-    }
-    for (int i = 7; i >= 0; i--) {
-        double s = A[i][8];
-        for (int j = i + 1; j < 8; j++) s -= A[i][j] * H[j];
-        H[i] = s / A[i][i];
-    }
-    H[8] = 1.0;
+    const double x0 = dst[0], y0 = dst[1];       // ul'
+    const double x3 = dst[2], y3 = dst[3];       // bl'  (s=0,t=1)
+    const double x2 = dst[4], y2 = dst[5];       // br'  (s=1,t=1)
+    const double x1 = dst[6], y1 = dst[7];       // ur'  (s=1,t=0)
+    const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+    const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+    const double det = dx1 * dy2 - dx2 * dy1;
+    const double g = (sx * dy2 - sy * dx2) / det;
+    const double h = (dx1 * sy - dy1 * sx) / det;
+    const double iw = 1.0 / (double)(IMG_W - 1), ih = 1.0 / (double)(IMG_H - 1);
+    H[0] = (x1 - x0 + g * x1) * iw; H[1] = (x3 - x0 + h * x3) * ih; H[2] = x0;
+    H[3] = (y1 - y0 + g * y1) * iw; H[4] = (y3 - y0 + h * y3) * ih; H[5] = y0;
+    H[6] = g * iw;                  H[7] = h * ih;                  H[8] = 1.0;
 }
 
 // C = A * B  (torch.bmm, model_to_trace.py:168,188,323)
@@ -66,26 +52,28 @@ HNET_HD void mat3_mul(const double a[9], const double b[9], double c[9]) {
     for (int i = 0; i < 9; i++) c[i] = t[i];
 }
 
-// ensemble statistics + transfer + output assembly for one pair
-//   (model_to_trace.py:274-281 ensemble, :18-38 transfer_mean_var_single, :311-317 assembly, :321-323 H_total)
-// mean_s / logvar_s: [n][8] per-sample head outputs (logvar already x1e-3).
-HNET_HD void finish_pair(const float* mean_s, const float* logvar_s, int n, const float* H1f,
-                         float* mean8, float* cov64, float* Htot9) {
+// ensemble statistics of output component i (0..7) over the n MC samples (model_to_trace.py:274-281):
+//   m_bar = mean_s m_i ; v_bar = mean_s exp(logvar_i) ; ens = mean_s (m_bar - m_i)^2 + v_bar ; p_bar = p4 + m_bar
+// mean_s / logvar_s: [n][8] per-sample head outputs (logvar already x1e-3).  fp32 where the reference holds a tensor.
+HNET_HD void ensemble_component(const float* mean_s, const float* logvar_s, int n, int i, double* pbar_i, double* ens_i) {
+    double sm = 0, sv = 0;
+    for (int s = 0; s < n; s++) {
+        sm += (double)mean_s[s * 8 + i];
+        sv += exp((double)logvar_s[s * 8 + i]);
+    }
+    const float mb = (float)(sm / n), vb = (float)(sv / n);
+    double se = 0;
+    for (int s = 0; s < n; s++) { const double d = (double)mb - (double)mean_s[s * 8 + i]; se += d * d; }
+    *ens_i = (double)(float)((double)(float)(se / n) + (double)vb);
+    *pbar_i = (double)(float)(p4(i) + (double)mb);
+}
+
+// transfer to the original frame + output assembly for one pair
+//   (model_to_trace.py:18-38 transfer_mean_var_single, :311-317 assembly, :321-323 H_total)
+HNET_HD void transfer_pair(const double pbar[8], const double ens[8], const float* H1f, float* mean8, float* cov64,
+                           float* Htot9) {
     double H1[9];
     for (int i = 0; i < 9; i++) H1[i] = (double)H1f[i];
-    double pbar[8], ens[8];
-    for (int i = 0; i < 8; i++) {
-        double sm = 0, sv = 0;
-        for (int s = 0; s < n; s++) {
-            sm += (double)mean_s[s * 8 + i];
-            sv += exp((double)logvar_s[s * 8 + i]);
-        }
-        const float mb = (float)(sm / n), vb = (float)(sv / n);     // tensors are fp32 in the reference
-        double se = 0;
-        for (int s = 0; s < n; s++) { const double d = (double)mb - (double)mean_s[s * 8 + i]; se += d * d; }
-        ens[i] = (double)(float)((double)(float)(se / n) + (double)vb);
-        pbar[i] = (double)(float)(p4(i) + (double)mb);
-    }
     for (int i = 0; i < 64; i++) cov64[i] = 0.0f;
     for (int c = 0; c < 4; c++) {
         const double pu = pbar[2 * c], pv = pbar[2 * c + 1];

@@ -7,8 +7,10 @@
 #include "geom.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,6 +76,8 @@ struct hnet_ctx {
     float* x_in[4] = {};
     float* act[20] = {};
     int act_c[20], act_h[20], act_w[20];
+    float* ws = nullptr;               // split-K partial sums (igemm.h), 64 MB
+    size_t ws_floats = 0;
     float *hidden = nullptr, *Hm = nullptr, *Htot = nullptr, *mean_s = nullptr, *logvar_s = nullptr;
     float *d_mean = nullptr, *d_cov = nullptr, *d_err = nullptr, *d_prior = nullptr;
     uint8_t* d_err_u8 = nullptr;
@@ -90,6 +94,12 @@ struct hnet_ctx {
     std::vector<hipEvent_t> prof_ev;   // when non-empty: one event after every stage
     size_t prof_pos = 0;
     int last_batch = 0;
+    // intra-batch concurrency: the batch is cut into n_streams chunks of independent pairs that run on separate HIP
+    // streams, so the tail of one chunk's layer overlaps the next layer of another chunk (frame pairs are independent)
+    int n_streams = 1;
+    std::vector<hipStream_t> aux;       // n_streams - 1 extra streams
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
 };
 
 namespace {
@@ -133,6 +143,24 @@ std::vector<float> pack_conv(const float* w, const ConvDesc& d, int kp) {
     return out;
 }
 
+// 7x7 / Cin 2 / stride 1 first layers: B-operand fragments of the pixel-pair GEMM of conv_first.h.
+// W'[kh][kk = 2*kw' + ci][(dx, co)] = W[co][ci][kh][kw' - dx]  (0 outside 0..6); fragment t of lane l:
+//   Cout  8 (16x16x4): t = kh*4 + e,        n = l&15, g = l>>4, kk = 4g + e
+//   Cout 16 (32x32x2): t = kh*8 + q*4 + e,  n = l&31, h = l>>5, kk = 8q + 4h + e
+std::vector<float> pack_first_weights(const float* w, int cout) {
+    const int nfrag = cout == 8 ? 28 : 56;
+    std::vector<float> out((size_t)nfrag * 64, 0.0f);
+    for (int t = 0; t < nfrag; t++)
+        for (int l = 0; l < 64; l++) {
+            int kh, kk, n;
+            if (cout == 8) { kh = t / 4; kk = 4 * (l >> 4) + (t % 4); n = l & 15; }
+            else { kh = t / 8; const int q = (t % 8) / 4, e = t % 4; kk = 8 * q + 4 * (l >> 5) + e; n = l & 31; }
+            const int kwp = kk >> 1, ci = kk & 1, dx = n / cout, co = n % cout, kw = kwp - dx;
+            if (kw >= 0 && kw < 7) out[(size_t)t * 64 + l] = w[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw];
+        }
+    return out;
+}
+
 // linear weight [out][5120] with NCHW-flatten input index c*20+pix -> NHWC-flatten index pix*256+c
 std::vector<float> permute_fc(const float* w, int n_out) {
     std::vector<float> out((size_t)n_out * 5120);
@@ -163,7 +191,8 @@ void build_stages(hnet_ctx* c) {
         if (blk < 3) c->stages.push_back({"fc_dlt_b" + std::to_string(blk + 1), 2.0 * 8 * 5120});
     }
     c->stages.push_back({"heads_fc1", 2.0 * 512 * 5120 * c->n_local});
-    c->stages.push_back({"heads_fc2_finish", 2.0 * 16 * 256 * c->n_local});
+    c->stages.push_back({"heads_fc2", 2.0 * 16 * 256 * c->n_local});
+    c->stages.push_back({"mc_finish", 0});
     if (g.emit_error_map) c->stages.push_back({"errmap", 0});
 }
 
@@ -178,6 +207,8 @@ struct FwdArgs {
     uint8_t* err_u8;
     float *mean_s, *logvar_s, *h_part1;   // partial path outputs (device) or null
     bool partial;
+    int pair0 = 0;            // first pair of this chunk inside the persistent buffers (caller arrays are pre-offset)
+    bool use_ws = true;       // may use the context's split-K workspace (false for concurrent chunks)
 };
 
 #define STAGE(call)                                                                                         \
@@ -190,46 +221,101 @@ struct FwdArgs {
         }                                                                                                   \
     } while (0)
 
-// The forward of combined_stu_model (model_to_trace.py:299-330) for `batch` independent frame pairs.
+// The forward of combined_stu_model (model_to_trace.py:299-330) for `a.batch` independent frame pairs that occupy
+// slots [a.pair0, a.pair0 + a.batch) of the persistent buffers; everything is enqueued on stream `s`.
+int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
+    const hnet_config& g = c->cfg;
+    const int B = a.batch;
+    const size_t P0 = (size_t)a.pair0;
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    float* Hm = c->Hm + P0 * 9;
+    float* Htot = c->Htot + P0 * 9;
+    // split-K workspace: only for a launch that covers the whole batch on one stream (small batches)
+    float* ws = a.use_ws ? c->ws : nullptr;
+    const size_t wsn = a.use_ws ? c->ws_floats : 0;
+    if (g.use_prior) STAGE(launch_prior_dlt(a.prior, Hm, B, s));                    // :129-130
+    const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
+    for (int blk = fb; blk < 4; blk++) {
+        const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
+        int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
+        float* x = c->x_in[blk] + P0 * h * w * 2;
+        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hm : nullptr, 8 >> blk, x, B, s));
+        const float* in = x;
+        for (int l = first[blk]; l <= last[blk]; l++) {
+            float* o = c->act[l] + P0 * c->act_c[l] * c->act_h[l] * c->act_w[l];
+            STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn));
+            in = o;
+            h = c->act_h[l];
+            w = c->act_w[l];
+        }
+        if (blk < 3)                                                                  // :143-150, :163-168, :183-188
+            STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? Hm : nullptr, Hm, B, s));
+    }
+    // block 4 heads (:272-282) and output assembly (:310-317)
+    const float* feat = c->act[19] + P0 * 5120;
+    float* hidden = c->hidden + P0 * c->n_local * 512;
+    STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn));
+    if (a.partial) {
+        STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2,
+                               a.mean_s, a.logvar_s, s));
+        if (a.h_part1) {
+            hipError_t e = hipMemcpyAsync(a.h_part1, Hm, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return fail(c, HNET_ERR_DEVICE, "copy H_part1");
+        }
+        return HNET_OK;
+    }
+    float* ms = c->mean_s + P0 * c->n_local * 8;
+    float* lv = c->logvar_s + P0 * c->n_local * 8;
+    STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s));
+    STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s));
+    if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
+        STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, Htot, a.err, a.err_u8, B, s));
+    return HNET_OK;
+}
+
+// Validates, then runs the batch as n_streams chunks of independent pairs on separate streams (fork / join with
+// events around the caller's stream `s`).  Results do not depend on the chunking (tests: slot invariance).
 int forward(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     const hnet_config& g = c->cfg;
     const int B = a.batch;
     if (B < 1) return fail(c, HNET_ERR_INVALID_ARG, "batch < 1");
     if (B > g.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
     if (g.use_prior && !a.prior) return fail(c, HNET_ERR_INVALID_ARG, "context uses a prior but none was given");
-    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
     c->last_batch = B;
-    if (g.use_prior) STAGE(launch_prior_dlt(a.prior, c->Hm, B, s));                 // :129-130
-    const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
-    for (int blk = fb; blk < 4; blk++) {
-        const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
-        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? c->Hm : nullptr, 8 >> blk, c->x_in[blk], B, s));
-        const float* in = c->x_in[blk];
-        int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
-        for (int l = first[blk]; l <= last[blk]; l++) {
-            STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], c->act[l], s));
-            in = c->act[l];
-            h = c->act_h[l];
-            w = c->act_w[l];
+    int ns = c->n_streams;
+    if (!c->prof_ev.empty() || B < 2 * 16) ns = 1;            // per-stage profiling and small batches: one stream
+    ns = std::min(ns, B / 16);
+    if (ns <= 1) return forward_chunk(c, a, s);
+    const size_t px = a.pix_fmt == HNET_PIX_U8 ? 1 : 4;
+    if (hipEventRecord(c->ev_fork, s) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipEventRecord(fork)");
+    const int per = (B + ns - 1) / ns;
+    for (int i = 0; i < ns; i++) {
+        const int b0 = i * per, nb = std::min(per, B - b0);
+        if (nb <= 0) break;
+        hipStream_t si = i == 0 ? s : c->aux[i - 1];
+        if (i > 0 && hipStreamWaitEvent(si, c->ev_fork, 0) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipStreamWaitEvent(fork)");
+        FwdArgs ch = a;
+        ch.use_ws = false;
+        ch.pair0 = a.pair0 + b0;
+        ch.batch = nb;
+        ch.seq0 = a.seq0 + (uint64_t)b0;
+        ch.prev = (const uint8_t*)a.prev + (size_t)b0 * NPIX * px;
+        ch.curr = (const uint8_t*)a.curr + (size_t)b0 * NPIX * px;
+        if (a.prior) ch.prior = a.prior + (size_t)b0 * 8;
+        if (a.mean) ch.mean = a.mean + (size_t)b0 * 8;
+        if (a.cov) ch.cov = a.cov + (size_t)b0 * 64;
+        if (a.err) ch.err = a.err + (size_t)b0 * NPIX;
+        if (a.err_u8) ch.err_u8 = a.err_u8 + (size_t)b0 * NPIX;
+        if (a.mean_s) ch.mean_s = a.mean_s + (size_t)b0 * c->n_local * 8;
+        if (a.logvar_s) ch.logvar_s = a.logvar_s + (size_t)b0 * c->n_local * 8;
+        if (a.h_part1) ch.h_part1 = a.h_part1 + (size_t)b0 * 9;
+        const int rc = forward_chunk(c, ch, si);
+        if (rc != HNET_OK) return rc;
+        if (i > 0) {
+            if (hipEventRecord(c->ev_join[i - 1], si) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipEventRecord(join)");
+            if (hipStreamWaitEvent(s, c->ev_join[i - 1], 0) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipStreamWaitEvent(join)");
         }
-        if (blk < 3)                                                                  // :143-150, :163-168, :183-188
-            STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? c->Hm : nullptr, c->Hm, B, s));
     }
-    // block 4 heads (:272-282) and output assembly (:310-317)
-    STAGE(launch_heads_fc1(c->act[19], B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, c->hidden, s));
-    if (a.partial) {
-        STAGE(launch_heads_fc2(c->hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, c->Hm,
-                               a.mean_s, a.logvar_s, 0, nullptr, nullptr, nullptr, s));
-        if (a.h_part1) {
-            hipError_t e = hipMemcpyAsync(a.h_part1, c->Hm, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
-            if (e != hipSuccess) return fail(c, HNET_ERR_DEVICE, "copy H_part1");
-        }
-        return HNET_OK;
-    }
-    STAGE(launch_heads_fc2(c->hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, c->Hm,
-                           c->mean_s, c->logvar_s, 1, a.mean, a.cov, c->Htot, s));
-    if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
-        STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, c->Htot, a.err, a.err_u8, B, s));
     return HNET_OK;
 }
 
@@ -268,6 +354,18 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
+    {
+        const char* e = getenv("HNET_STREAMS");
+        c->n_streams = e ? std::max(1, std::min(8, atoi(e))) : 1;
+        CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int i = 1; i < c->n_streams; i++) {
+            hipStream_t st; hipEvent_t ev;
+            CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->aux.push_back(st);
+            c->ev_join.push_back(ev);
+        }
+    }
 
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
     for (int l = 0; l < 20; l++) {
@@ -276,7 +374,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const Tensor* w = b.find(pre + "weight", (size_t)d.cout * d.cin * d.ks * d.ks);
         const Tensor* bi = b.find(pre + "bias", d.cout);
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
-        CK(upload(&c->conv_w[l], pack_conv(w->data, d, conv_padded_k(l))));
+        if (conv_is_first_direct(l)) CK(upload(&c->conv_w[l], pack_first_weights(w->data, d.cout)));
+        else CK(upload(&c->conv_w[l], pack_conv(w->data, d, conv_padded_k(l))));
         CK(upload(&c->conv_b[l], std::vector<float>(bi->data, bi->data + d.cout)));
     }
     for (int k = 0; k < 3; k++) {
@@ -319,6 +418,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             CK(dalloc(&c->act[l], MB * h * w * kConvs[l].cout));
         }
     }
+    c->ws_floats = (size_t)16 << 20;
+    CK(dalloc(&c->ws, c->ws_floats));
     CK(dalloc(&c->hidden, MB * c->n_local * 512));
     CK(dalloc(&c->Hm, MB * 9));
     CK(dalloc(&c->Htot, MB * 9));
@@ -405,10 +506,13 @@ void hnet_destroy(hnet_ctx* c) {
     for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
-    fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
+    fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
+    for (auto st : c->aux) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto e : c->ev_join) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -10,11 +10,11 @@
 // Design for CDNA4:
 //   * 256 threads = 4 waves (one per SIMD); v_mfma_f32_32x32x2_f32 (or 16x16x4 for Cout <= 16): exact fp32
 //     fma chain, 64 FLOP/clk/SIMD.
-//   * both operand tiles live in LDS as [rows][BK+4] fp32 (K contiguous).  Staging is one global float4
+//   * both operand tiles live in LDS as [rows][BK] fp32 (K contiguous, 16-byte quads XOR-swizzled per row).  Staging is one global float4
 //     load + one ds_write_b128 per 4 K-values; fragments are read with ds_read_b128 using a K-permutation:
 //     lane half h of the wave reads K = 8q+4h .. 8q+4h+3 of its row and feeds element i to MFMA step 4q+i.
 //     Both operands use the same permutation so the contraction is unchanged; one LDS read serves 4 MFMAs and
-//     the 36-float row stride makes the b128 reads bank-conflict free.
+//     an XOR swizzle of the 16-byte quads (ig_swz) makes the b128 reads bank-conflict free for both MFMA shapes.
 //   * register-prefetch double buffering: global loads of tile t+1 are issued before the MFMAs of tile t,
 //     written to the other LDS buffer afterwards; one barrier per K-tile.
 //   * K order of a conv is (kh, [kw, ci]) so that, in NHWC, every (kh) row is one contiguous run of KS*CIN
@@ -44,10 +44,21 @@ struct IgemmParams {
     uint32_t thr;         // drop threshold (24 bit)
     float scale;          // 1/(1-p)
     uint64_t mc_seed, pair_seq0;
+    // split-K (small-M launches): gridDim.z = k_split slices of the K loop, raw partial sums go to
+    // partial[z][M][N]; splitk_reduce_kernel adds them in z order (deterministic) and applies bias + LeakyReLU
+    int k_split;
+    float* partial;
 };
 
 constexpr int IG_BK = 32;          // K-tile (floats)
-constexpr int IG_BKP = IG_BK + 4;  // LDS row stride (floats): 144 B, keeps ds_read_b128 conflict-free
+constexpr int IG_BKP = IG_BK;      // LDS row stride (floats): 128 B = 8 quads, no padding; quads are XOR-swizzled
+
+// LDS tile layout: row r holds its 8 K-quads (16 B each) at physical quad position (q ^ ((r >> 1) & 7)).
+// With 128-B rows two consecutive rows fill one 256-B bank row; the XOR makes the ds_read_b128 of every 16-lane
+// group hit 16 distinct 16-B slots for both fragment shapes (32x32x2: rows l&31, quad 2q+h; 16x16x4: rows l&15,
+// quad 4q+g) — the padded layout used before was conflict free only for the 32x32 shape (rocprof r01_v1:
+// SQ_LDS_BANK_CONFLICT = 80 % of the LDS cycles of the 16x16 kernels).  Staging writes stay 128 contiguous bytes.
+__device__ __forceinline__ int ig_swz(int row, int quad) { return (quad ^ ((row >> 1) & 7)) * 4; }
 
 // ---------------------------------------------------------------------------------------------
 // A-operand loaders
@@ -217,7 +228,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     f32x4 areg[A_ROWS], breg[B_ROWS];
     uint32_t amask[A_ROWS];
     bool bok[B_ROWS];
-    const int n_iter = (p.Kp + BK - 1) / BK;
+    const int n_iter_total = (p.Kp + BK - 1) / BK;
+    const int it0 = (int)(((long)blockIdx.z * n_iter_total) / p.k_split);
+    const int n_iter = (int)(((long)(blockIdx.z + 1) * n_iter_total) / p.k_split) - it0;
 
     // raw, unconditional global loads of K-tile `it` into registers (masks computed, not yet applied)
     auto g_load = [&](int it) {
@@ -234,36 +247,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     auto s_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; i++)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + i * 32) * BKP + skk]) = L::finalize(p, areg[i], amask[i]);
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + srow + i * 32) * BKP + ig_swz(srow + i * 32, skk >> 2)]) = L::finalize(p, areg[i], amask[i]);
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++)
             if (srow + i * 32 < BN) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = bok[i] ? breg[i][e] : 0.0f;
-                *reinterpret_cast<f32x4*>(&Bs[(buf * BN + srow + i * 32) * BKP + skk]) = v;
+                *reinterpret_cast<f32x4*>(&Bs[(buf * BN + srow + i * 32) * BKP + ig_swz(srow + i * 32, skk >> 2)]) = v;
             }
     };
 
-    g_load(0);
+    g_load(it0);
     s_store(0);
     __syncthreads();
 
     for (int it = 0; it < n_iter; it++) {
         const int buf = it & 1;
-        if (it + 1 < n_iter) g_load(it + 1);
+        if (it + 1 < n_iter) g_load(it0 + it + 1);
 
         if constexpr (MF == 32) {
-            const int frow = lane & 31, fk = (lane >> 5) * 4;
+            const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 f32x4 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; i++)
-                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + wm * WM + i * 32 + frow) * BKP + q * 8 + fk]);
+                for (int i = 0; i < TM; i++) {
+                    const int r = wm * WM + i * 32 + frow;
+                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + r) * BKP + ig_swz(r, 2 * q + fh)]);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + wn * WN + j * 32 + frow) * BKP + q * 8 + fk]);
+                for (int j = 0; j < TN; j++) {
+                    const int r = wn * WN + j * 32 + frow;
+                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + r) * BKP + ig_swz(r, 2 * q + fh)]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -273,16 +290,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
             }
         } else {
-            const int frow = lane & 15, fk = (lane >> 4) * 4;
+            const int frow = lane & 15, fg = lane >> 4;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 f32x4 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; i++)
-                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + wm * WM + i * 16 + frow) * BKP + q * 16 + fk]);
+                for (int i = 0; i < TM; i++) {
+                    const int r = wm * WM + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const f32x4*>(&As[(buf * BM + r) * BKP + ig_swz(r, 4 * q + fg)]);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + wn * WN + j * 16 + frow) * BKP + q * 16 + fk]);
+                for (int j = 0; j < TN; j++) {
+                    const int r = wn * WN + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + r) * BKP + ig_swz(r, 4 * q + fg)]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -300,13 +321,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    // epilogue: bias + LeakyReLU(0.1), NHWC store (lanes run along N = channels)
+    // epilogue: bias + LeakyReLU(0.1), NHWC store (lanes run along N = channels); split-K: raw partial sums
+    const bool split = p.k_split > 1;
+    float* const dst = split ? p.partial + (size_t)blockIdx.z * p.M * p.N : p.out;
     if constexpr (MF == 32) {
         const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + wn * WN + j * 32 + col;
-            const float bv = n < p.N ? p.bias[n] : 0.0f;
+            const float bv = (n < p.N && !split) ? p.bias[n] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -314,7 +337,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                     const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                     if (m < p.M && n < p.N) {
                         float v = acc[i][j][r] + bv;
-                        p.out[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                        dst[(size_t)m * p.N + n] = (v > 0.0f || split) ? v : v * 0.1f;
                     }
                 }
         }
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + wn * WN + j * 16 + col;
-            const float bv = n < p.N ? p.bias[n] : 0.0f;
+            const float bv = (n < p.N && !split) ? p.bias[n] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -331,11 +354,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                     const int m = m0 + wm * WM + i * 16 + rbase + r;
                     if (m < p.M && n < p.N) {
                         float v = acc[i][j][r] + bv;
-                        p.out[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                        dst[(size_t)m * p.N + n] = (v > 0.0f || split) ? v : v * 0.1f;
                     }
                 }
         }
     }
+}
+
+// out[m][n] = LeakyReLU(bias[n] + sum_z partial[z][m][n]), z ascending (fixed order => reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int k_split, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ out) {
+    const size_t total4 = (size_t)M * N / 4;     // N is a multiple of 4 for every layer
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const size_t stride = (size_t)M * N;
+    f32x4 s = *reinterpret_cast<const f32x4*>(partial + i * 4);
+    for (int z = 1; z < k_split; z++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(partial + z * stride + i * 4);
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const int n = (int)((i * 4) % N);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float v = s[e] + b[e]; s[e] = v > 0.0f ? v : v * 0.1f; }
+    *reinterpret_cast<f32x4*>(out + i * 4) = s;
 }
 
 }  // namespace hnet

@@ -12,16 +12,19 @@ struct ConvDesc {
     int block;   // 1..4
 };
 extern const ConvDesc kConvs[20];
-int conv_padded_k(int layer);    // Kp of the packed weight matrix [Cout][Kp]
+int conv_padded_k(int layer);    // Kp of the packed weight matrix [Cout][Kp] (0 for the direct first layers)
+bool conv_is_first_direct(int layer);   // layers served by conv_first.h (weights = MFMA fragments)
 inline int conv_out_dim(int n, int ks, int stride) { return (n + 2 * ((ks - 1) / 2) - ks) / stride + 1; }
 
 // conv + bias + LeakyReLU on NHWC fp32: in [B][H][W][Cin] -> out [B][Ho][Wo][Cout]
+//   ws / ws_floats: optional split-K workspace (nullptr = never split)
 hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, const float* wpacked,
-                       const float* bias, float* out, hipStream_t s);
+                       const float* bias, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0);
 
 // first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
-                            uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s);
+                            uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s,
+                            float* ws = nullptr, size_t ws_floats = 0);
 
 // cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
@@ -43,12 +46,10 @@ hipError_t launch_dlt(const float* dst, float* H, int n, hipStream_t s);
 hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float* bfc, const float* H_in,
                                float* H_out, int batch, hipStream_t s);
 
-// second FC of both heads (Dropout -> Linear(256,8)) -> per-sample outputs; optionally the ensemble/transfer
-//   hidden [B*n_local][512]; mean_s/logvar_s [B][n_local][8] (may be nullptr when finish != 0)
-//   finish: also writes mean [B][8], cov [B][64], Htot [B][9] from the n_local samples
+// second FC of both heads (Dropout -> Linear(256,8)) -> per-sample outputs mean_s / logvar_s [B][n_local][8]
+//   hidden [B*n_local][512]
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
-                            uint64_t pair_seq0, const float* w2, const float* b2, const float* H1,
-                            float* mean_s, float* logvar_s, int finish, float* mean, float* cov, float* Htot,
+                            uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
                             hipStream_t s);
 
 // ensemble/transfer from gathered per-sample outputs [B][n][8]

@@ -259,99 +259,91 @@ hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float*
 
 // ---------------------------------------------------------------------------------------------
 // heads, second half: Dropout -> Linear(256, 8) for both heads and every local MC sample
-//   (model_to_trace.py:226-227,233-234; run_fc :252-256 scales the uncertainty head by 1e-3), then
-//   optionally the ensemble + transfer (geom.h finish_pair).  One workgroup per frame pair.
+//   (model_to_trace.py:226-227,233-234; run_fc :252-256 scales the uncertainty head by 1e-3).
 //   hidden [B*n_local][512] holds LeakyReLU(Linear(5120,256)) of both heads (columns 0..255 mean head).
+//   One workgroup per (pair, chunk of 4 samples): 64 dot products of length 256, four lanes per dot; every lane
+//   walks its 64 elements in a rotated order so that the 32 lanes served per LDS cycle hit 32 different banks.
+//   Per-sample outputs go to mean_s / logvar_s [B][n_local][8]; the ensemble is a separate launch (mc_finish).
 // ---------------------------------------------------------------------------------------------
-constexpr int FC2_CHUNK = 8;   // samples staged in LDS per pass
+constexpr int FC2_CHUNK = 4;
 
 __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
                                                         uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        const float* __restrict__ H1, float* __restrict__ mean_s,
-                                                        float* __restrict__ logvar_s, int finish,
-                                                        float* __restrict__ mean, float* __restrict__ cov,
-                                                        float* __restrict__ Htot) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* w2s = sm;                         // [2][8][256]
-    float* hid = sm + 4096;                  // [FC2_CHUNK][512] after dropout
-    float* outs = hid + FC2_CHUNK * 512;     // [n_local][16]  (8 mean, 8 logvar)
-    const int b = blockIdx.x, tid = threadIdx.x;
+                                                        float* __restrict__ mean_s, float* __restrict__ logvar_s) {
+    __shared__ float w2s[4096];                  // [2][8][256]
+    __shared__ float hid[FC2_CHUNK * 512];       // after dropout
+    const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
+    const int b = blockIdx.x / n_chunks, c0 = (blockIdx.x % n_chunks) * FC2_CHUNK;
+    const int nc = min(FC2_CHUNK, n_local - c0);
+    const int tid = threadIdx.x;
     for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
     const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (uint64_t)b);
-    for (int c0 = 0; c0 < n_local; c0 += FC2_CHUNK) {
-        const int nc = min(FC2_CHUNK, n_local - c0);
-        __syncthreads();
-        for (int i = tid; i < nc * 512; i += 256) {
-            const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
-            const uint32_t pre = hnet_mask_prefix(key, (uint32_t)(2 * head + 1), (uint32_t)(s_begin + c0 + sl));
-            const float v = hidden[((size_t)b * n_local + c0 + sl) * 512 + col];
-            hid[i] = hnet_mask_keep(pre, (uint32_t)j, thr) ? v * scale : 0.0f;
-        }
-        __syncthreads();
-        // 8 samples x 16 outputs = 128 dots of length 256, two threads per dot
-        const int d = tid >> 1, half = tid & 1;
-        const int sl = d >> 4, o = d & 15, head = o >> 3, oi = o & 7;
-        float acc = 0.0f;
+    for (int i = tid; i < FC2_CHUNK * 512; i += 256) {
+        const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
+        float v = 0.0f;
         if (sl < nc) {
-            const float* hrow = hid + sl * 512 + head * 256 + half * 128;
-            const float* wrow = w2s + (head * 8 + oi) * 256 + half * 128;
-#pragma unroll 8
-            for (int j = 0; j < 128; j++) acc = fmaf(hrow[j], wrow[j], acc);
+            const uint32_t pre = hnet_mask_prefix(key, (uint32_t)(2 * head + 1), (uint32_t)(s_begin + c0 + sl));
+            const float x = hidden[((size_t)b * n_local + c0 + sl) * 512 + col];
+            v = hnet_mask_keep(pre, (uint32_t)j, thr) ? x * scale : 0.0f;
         }
-        acc += __shfl_xor(acc, 1);
-        if (sl < nc && half == 0) {
-            float v = acc + b2[head * 8 + oi];
-            if (head == 1) v *= 1e-3f;
-            outs[(c0 + sl) * 16 + o] = v;
-        }
+        hid[i] = v;
     }
     __syncthreads();
-    // per-sample outputs to global, [B][n_local][8] each
-    if (mean_s && logvar_s)
-        for (int i = tid; i < n_local * 16; i += 256) {
-            const int s = i >> 4, o = i & 15;
-            if (o < 8) mean_s[((size_t)b * n_local + s) * 8 + o] = outs[i];
-            else logvar_s[((size_t)b * n_local + s) * 8 + (o - 8)] = outs[i];
-        }
-    if (finish) {
-        // repack to the [n][8] layout finish_pair expects (in place is not possible: use the hid area)
-        float* ms = hid;                    // n_local*8 <= FC2_CHUNK*512 for n_local <= 512
-        float* ls = hid + n_local * 8;
-        __syncthreads();
-        for (int i = tid; i < n_local * 16; i += 256) {
-            const int s = i >> 4, o = i & 15;
-            if (o < 8) ms[s * 8 + o] = outs[i]; else ls[s * 8 + o - 8] = outs[i];
-        }
-        __syncthreads();
-        if (tid == 0) finish_pair(ms, ls, n_local, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
+    const int d = tid >> 2, part = tid & 3;      // dot index (sample, output), quarter of the dot
+    const int sl = d >> 4, o = d & 15, head = o >> 3, oi = o & 7;
+    const float* hrow = hid + sl * 512 + head * 256 + part * 64;
+    const float* wrow = w2s + (head * 8 + oi) * 256 + part * 64;
+    const int rot = (o & 7) * 4 + part;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) {
+        const int jj = (j + rot) & 63;
+        acc = fmaf(hrow[jj], wrow[jj], acc);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part == 0 && sl < nc) {
+        float v = acc + b2[head * 8 + oi];
+        float* dst = head == 0 ? mean_s : logvar_s;
+        if (head == 1) v *= 1e-3f;
+        dst[((size_t)b * n_local + c0 + sl) * 8 + oi] = v;
     }
 }
 
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
-                            uint64_t pair_seq0, const float* w2, const float* b2, const float* H1,
-                            float* mean_s, float* logvar_s, int finish, float* mean, float* cov, float* Htot,
+                            uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
                             hipStream_t s) {
-    if (n_local < 1 || n_local > 256) return hipErrorInvalidValue;
-    const size_t shmem = (4096 + FC2_CHUNK * 512 + (size_t)n_local * 16) * sizeof(float);
-    hipLaunchKernelGGL(heads_fc2_kernel, dim3(batch), dim3(256), shmem, s, hidden, n_local, s_begin,
-                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, w2, b2, H1, mean_s, logvar_s,
-                       finish, mean, cov, Htot);
+    if (n_local < 1 || !mean_s || !logvar_s) return hipErrorInvalidValue;
+    const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
+    hipLaunchKernelGGL(heads_fc2_kernel, dim3((unsigned)(batch * n_chunks)), dim3(256), 0, s, hidden, n_local, s_begin,
+                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, w2, b2, mean_s, logvar_s);
     return hipGetLastError();
 }
 
-__global__ void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
-                                 const float* __restrict__ H1, int batch, float* __restrict__ mean,
-                                 float* __restrict__ cov, float* __restrict__ Htot) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    finish_pair(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + b * 8, cov + b * 64,
-                Htot ? Htot + b * 9 : nullptr);
+// ensemble + transfer + assembly from per-sample outputs [B][n][8]: 8 lanes per pair compute the 8 component
+// statistics (two passes over the samples, model_to_trace.py:274-280), lane 0 of the group finishes (geom.h).
+__global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
+                                                       const float* __restrict__ H1, int batch, float* __restrict__ mean,
+                                                       float* __restrict__ cov, float* __restrict__ Htot) {
+    const int t = threadIdx.x, i = t & 7, grp = t >> 3;
+    const int b = blockIdx.x * 8 + grp;
+    const bool ok = b < batch;
+    const int bb = ok ? b : 0;
+    double pb, en;
+    ensemble_component(mean_s + (size_t)bb * n * 8, logvar_s + (size_t)bb * n * 8, n, i, &pb, &en);
+    double pbar[8], ens[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        pbar[k] = __shfl(pb, grp * 8 + k);
+        ens[k] = __shfl(en, grp * 8 + k);
+    }
+    if (ok && i == 0) transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
                             float* mean, float* cov, float* Htot, hipStream_t s) {
-    hipLaunchKernelGGL(mc_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
+    hipLaunchKernelGGL(mc_finish_kernel, dim3((batch + 7) / 8), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
     return hipGetLastError();
 }
 

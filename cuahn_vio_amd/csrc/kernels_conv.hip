@@ -1,7 +1,10 @@
 // kernels_conv.hip — instantiations and dispatch of the implicit-GEMM kernel (igemm.h) for the 20
 // convolution layers of HomographyNet (reference model_to_trace.py:88-113, :210-216) and the heads' first FC.
 #include "igemm.h"
+#include "conv_first.h"
 #include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace hnet {
 
@@ -17,38 +20,64 @@ const ConvDesc kConvs[20] = {
     {"block_4_6", 256, 256, 3, 2, 32, 4},
 };
 
+bool conv_is_first_direct(int layer) { return layer == 7 || layer == 13; }   // block_3_0, block_4_0: conv_first.h
+
 int conv_padded_k(int layer) {
     const ConvDesc& d = kConvs[layer];
+    if (conv_is_first_direct(layer)) return 0;
     const int rl = d.ks * d.cin;
     const int spr = (rl + d.seg - 1) / d.seg;
     return d.ks * spr * d.seg;
 }
 
+// Small-M launches (batch-1 latency: a 4x5 feature map is 20 GEMM rows) would run a handful of workgroups through a
+// long serial K loop (72 K-tiles ~ 72 us).  They are cut along K into gridDim.z slices whose raw partial sums are
+// combined in a fixed order by splitk_reduce_kernel: deterministic, one extra launch.
 template <class L, int BM, int BN, int WGM, int MF>
-static hipError_t run(const IgemmParams& p, hipStream_t s) {
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+static hipError_t run(IgemmParams p, hipStream_t s, float* ws, size_t ws_floats) {
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
+    const long tiles = (long)grid.x * grid.y;
+    const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
+    int split = 1;
+    if (ws && tiles < 192 && n_iter >= 8 && (p.N % 4) == 0) {
+        split = (int)std::min<long>(std::min<long>(n_iter / 3, (384 + tiles - 1) / tiles), 64);
+        const size_t per = (size_t)p.M * p.N;
+        if ((size_t)split * per > ws_floats) split = (int)(ws_floats / per);
+        if (split < 2) split = 1;
+    }
+    p.k_split = split;
+    p.partial = ws;
+    grid.z = split;
     hipLaunchKernelGGL((igemm_kernel<L, BM, BN, WGM, MF>), grid, dim3(256), 0, s, p);
+    if (split > 1) {
+        const size_t total4 = (size_t)p.M * p.N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out);
+    }
     return hipGetLastError();
 }
 
 // tile choice: Cout <= 16 -> 16x16x4 MFMA, BN = 16;  Cout = 32 -> BN = 32;  else BN = 64.
 // BM = 128 when that still gives >= 2 workgroups per CU worth of tiles, else 64.
 template <int CIN, int KS, int STRIDE, int SEG, int COUT>
-static hipError_t run_conv(const IgemmParams& p, hipStream_t s) {
+static hipError_t run_conv(const IgemmParams& p, hipStream_t s, float* ws, size_t wsn) {
     typedef ConvLoader<CIN, KS, STRIDE, SEG> L;
     if constexpr (COUT <= 16) {
-        return run<L, 128, 16, 4, 16>(p, s);
+        return run<L, 128, 16, 4, 16>(p, s, ws, wsn);
     } else if constexpr (COUT == 32) {
-        return run<L, 128, 32, 4, 32>(p, s);
+        return run<L, 128, 32, 4, 32>(p, s, ws, wsn);
     } else {
+        static const int force = std::getenv("HNET_TILE") ? std::atoi(std::getenv("HNET_TILE")) : -1;   // experiments
         const long tiles128 = (long)((p.M + 127) / 128) * (COUT / 64);
-        if (tiles128 >= 512) return run<L, 128, 64, 2, 32>(p, s);
-        return run<L, 64, 64, 2, 32>(p, s);
+        if (force == 0) return run<L, 64, 64, 2, 32>(p, s, ws, wsn);
+        if (force == 1) return run<L, 128, 64, 2, 32>(p, s, ws, wsn);
+        if constexpr (COUT >= 128) { if (force == 2) return run<L, 128, 128, 2, 32>(p, s, ws, wsn); }
+        (void)tiles128;
+        return run<L, 64, 64, 2, 32>(p, s, ws, wsn);   // 64x64: 4 workgroups/CU; measured faster than 128x64 / 128x128 on every layer
     }
 }
 
 hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, const float* wpacked,
-                       const float* bias, float* out, hipStream_t s) {
+                       const float* bias, float* out, hipStream_t s, float* ws, size_t wsn) {
     if (layer < 0 || layer >= 20) return hipErrorInvalidValue;
     const ConvDesc& d = kConvs[layer];
     IgemmParams p = {};
@@ -59,26 +88,35 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
     p.M = batch * p.Ho * p.Wo;
     p.N = d.cout;
     p.Kp = conv_padded_k(layer);
+    if (conv_is_first_direct(layer)) {   // wpacked = MFMA B-fragments [NFRAG][64] (pack_first_weights)
+        if (d.cout == 8) {
+            const int tx = (w + 63) / 64, ty = (h + 15) / 16;
+            hipLaunchKernelGGL(conv7_c2_s1_kernel<8>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, h, w, tx, ty);
+        } else {
+            const int tx = (w + 31) / 32, ty = (h + 15) / 16;
+            hipLaunchKernelGGL(conv7_c2_s1_kernel<16>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, h, w, tx, ty);
+        }
+        return hipGetLastError();
+    }
     switch (layer) {
-        case 0:  return run_conv<2, 7, 2, 16, 128>(p, s);
-        case 1:  return run_conv<128, 5, 2, 32, 128>(p, s);
-        case 2: case 5: case 11: case 18: return run_conv<128, 3, 2, 32, 256>(p, s);
-        case 3:  return run_conv<2, 7, 2, 16, 64>(p, s);
-        case 4:  return run_conv<64, 5, 2, 32, 128>(p, s);
-        case 6: case 12: case 19: return run_conv<256, 3, 2, 32, 256>(p, s);
-        case 7:  return run_conv<2, 7, 1, 16, 16>(p, s);
-        case 8:  return run_conv<16, 5, 2, 16, 32>(p, s);
-        case 9: case 16: return run_conv<32, 3, 2, 32, 64>(p, s);
-        case 10: case 17: return run_conv<64, 3, 2, 32, 128>(p, s);
-        case 13: return run_conv<2, 7, 1, 16, 8>(p, s);
-        case 14: return run_conv<8, 5, 2, 8, 16>(p, s);
-        case 15: return run_conv<16, 3, 2, 16, 32>(p, s);
+        case 0:  return run_conv<2, 7, 2, 16, 128>(p, s, ws, wsn);
+        case 1:  return run_conv<128, 5, 2, 32, 128>(p, s, ws, wsn);
+        case 2: case 5: case 11: case 18: return run_conv<128, 3, 2, 32, 256>(p, s, ws, wsn);
+        case 3:  return run_conv<2, 7, 2, 16, 64>(p, s, ws, wsn);
+        case 4:  return run_conv<64, 5, 2, 32, 128>(p, s, ws, wsn);
+        case 6: case 12: case 19: return run_conv<256, 3, 2, 32, 256>(p, s, ws, wsn);
+        case 8:  return run_conv<16, 5, 2, 16, 32>(p, s, ws, wsn);
+        case 9: case 16: return run_conv<32, 3, 2, 32, 64>(p, s, ws, wsn);
+        case 10: case 17: return run_conv<64, 3, 2, 32, 128>(p, s, ws, wsn);
+        case 14: return run_conv<8, 5, 2, 8, 16>(p, s, ws, wsn);
+        case 15: return run_conv<16, 3, 2, 16, 32>(p, s, ws, wsn);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
-                            uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s) {
+                            uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s,
+                            float* ws, size_t wsn) {
     IgemmParams p = {};
     p.A = feat; p.Wp = w1packed; p.bias = b1; p.out = hidden;
     p.M = batch * n_local;
@@ -90,9 +128,9 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
     p.scale = 1.0f / (1.0f - p_drop);
     p.mc_seed = mc_seed;
     p.pair_seq0 = pair_seq0;
-    const long tiles128 = (long)((p.M + 127) / 128) * 8;
-    if (tiles128 >= 512) return run<HeadLoader, 128, 64, 2, 32>(p, s);
-    return run<HeadLoader, 64, 64, 2, 32>(p, s);
+    static const int force = std::getenv("HNET_TILE") ? std::atoi(std::getenv("HNET_TILE")) : -1;   // experiments
+    if (force == 1) return run<HeadLoader, 128, 64, 2, 32>(p, s, ws, wsn);
+    return run<HeadLoader, 64, 64, 2, 32>(p, s, ws, wsn);
 }
 
 }  // namespace hnet
