@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm.h"
+#include "igemm_s3.h"
 
 namespace hnet {
 
@@ -28,14 +29,19 @@ template <> struct FirstCfg<16> {
 };
 
 // wfrag: [NFRAG][64] floats, fragment t of lane l (host-packed, see pack_first_weights in hnet_capi.hip)
+// out16 != nullptr: the output is written as three bf16 planes (S3, igemm_s3.h) instead of fp32
 template <int COUT>
 __global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restrict__ in, const float* __restrict__ wfrag,
                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                          uint16_t* __restrict__ out16, size_t o_plane,
                                                           int H, int W, int tiles_x, int tiles_y) {
     typedef FirstCfg<COUT> C;
     constexpr int TH = C::TH, TW = C::TW, PH = TH + 6, PW = TW + 8;   // patch: 3-px halo + 2 columns for kw' = 7 / padding
     constexpr int PROW = PW * 2;                                       // floats per patch row
     __shared__ __attribute__((aligned(16))) float patch[PH * PROW];
+    // wave-private staging of one split output tile: [plane][rows][cols] bf16 (16x16 for Cout 8, 32x32 for Cout 16)
+    constexpr int ST_ROWS = COUT == 8 ? 16 : 32;
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4 * 3 * ST_ROWS * ST_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -78,14 +84,42 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restric
             }
             // D: col n = lane&15 = (dx, co); row = 4*(lane>>4) + r = pixel pair
             const int y = y0 + row;
+            if (out16 == nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int pp = half * 16 + 4 * g + r;
-                const int x = x0 + 2 * pp + (m >> 3);
-                if (y < H && x < W) {
-                    const float v = acc[r] + bv;
-                    out[(((size_t)b * H + y) * W + x) * 8 + (m & 7)] = v > 0.f ? v : v * 0.1f;
+                for (int r = 0; r < 4; r++) {
+                    const int pp = half * 16 + 4 * g + r;
+                    const int x = x0 + 2 * pp + (m >> 3);
+                    if (y < H && x < W) {
+                        const float v = acc[r] + bv;
+                        out[(((size_t)b * H + y) * W + x) * 8 + (m & 7)] = v > 0.f ? v : v * 0.1f;
+                    }
                 }
+            } else {
+                // tile = 16 pixel pairs x 16 (dx,co): per plane 16 rows of 32 bytes = 2 pieces of 16 B (one pixel each)
+                uint16_t* st = stage + wave * (3 * 16 * 16);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[r] + bv;
+                    v = v > 0.f ? v : v * 0.1f;
+                    uint16_t sa, sb, sc;
+                    split3(v, sa, sb, sc);
+                    const int trow = 4 * g + r;
+                    st[(0 * 16 + trow) * 16 + m] = sa;
+                    st[(1 * 16 + trow) * 16 + m] = sb;
+                    st[(2 * 16 + trow) * 16 + m] = sc;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int piece = q * 64 + lane;             // 96 pieces: [plane][row][dx]
+                    if (piece < 96) {
+                        const int pl = piece >> 5, rem = piece & 31, trow = rem >> 1, dx = rem & 1;
+                        const int x = x0 + 2 * (half * 16 + trow) + dx;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 16 + trow) * 16 + dx * 8]);
+                        if (y < H && x < W) *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * H + y) * W + x) * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
             }
         }
     } else {
@@ -110,15 +144,43 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restric
                 for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], wreg[kh * 8 + 4 + e], acc, 0, 0, 0);
             }
             // D: col n = lane&31 = (dx, co); row = (r&3) + 8*(r>>2) + 4*(lane>>5) = (row-in-pair-of-rows, pixel pair)
+            if (out16 == nullptr) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int y = y0 + mt * 2 + (mr >> 4);
-                const int x = x0 + 2 * (mr & 15) + (m >> 4);
-                if (y < H && x < W) {
-                    const float v = acc[r] + bv;
-                    out[(((size_t)b * H + y) * W + x) * 16 + (m & 15)] = v > 0.f ? v : v * 0.1f;
+                for (int r = 0; r < 16; r++) {
+                    const int mr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int y = y0 + mt * 2 + (mr >> 4);
+                    const int x = x0 + 2 * (mr & 15) + (m >> 4);
+                    if (y < H && x < W) {
+                        const float v = acc[r] + bv;
+                        out[(((size_t)b * H + y) * W + x) * 16 + (m & 15)] = v > 0.f ? v : v * 0.1f;
+                    }
                 }
+            } else {
+                // tile = 32 (row-of-pair, pixel pair) x 32 (dx,co): per plane 32 rows of 64 bytes = 4 pieces (dx, co-half)
+                uint16_t* st = stage + wave * (3 * 32 * 32);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int mr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = acc[r] + bv;
+                    v = v > 0.f ? v : v * 0.1f;
+                    uint16_t sa, sb, sc;
+                    split3(v, sa, sb, sc);
+                    st[(0 * 32 + mr) * 32 + m] = sa;
+                    st[(1 * 32 + mr) * 32 + m] = sb;
+                    st[(2 * 32 + mr) * 32 + m] = sc;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const int piece = q * 64 + lane;             // 384 pieces: [plane][32 rows][4 chunks]
+                    const int pl = piece >> 7, rem = piece & 127, mr = rem >> 2, ch = rem & 3;
+                    const int y = y0 + mt * 2 + (mr >> 4);
+                    const int x = x0 + 2 * (mr & 15) + (ch >> 1);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 32 + mr) * 32 + ch * 8]);
+                    if (y < H && x < W)
+                        *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * H + y) * W + x) * 16 + (ch & 1) * 8) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
             }
         }
     }

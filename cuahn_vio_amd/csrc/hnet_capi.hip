@@ -6,6 +6,7 @@
 #include "../../include/hnet.h"
 #include "geom.h"
 #include "kernels.h"
+#include "s3_format.h"
 
 #include <algorithm>
 #include <chrono>
@@ -73,6 +74,11 @@ struct hnet_ctx {
     float* fc_b[3] = {};
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     // activations (device), sized for cfg.max_batch
+    // split-bf16 mode (HNET_PREC_BF16X3): activations of the layers feeding a conv are three bf16 planes
+    bool s3 = false;
+    uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
+    uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
+    size_t act_count[20] = {};         // elements per pair of layer l's output
     float* x_in[4] = {};
     float* act[20] = {};
     int act_c[20], act_h[20], act_w[20];
@@ -241,10 +247,21 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         float* x = c->x_in[blk] + P0 * h * w * 2;
         STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hm : nullptr, 8 >> blk, x, B, s));
         const float* in = x;
+        const uint16_t* in16 = nullptr;
+        size_t in_plane = 0;
+        const size_t MB = (size_t)g.max_batch;
         for (int l = first[blk]; l <= last[blk]; l++) {
-            float* o = c->act[l] + P0 * c->act_c[l] * c->act_h[l] * c->act_w[l];
-            STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn));
+            const size_t cnt = c->act_count[l];
+            float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
+            uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
+            if (c->s3 && conv_is_s3_layer(l))
+                STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn));
+            else
+                STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
+            in16 = o16;
+            in_plane = MB * cnt;
             h = c->act_h[l];
             w = c->act_w[l];
         }
@@ -328,7 +345,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
-    if (g.precision != HNET_PREC_FP32) return HNET_ERR_UNSUPPORTED;
+    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3) return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
     if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
         return HNET_ERR_INVALID_ARG;
@@ -339,6 +356,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
     hnet_ctx* c = new hnet_ctx();
     c->cfg = g;
+    c->s3 = g.precision == HNET_PREC_BF16X3;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -375,7 +393,17 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const Tensor* bi = b.find(pre + "bias", d.cout);
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
         if (conv_is_first_direct(l)) CK(upload(&c->conv_w[l], pack_first_weights(w->data, d.cout)));
-        else CK(upload(&c->conv_w[l], pack_conv(w->data, d, conv_padded_k(l))));
+        else {
+            const std::vector<float> packed = pack_conv(w->data, d, conv_padded_k(l));
+            CK(upload(&c->conv_w[l], packed));
+            if (c->s3 && conv_is_s3_layer(l)) {     // exact 3-way bf16 split of every weight: planes [3][Cout][Kp]
+                std::vector<uint16_t> pl(packed.size() * 3);
+                for (size_t i = 0; i < packed.size(); i++)
+                    split3(packed[i], pl[i], pl[packed.size() + i], pl[2 * packed.size() + i]);
+                CK(hipMalloc((void**)&c->conv_w16[l], pl.size() * 2));
+                CK(hipMemcpy(c->conv_w16[l], pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+            }
+        }
         CK(upload(&c->conv_b[l], std::vector<float>(bi->data, bi->data + d.cout)));
     }
     for (int k = 0; k < 3; k++) {
@@ -415,7 +443,9 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
             w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
             c->act_c[l] = kConvs[l].cout; c->act_h[l] = h; c->act_w[l] = w;
-            CK(dalloc(&c->act[l], MB * h * w * kConvs[l].cout));
+            c->act_count[l] = (size_t)h * w * kConvs[l].cout;
+            if (c->s3 && l != last[blk]) CK(hipMalloc((void**)&c->act16[l], 3 * MB * c->act_count[l] * 2));   // feeds a conv: S3 planes
+            else CK(dalloc(&c->act[l], MB * c->act_count[l]));
         }
     }
     c->ws_floats = (size_t)16 << 20;
@@ -503,7 +533,7 @@ void hnet_destroy(hnet_ctx* c) {
     (void)hipSetDevice(c->cfg.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); }
+    for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
@@ -749,9 +779,26 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
     float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
     HIPCHK(c, dalloc(&d_a, n_in)); HIPCHK(c, dalloc(&d_b, n_in)); HIPCHK(c, dalloc(&d_c, n_out)); HIPCHK(c, dalloc(&d_d, n_out));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
-    HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], d_c, c->stream));
-    HIPCHK(c, launch_nhwc_to_nchw(d_c, d_d, batch, d.cout, ho, wo, c->stream));
+    if (!c->s3) {
+        HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
+        HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], d_c, c->stream));
+        HIPCHK(c, launch_nhwc_to_nchw(d_c, d_d, batch, d.cout, ho, wo, c->stream));
+    } else {   // split-bf16 mode: the layer reads / writes three bf16 planes, exactly as inside the forward
+        uint16_t *p_in = nullptr, *p_out = nullptr;
+        HIPCHK(c, hipMalloc((void**)&p_in, 3 * n_in * 2 + 64));
+        HIPCHK(c, hipMalloc((void**)&p_out, 3 * n_out * 2 + 64));
+        if (conv_is_s3_layer(layer)) {
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
+                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream));
+        } else {
+            HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
+        }
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(p_in); (void)hipFree(p_out);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_c); (void)hipFree(d_d);
@@ -783,7 +830,11 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     if (cap < n) return fail(c, HNET_ERR_INVALID_ARG, "buffer too small");
     float* d_t = nullptr;
     HIPCHK(c, dalloc(&d_t, n));
-    HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
+    if (c->act16[layer])
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
+                                             c->act_h[layer], c->act_w[layer], c->stream));
+    else
+        HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_t, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_t);

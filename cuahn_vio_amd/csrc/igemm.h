@@ -48,6 +48,9 @@ struct IgemmParams {
     // partial[z][M][N]; splitk_reduce_kernel adds them in z order (deterministic) and applies bias + LeakyReLU
     int k_split;
     float* partial;
+    // optional S3 output (three bf16 planes, igemm_s3.h) instead of fp32; 32x32 MFMA tiles only, no split-K
+    uint16_t* out16;
+    size_t o_plane;
 };
 
 constexpr int IG_BK = 32;          // K-tile (floats)
@@ -172,6 +175,55 @@ struct HeadLoader {
         return v;
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// S3 epilogue shared by the fp32 and the split-bf16 kernels: bias + LeakyReLU(0.1), split each value into 3 bf16
+// planes, stage the wave's 32x32 tile per plane in wave-private LDS and write 16 bytes per lane (64-byte rows).
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint16_t ig_bf16_rn(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_store_s3(f32x16 (&acc)[TM][TN], uint16_t* st, const float* bias, uint16_t* out16,
+                                               size_t o_plane, int M, int N, int mw, int nw, int lane) {
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int nb = nw + j * 32;
+        const float bv = (nb + col) < N ? bias[nb + col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mb = mw + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + rbase;
+                float v = acc[i][j][r] + bv;
+                v = v > 0.0f ? v : v * 0.1f;
+                const uint16_t a = ig_bf16_rn(v);
+                const float r1 = v - __uint_as_float((uint32_t)a << 16);
+                const uint16_t b = ig_bf16_rn(r1);
+                const float r2 = r1 - __uint_as_float((uint32_t)b << 16);
+                const uint16_t c = ig_bf16_rn(r2);
+                st[(0 * 32 + row) * 32 + col] = a;
+                st[(1 * 32 + row) * 32 + col] = b;
+                st[(2 * 32 + row) * 32 + col] = c;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const int piece = q * 64 + lane;             // 3 planes x 32 rows x 4 chunks of 16 B
+                const int pl = piece >> 7, rem = piece & 127, row = rem >> 2, ch = rem & 3;
+                const int m = mb + row, n = nb + ch * 8;
+                const ig_u32x4 v = *reinterpret_cast<const ig_u32x4*>(&st[(pl * 32 + row) * 32 + ch * 8]);
+                if (m < M && n < N) *reinterpret_cast<ig_u32x4*>(out16 + pl * o_plane + (size_t)m * N + n) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernel
@@ -325,6 +377,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const bool split = p.k_split > 1;
     float* const dst = split ? p.partial + (size_t)blockIdx.z * p.M * p.N : p.out;
     if constexpr (MF == 32) {
+        if (p.out16 != nullptr) {
+            igemm_store_s3<TM, TN>(acc, reinterpret_cast<uint16_t*>(smem) + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane,
+                                   p.M, p.N, m0 + wm * WM, n0 + wn * WN, lane);
+            return;
+        }
         const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < TN; j++) {

@@ -1,0 +1,305 @@
+// igemm_s3.h — implicit-GEMM convolution on the bf16 matrix cores with fp32-grade accuracy ("split-bf16 x3").
+//
+// CDNA4 has no TF32/xf32; its exact-fp32 MFMA runs at 1/16 of the bf16 rate and, sustained, is power limited
+// to ~100-125 TFLOP/s on this part (tools/mfma_peak.hip).  Every fp32 value v is therefore carried as THREE bf16
+// planes  v = v1 + v2 + v3  (v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2): 3 x 8 significant bits = the
+// 24 bits of fp32, the split is exact), and a product a*b is evaluated as the six partial products
+//     a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1        (dropped: a2b3, a3b2, a3b3 <= 2^-24 |ab| each)
+// by six v_mfma_f32_32x32x16_bf16 accumulating in fp32.  bf16 x bf16 products are exact in fp32, so the result has
+// the accuracy of an fp32 dot product (measured against the oracle in tests/test_gpu_parity.py) at 6/16 of the
+// fp32-MFMA issue cycles.
+//
+// Data layout ("S3"): an activation tensor is three NHWC bf16 planes [3][B][H][W][C]; weights are pre-split on the
+// host to [3][Cout][Kp] with the same K order as igemm.h ((kh, [kw, ci]) segments).  Producers write S3 in their
+// epilogue (one split per output element, amortised over the 6-25 times each element is consumed), so the staging
+// path is pure 16-byte copies: global -> registers -> ds_write_b128, no conversion.
+//
+// Tile: 256 threads = 4 waves, each wave a 32x32 (x TM x TN) accumulator tile; K-tile 32; LDS per operand and plane
+// [rows][32] bf16 = 64-byte rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3 so that the
+// ds_read_b128 of an MFMA fragment (rows l&31, chunk 2*step + (l>>5)) is bank-conflict free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "igemm.h"
+#include "s3_format.h"
+
+namespace hnet {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct S3Params {
+    const uint16_t* A;     // input planes [3][...] NHWC bf16
+    size_t a_plane;        // elements per input plane
+    const uint16_t* Wp;    // weights [3][N][Kp] bf16
+    size_t w_plane;
+    const float* bias;     // [N]
+    uint16_t* out16;       // S3 output planes (or nullptr)
+    size_t o_plane;
+    float* out32;          // fp32 output [M][N] (last layer of a block) (or nullptr)
+    int M, N, Kp;
+    int H, W, Ho, Wo;
+    int k_split;           // gridDim.z slices of the K loop (small-M launches), raw fp32 partials -> partial[z][M][N]
+    float* partial;
+};
+
+template <int CIN_, int KS_, int STRIDE_, int SEG_>
+struct ConvLoaderS3 {
+    static constexpr int CIN = CIN_, KS = KS_, STRIDE = STRIDE_, SEG = SEG_;
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int RL = KS * CIN;
+    static constexpr int SPR = (RL + SEG - 1) / SEG;
+    static constexpr int TOTAL_SEGS = KS * SPR;
+    static constexpr int KP = TOTAL_SEGS * SEG;
+    static_assert(IG_BK % SEG == 0 && SEG % 8 == 0 && CIN % 8 == 0, "16-byte chunks must stay inside one pixel");
+    static_assert(RL % SEG == 0, "no padded segments for Cin >= 8 layers");
+
+    struct Row { int pix0, iy0, ix0; bool valid; };
+
+    __device__ static inline Row make_row(const S3Params& p, int m) {
+        Row r;
+        r.valid = m < p.M;
+        const int mm = r.valid ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        r.iy0 = oy * STRIDE - PAD;
+        r.ix0 = ox * STRIDE - PAD;
+        r.pix0 = (b * p.H + r.iy0) * p.W + r.ix0;
+        return r;
+    }
+    // element offset (within a plane) of the 8 K-values starting at padded-K index kp, and whether they are real
+    __device__ static inline size_t offset(const S3Params& p, const Row& r, int kp, bool& ok) {
+        const int sg = kp / SEG, within = kp % SEG;
+        const int kh = sg / SPR;
+        const int rr = (sg % SPR) * SEG + within;
+        const int kw = rr / CIN, ci = rr % CIN;
+        const int iy = r.iy0 + kh, ix = r.ix0 + kw;
+        ok = r.valid && sg < TOTAL_SEGS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        return ok ? ((size_t)(r.pix0 + kh * p.W + kw)) * CIN + ci : 0;
+    }
+};
+
+__device__ __forceinline__ int s3_swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }   // bf16 elements
+
+// OUT32 = true: fp32 [M][N] output (feeds an FC);  false: S3 planes
+// NBUF = 2: double-buffered LDS, one barrier per K-tile.  NBUF = 1: single LDS buffer, two barriers per K-tile but half
+// the LDS, i.e. twice the resident workgroups per CU: with 6 MFMAs x 32 cycles per k16-step a K-tile lasts ~400 cycles,
+// less than the latency of its own prefetch, so the latency has to be hidden by more workgroups instead.
+template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1>
+__global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
+    constexpr int BK = IG_BK;                         // 32 K-values = 4 chunks of 8
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
+    constexpr int A_ROWS = (BM + 63) / 64, B_ROWS = (BN + 63) / 64;   // rows staged per thread and plane (256 threads = 64 rows x 4 chunks)
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
+    constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
+
+    // [buf][plane][rows][32]; the epilogue reuses it as a store staging area
+    constexpr int SMEM_ELEMS = NBUF * 3 * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NBUF * 3 * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
+    uint16_t* As = smem;
+    uint16_t* Bs = smem + NBUF * 3 * TILE_A;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int srow = tid >> 2, schunk = tid & 3;      // staging: 64 rows x 4 chunks
+
+    typename L::Row rows[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, (srow + i * 64) < BM ? m0 + srow + i * 64 : p.M);
+    const uint16_t* wsrc[B_ROWS];
+    bool wvalid[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) {
+        const int n = n0 + srow + i * 64;
+        wvalid[i] = n < p.N && (srow + i * 64) < BN;
+        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n : 0) * p.Kp + schunk * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
+    bool aok[A_ROWS], bok[B_ROWS];
+    const int n_iter_total = (p.Kp + BK - 1) / BK;
+    const int it0 = (int)(((long)blockIdx.z * n_iter_total) / p.k_split);
+    const int n_iter = (int)(((long)(blockIdx.z + 1) * n_iter_total) / p.k_split) - it0;
+
+    auto g_load = [&](int it) {
+        const int kp = it * BK + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            const size_t off = L::offset(p, rows[i], kp, aok[i]);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) areg[i][pl] = *reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane + off);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++) {
+            bok[i] = wvalid[i] && kp < p.Kp;
+            const uint16_t* src = bok[i] ? wsrc[i] + it * BK : p.Wp;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) breg[i][pl] = *reinterpret_cast<const u32x4*>(src + pl * p.w_plane);
+        }
+    };
+    auto s_store = [&](int buf) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            const int r = srow + i * 64;
+            if (r < BM) {
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, schunk)]) = aok[i] ? areg[i][pl] : z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++) {
+            const int r = srow + i * 64;
+            if (r < BN) {
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    *reinterpret_cast<u32x4*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz(r, schunk)]) = bok[i] ? breg[i][pl] : z;
+            }
+        }
+    };
+
+    g_load(it0);
+    s_store(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int it = 0; it < n_iter; it++) {
+        const int buf = NBUF == 2 ? (it & 1) : 0;
+        if (it + 1 < n_iter) g_load(it0 + it + 1);
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, 2 * step + fh)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz(r, 2 * step + fh)]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    // smallest partial products first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the consumers of the prefetched registers behind the MFMAs (see igemm.h)
+        if constexpr (NBUF == 2) {
+            if (it + 1 < n_iter) s_store(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                 // every wave has read tile `it`
+            if (it + 1 < n_iter) s_store(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU(0.1); D layout: col n = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rbase = 4 * fh;
+    if (p.k_split > 1) {   // raw partial sums; splitk_reduce*_kernel applies bias / activation / split
+        float* dst = p.partial + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + j * 32 + col;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m < p.M && n < p.N) dst[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+    if constexpr (OUT32) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + j * 32 + col;
+            const float bv = n < p.N ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m < p.M && n < p.N) {
+                        const float v = acc[i][j][r] + bv;
+                        p.out32[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                    }
+                }
+        }
+    } else {
+        // the K loop's last barrier has passed: the staging LDS is free; 6 KB per wave
+        igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
+                               n0 + wn * WN, lane);
+    }
+}
+
+// S3 variant of splitk_reduce_kernel: out planes <- split3(LeakyReLU(bias + sum_z partial[z]))
+__global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const float* __restrict__ partial, int k_split, int M, int N,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ out16,
+                                                               size_t o_plane) {
+    const size_t total = (size_t)M * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = partial[i];
+    for (int z = 1; z < k_split; z++) s += partial[z * total + i];
+    float v = s + bias[i % N];
+    v = v > 0.0f ? v : v * 0.1f;
+    uint16_t a, b, c;
+    split3(v, a, b, c);
+    out16[i] = a; out16[o_plane + i] = b; out16[2 * o_plane + i] = c;
+}
+
+// layout / format conversion helpers (operator-level entry points and debug read-back)
+__global__ void nchw_f32_to_nhwc_s3_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t o_plane,
+                                           int batch, int c, int hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int ch = (int)(idx % c);
+    const long t = idx / c;
+    const int px = (int)(t % hw), b = (int)(t / hw);
+    uint16_t x, y, z;
+    split3(in[((size_t)b * c + ch) * hw + px], x, y, z);
+    out[idx] = x; out[o_plane + idx] = y; out[2 * o_plane + idx] = z;
+}
+__global__ void nhwc_s3_to_nchw_f32_kernel(const uint16_t* __restrict__ in, size_t i_plane, float* __restrict__ out,
+                                           int batch, int c, int hw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int px = (int)(idx % hw);
+    const long t = idx / hw;
+    const int ch = (int)(t % c), b = (int)(t / c);
+    const size_t src = ((size_t)b * hw + px) * c + ch;
+    out[idx] = (bf16_to_f32(in[src]) + bf16_to_f32(in[i_plane + src])) + bf16_to_f32(in[2 * i_plane + src]);
+}
+
+}  // namespace hnet

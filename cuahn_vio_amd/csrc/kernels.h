@@ -18,8 +18,19 @@ inline int conv_out_dim(int n, int ks, int stride) { return (n + 2 * ((ks - 1) /
 
 // conv + bias + LeakyReLU on NHWC fp32: in [B][H][W][Cin] -> out [B][Ho][Wo][Cout]
 //   ws / ws_floats: optional split-K workspace (nullptr = never split)
+//   out16 / o_plane: when set, the output is written as three bf16 planes (S3, igemm_s3.h) instead of fp32
 hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, const float* wpacked,
-                       const float* bias, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0);
+                       const float* bias, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0,
+                       uint16_t* out16 = nullptr, size_t o_plane = 0);
+
+// split-bf16 (S3) convolution of the layers with Cin >= 8: in / out16 are [3][B][H][W][C] bf16 planes
+// (plane stride in elements), wplanes [3][Cout][Kp]; out32 != nullptr selects an fp32 [B][Ho][Wo][Cout] output
+bool conv_is_s3_layer(int layer);
+hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
+                          size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
+                          float* ws = nullptr, size_t ws_floats = 0);
+hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s);
+hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s);
 
 // first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,

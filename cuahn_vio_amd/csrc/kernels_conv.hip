@@ -2,6 +2,7 @@
 // convolution layers of HomographyNet (reference model_to_trace.py:88-113, :210-216) and the heads' first FC.
 #include "igemm.h"
 #include "conv_first.h"
+#include "igemm_s3.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -77,11 +78,13 @@ static hipError_t run_conv(const IgemmParams& p, hipStream_t s, float* ws, size_
 }
 
 hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, const float* wpacked,
-                       const float* bias, float* out, hipStream_t s, float* ws, size_t wsn) {
+                       const float* bias, float* out, hipStream_t s, float* ws, size_t wsn, uint16_t* out16, size_t o_plane) {
     if (layer < 0 || layer >= 20) return hipErrorInvalidValue;
     const ConvDesc& d = kConvs[layer];
     IgemmParams p = {};
     p.A = in; p.Wp = wpacked; p.bias = bias; p.out = out;
+    p.out16 = out16; p.o_plane = o_plane;
+    if (out16) { ws = nullptr; wsn = 0; }   // the S3 epilogue is not combined with split-K (only block_1_1 / block_2_1 use it)
     p.H = h; p.W = w;
     p.Ho = conv_out_dim(h, d.ks, d.stride);
     p.Wo = conv_out_dim(w, d.ks, d.stride);
@@ -91,10 +94,10 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
     if (conv_is_first_direct(layer)) {   // wpacked = MFMA B-fragments [NFRAG][64] (pack_first_weights)
         if (d.cout == 8) {
             const int tx = (w + 63) / 64, ty = (h + 15) / 16;
-            hipLaunchKernelGGL(conv7_c2_s1_kernel<8>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, h, w, tx, ty);
+            hipLaunchKernelGGL(conv7_c2_s1_kernel<8>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, out16, o_plane, h, w, tx, ty);
         } else {
             const int tx = (w + 31) / 32, ty = (h + 15) / 16;
-            hipLaunchKernelGGL(conv7_c2_s1_kernel<16>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, h, w, tx, ty);
+            hipLaunchKernelGGL(conv7_c2_s1_kernel<16>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, in, wpacked, bias, out, out16, o_plane, h, w, tx, ty);
         }
         return hipGetLastError();
     }
@@ -112,6 +115,95 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
         case 15: return run_conv<16, 3, 2, 16, 32>(p, s, ws, wsn);
     }
     return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-bf16 (S3) path, igemm_s3.h
+// ---------------------------------------------------------------------------------------------
+template <class L, int BM, int BN, int WGM, bool OUT32>
+static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
+    static const int nbuf = std::getenv("HNET_S3_NBUF") ? std::atoi(std::getenv("HNET_S3_NBUF")) : 1;   // experiments
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
+    const long tiles = (long)grid.x * grid.y;
+    const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
+    int split = 1;
+    if (ws && tiles < 192 && n_iter >= 8) {
+        split = (int)std::min<long>(std::min<long>(n_iter / 3, (384 + tiles - 1) / tiles), 64);
+        const size_t per = (size_t)p.M * p.N;
+        if ((size_t)split * per > ws_floats) split = (int)(ws_floats / per);
+        if (split < 2) split = 1;
+    }
+    p.k_split = split;
+    p.partial = ws;
+    grid.z = split;
+    if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
+    if (split > 1) {
+        if (OUT32) {
+            const size_t total4 = (size_t)p.M * p.N / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out32);
+        } else {
+            const size_t total = (size_t)p.M * p.N;
+            hipLaunchKernelGGL(splitk_reduce_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out16, p.o_plane);
+        }
+    }
+    return hipGetLastError();
+}
+
+template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32>
+static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
+    typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
+    static const int tile = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;   // experiments
+    if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32>(p, s, ws, wsn);
+    else {
+        if (tile == 1) return run_s3<L, 128, 64, 2, OUT32>(p, s, ws, wsn);
+        if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
+        return run_s3<L, 64, 64, 2, OUT32>(p, s, ws, wsn);
+    }
+}
+
+bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
+
+hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
+                          size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
+                          float* ws, size_t wsn) {
+    if (layer < 0 || layer >= 20 || !conv_is_s3_layer(layer)) return hipErrorInvalidValue;
+    const ConvDesc& d = kConvs[layer];
+    S3Params p = {};
+    p.A = in; p.a_plane = in_plane; p.Wp = wplanes; p.w_plane = w_plane; p.bias = bias;
+    p.out16 = out16; p.o_plane = o_plane; p.out32 = out32;
+    p.H = h; p.W = w;
+    p.Ho = conv_out_dim(h, d.ks, d.stride);
+    p.Wo = conv_out_dim(w, d.ks, d.stride);
+    p.M = batch * p.Ho * p.Wo;
+    p.N = d.cout;
+    p.Kp = conv_padded_k(layer);
+    const bool o32 = out32 != nullptr;
+    switch (layer) {
+        case 1:  return run_conv_s3<128, 5, 2, 32, 128, false>(p, s, ws, wsn);
+        case 2: case 5: case 11: case 18:
+            return o32 ? run_conv_s3<128, 3, 2, 32, 256, true>(p, s, ws, wsn) : run_conv_s3<128, 3, 2, 32, 256, false>(p, s, ws, wsn);
+        case 4:  return run_conv_s3<64, 5, 2, 32, 128, false>(p, s, ws, wsn);
+        case 6: case 12: case 19:
+            return o32 ? run_conv_s3<256, 3, 2, 32, 256, true>(p, s, ws, wsn) : run_conv_s3<256, 3, 2, 32, 256, false>(p, s, ws, wsn);
+        case 8:  return run_conv_s3<16, 5, 2, 16, 32, false>(p, s, ws, wsn);
+        case 9: case 16: return run_conv_s3<32, 3, 2, 32, 64, false>(p, s, ws, wsn);
+        case 10: case 17: return run_conv_s3<64, 3, 2, 32, 128, false>(p, s, ws, wsn);
+        case 14: return run_conv_s3<8, 5, 2, 8, 16, false>(p, s, ws, wsn);
+        case 15: return run_conv_s3<16, 3, 2, 16, 32, false>(p, s, ws, wsn);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s) {
+    const long n = (long)batch * c * h * w;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_s3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, o_plane, batch, c, h * w);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s) {
+    const long n = (long)batch * c * h * w;
+    hipLaunchKernelGGL(nhwc_s3_to_nchw_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, i_plane, out, batch, c, h * w);
+    return hipGetLastError();
 }
 
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,

@@ -9,6 +9,7 @@ behaviour so the parity tests read like a port of the reference's call sites
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -27,8 +28,10 @@ class HnetEngine:
     """One hnet context (one GPU).  `weights` is an HNETW001 blob (bytes) or a path to one."""
 
     def __init__(self, weights, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1,
-                 emit_error_map=False, device_id=0, mc_shard=None, precision=_capi.PREC_FP32):
+                 emit_error_map=False, device_id=0, mc_shard=None, precision=None):
         L = lib()
+        if precision is None:   # HNET_PRECISION=2 runs everything on the split-bf16 (fp32-grade) MFMA path
+            precision = int(os.environ.get("HNET_PRECISION", str(_capi.PREC_FP32)))
         cfg = Config()
         L.hnet_default_config(C.byref(cfg))
         cfg.device_id = device_id

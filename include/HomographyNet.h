@@ -18,7 +18,7 @@
 //     photometric error map (HomographyNet.cpp:96-100).
 //   * what the reference freezes into the traced file is read from optional environment variables:
 //     HNET_BLOCKS_TO_RUN (1..3, default 3 = "3_blocks_using_prior"), HNET_MC_SAMPLES (default 16),
-//     HNET_DROPOUT_P (default 0.05), HNET_MC_SEED (default 0), HNET_DEVICE (default 0).
+//     HNET_DROPOUT_P (default 0.05), HNET_MC_SEED (default 0), HNET_DEVICE (default 0), HNET_PRECISION (hnet.h).
 //   * the IEKF "iterative" model of the reference is the same network traced a second time; here one context
 //     serves every iteration (`network_model_iterative_path` is accepted and ignored).
 //   * a failed load throws std::runtime_error instead of printing and crashing at the first forward
@@ -65,6 +65,7 @@ public:
         cfg.mc_samples = env_int("HNET_MC_SAMPLES", 16);
         cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", 0.05);
         cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);
+        cfg.precision = env_int("HNET_PRECISION", cfg.precision);      // HNET_PREC_FP32 (0) or HNET_PREC_BF16X3 (2)
         cfg.emit_error_map = show_phtometric_error ? 1 : 0;
         cfg.max_batch = 1;
         std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());

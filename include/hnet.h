@@ -38,7 +38,12 @@ enum {
     HNET_ERR_UNSUPPORTED = 6
 };
 
-enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1 };   /* operand precision of conv / FC contractions */
+/* arithmetic of the conv contractions:
+ *   HNET_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic
+ *   HNET_PREC_BF16X3 fp32-grade accuracy on the bf16 matrix cores: every value is carried as three bf16 planes
+ *                    (an exact split of its 24-bit significand) and each product is six bf16 MFMAs (csrc/igemm_s3.h)
+ *   HNET_PREC_BF16   plain bf16 operands (not implemented: ~2e-2 px, outside the parity tolerance) */
+enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1, HNET_PREC_BF16X3 = 2 };
 enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buffers */
 
 /* Replaces: the variant choice the reference bakes into the traced .pt file
