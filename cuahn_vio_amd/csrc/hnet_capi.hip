@@ -78,6 +78,11 @@ struct hnet_ctx {
     bool s3 = false;
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
+    bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
+    uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
+    uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
+    uint16_t* feat16 = nullptr;        // [3][max_batch][5120] bf16: feat * 1/(1-p), split
+    uint8_t* head_mask = nullptr;      // [max_batch][n_local][2][640] keep bits
     size_t act_count[20] = {};         // elements per pair of layer l's output
     float* x_in[4] = {};
     float* act[20] = {};
@@ -190,9 +195,18 @@ void build_stages(hnet_ctx* c) {
         c->stages.push_back({"prep_b" + std::to_string(blk + 1), 0});
         int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
         for (int l = first[blk]; l <= last[blk]; l++) {
-            c->stages.push_back({kConvs[l].name, conv_flops(l, h, w)});
+            double fl = conv_flops(l, h, w);
+            std::string nm = kConvs[l].name;
             h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
             w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
+            if (c->fuse_b4 && l == 13) {       // one launch for block_4_0 + block_4_1
+                fl += conv_flops(14, h, w);
+                nm = "block_4_0+4_1";
+                h = conv_out_dim(h, kConvs[14].ks, kConvs[14].stride);
+                w = conv_out_dim(w, kConvs[14].ks, kConvs[14].stride);
+                l = 14;
+            }
+            c->stages.push_back({nm, fl});
         }
         if (blk < 3) c->stages.push_back({"fc_dlt_b" + std::to_string(blk + 1), 2.0 * 8 * 5120});
     }
@@ -251,6 +265,15 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         size_t in_plane = 0;
         const size_t MB = (size_t)g.max_batch;
         for (int l = first[blk]; l <= last[blk]; l++) {
+            if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
+                const size_t cnt1 = c->act_count[14];
+                uint16_t* o16 = c->act16[14] + P0 * cnt1;
+                STAGE(launch_block4_fused(in, c->conv_w[13], c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s));
+                in = nullptr; in16 = o16; in_plane = MB * cnt1;
+                h = c->act_h[14]; w = c->act_w[14];
+                l = 14;
+                continue;
+            }
             const size_t cnt = c->act_count[l];
             float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
@@ -271,7 +294,11 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // block 4 heads (:272-282) and output assembly (:310-317)
     const float* feat = c->act[19] + P0 * 5120;
     float* hidden = c->hidden + P0 * c->n_local * 512;
-    STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn));
+    if (c->s3)
+        STAGE(launch_heads_fc1_s3(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1_16, c->b1, hidden,
+                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn));
+    else
+        STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn));
     if (a.partial) {
         STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2,
                                a.mean_s, a.logvar_s, s));
@@ -357,6 +384,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     hnet_ctx* c = new hnet_ctx();
     c->cfg = g;
     c->s3 = g.precision == HNET_PREC_BF16X3;
+    c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -396,6 +424,22 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         else {
             const std::vector<float> packed = pack_conv(w->data, d, conv_padded_k(l));
             CK(upload(&c->conv_w[l], packed));
+            if (c->s3 && l == 14) {                 // block_4_1 B-fragments for the fused kernel: tap t = 4*st + g, 8 channels
+                std::vector<uint16_t> fr((size_t)7 * 3 * 64 * 8, 0);
+                for (int st = 0; st < 7; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int n = ln & 15, t = 4 * st + (ln >> 4);
+                        if (t >= 25) continue;
+                        const int kh = t / 5, kw = t % 5;
+                        for (int ci = 0; ci < 8; ci++) {
+                            uint16_t sp[3];
+                            split3(w->data[(((size_t)n * 8 + ci) * 5 + kh) * 5 + kw], sp[0], sp[1], sp[2]);
+                            for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + ci] = sp[pl];
+                        }
+                    }
+                CK(hipMalloc((void**)&c->b41_frag, fr.size() * 2));
+                CK(hipMemcpy(c->b41_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            }
             if (c->s3 && conv_is_s3_layer(l)) {     // exact 3-way bf16 split of every weight: planes [3][Cout][Kp]
                 std::vector<uint16_t> pl(packed.size() * 3);
                 for (size_t i = 0; i < packed.size(); i++)
@@ -431,6 +475,12 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             b2.insert(b2.end(), tb2->data, tb2->data + 8);
         }
         CK(upload(&c->w1, w1)); CK(upload(&c->b1, b1)); CK(upload(&c->w2, w2)); CK(upload(&c->b2, b2));
+        if (c->s3) {
+            std::vector<uint16_t> pl(w1.size() * 3);
+            for (size_t i = 0; i < w1.size(); i++) split3(w1[i], pl[i], pl[w1.size() + i], pl[2 * w1.size() + i]);
+            CK(hipMalloc((void**)&c->w1_16, pl.size() * 2));
+            CK(hipMemcpy(c->w1_16, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+        }
     }
 
     // ---- persistent activation buffers (NHWC fp32), one per layer so every intermediate can be read back
@@ -451,6 +501,10 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->ws_floats = (size_t)16 << 20;
     CK(dalloc(&c->ws, c->ws_floats));
     CK(dalloc(&c->hidden, MB * c->n_local * 512));
+    if (c->s3) {
+        CK(hipMalloc((void**)&c->feat16, 3 * MB * 5120 * 2));
+        CK(hipMalloc((void**)&c->head_mask, MB * c->n_local * 2 * 640));
+    }
     CK(dalloc(&c->Hm, MB * 9));
     CK(dalloc(&c->Htot, MB * 9));
     CK(dalloc(&c->mean_s, MB * c->n_local * 8));
@@ -536,6 +590,7 @@ void hnet_destroy(hnet_ctx* c) {
     for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
+    fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -830,7 +885,15 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     if (cap < n) return fail(c, HNET_ERR_INVALID_ARG, "buffer too small");
     float* d_t = nullptr;
     HIPCHK(c, dalloc(&d_t, n));
-    if (c->act16[layer])
+    if (c->fuse_b4 && layer == 13) {   // the fused kernel keeps block_4_0's output in LDS: recompute it unfused for inspection
+        uint16_t* tmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&tmp, 3 * n * 2));
+        HIPCHK(c, launch_conv(13, c->x_in[3] + (size_t)pair * NPIX * 2, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
+                              nullptr, 0, tmp, n));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(tmp);
+    } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
                                              c->act_h[layer], c->act_w[layer], c->stream));
     else

@@ -181,11 +181,7 @@ struct HeadLoader {
 // planes, stage the wave's 32x32 tile per plane in wave-private LDS and write 16 bytes per lane (64-byte rows).
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t ig_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint16_t ig_bf16_rn(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+__device__ __forceinline__ uint16_t ig_bf16_rn(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }   // v_cvt_pk_bf16_f32 (RNE)
 template <int TM, int TN>
 __device__ __forceinline__ void igemm_store_s3(f32x16 (&acc)[TM][TN], uint16_t* st, const float* bias, uint16_t* out16,
                                                size_t o_plane, int M, int N, int mw, int nw, int lane) {

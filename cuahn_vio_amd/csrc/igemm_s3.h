@@ -41,6 +41,9 @@ struct S3Params {
     int H, W, Ho, Wo;
     int k_split;           // gridDim.z slices of the K loop (small-M launches), raw fp32 partials -> partial[z][M][N]
     float* partial;
+    // heads only (HeadLoaderS3): keep-mask bits [B][n_local][2 heads][640 bytes], bit i of byte j = element 8j+i (NHWC k)
+    const uint8_t* mask;
+    int n_local;
 };
 
 template <int CIN_, int KS_, int STRIDE_, int SEG_>
@@ -55,8 +58,10 @@ struct ConvLoaderS3 {
     static_assert(RL % SEG == 0, "no padded segments for Cin >= 8 layers");
 
     struct Row { int pix0, iy0, ix0; bool valid; };
+    static constexpr bool HAS_MASK = false;
+    __device__ static inline uint32_t mask_byte(const S3Params&, const Row&, int) { return 0xFFu; }
 
-    __device__ static inline Row make_row(const S3Params& p, int m) {
+    __device__ static inline Row make_row(const S3Params& p, int m, int /*n0*/) {
         Row r;
         r.valid = m < p.M;
         const int mm = r.valid ? m : 0;
@@ -80,6 +85,30 @@ struct ConvLoaderS3 {
         ok = r.valid && sg < TOTAL_SEGS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         return ok ? ((size_t)(r.pix0 + kh * p.W + kw)) * CIN + ci : 0;
     }
+};
+
+// MC-dropout input of the heads in S3 form: A[(b, s)][k] = keep(s, k) ? featS3[b][k] : 0, where featS3 are the three
+// bf16 planes of feat * 1/(1-p) (heads_prep_kernel) and the keep bits come from a precomputed bit array (one byte per
+// 8-element chunk) so that the staging path does no hashing (reference: Dropout -> Linear(5120,256),
+// model_to_trace.py:222-225,229-232).
+struct HeadLoaderS3 {
+    static constexpr int KP = 5120;
+    static constexpr bool HAS_MASK = true;
+    struct Row { int b; size_t mrow; bool valid; };
+    __device__ static inline Row make_row(const S3Params& p, int m, int n0) {
+        Row r;
+        r.valid = m < p.M;
+        const int mm = r.valid ? m : 0;
+        r.b = mm / p.n_local;
+        const int head = n0 >> 8;
+        r.mrow = ((size_t)mm * 2 + head) * 640;
+        return r;
+    }
+    __device__ static inline size_t offset(const S3Params&, const Row& r, int kp, bool& ok) {
+        ok = r.valid;
+        return (size_t)r.b * 5120 + kp;
+    }
+    __device__ static inline uint32_t mask_byte(const S3Params& p, const Row& r, int kp) { return p.mask[r.mrow + (kp >> 3)]; }
 };
 
 __device__ __forceinline__ int s3_swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }   // bf16 elements
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 
     typename L::Row rows[A_ROWS];
 #pragma unroll
-    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, (srow + i * 64) < BM ? m0 + srow + i * 64 : p.M);
+    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, (srow + i * 64) < BM ? m0 + srow + i * 64 : p.M, n0);
     const uint16_t* wsrc[B_ROWS];
     bool wvalid[B_ROWS];
 #pragma unroll
@@ -132,6 +161,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 
     u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
     bool aok[A_ROWS], bok[B_ROWS];
+    uint32_t amask[A_ROWS];
     const int n_iter_total = (p.Kp + BK - 1) / BK;
     const int it0 = (int)(((long)blockIdx.z * n_iter_total) / p.k_split);
     const int n_iter = (int)(((long)(blockIdx.z + 1) * n_iter_total) / p.k_split) - it0;
@@ -143,6 +173,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
             const size_t off = L::offset(p, rows[i], kp, aok[i]);
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) areg[i][pl] = *reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane + off);
+            if constexpr (L::HAS_MASK) amask[i] = L::mask_byte(p, rows[i], kp < p.Kp ? kp : 0);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++) {
@@ -158,9 +189,20 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         for (int i = 0; i < A_ROWS; i++) {
             const int r = srow + i * 64;
             if (r < BM) {
+                u32x4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if constexpr (L::HAS_MASK) {   // byte -> 8 x 16-bit lane masks
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, schunk)]) = aok[i] ? areg[i][pl] : z;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t x = (amask[i] >> (2 * j)) & 3u;
+                        mk[j] = (x & 1u) * 0xFFFFu | (x >> 1) * 0xFFFF0000u;
+                    }
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    u32x4 v = aok[i] ? areg[i][pl] : z;
+                    if constexpr (L::HAS_MASK) { v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3]; }
+                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, schunk)]) = v;
+                }
             }
         }
 #pragma unroll
@@ -260,6 +302,35 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         // the K loop's last barrier has passed: the staging LDS is free; 6 KB per wave
         igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
                                n0 + wn * WN, lane);
+    }
+}
+
+// heads preparation: (a) featS3 = split3(feat * scale) as three planes [3][B][5120]; (b) the keep bits of both heads'
+// first dropout for every local sample, one byte per 8 consecutive NHWC elements.  The hash is evaluated on the
+// reference's NCHW flatten index c*20 + pix (include/hnet_rng.h); stream 0 = mean head, 2 = uncertainty head.
+__global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
+                                                         uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
+                                                         uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask) {
+    const size_t nfeat = (size_t)batch * 5120;
+    const size_t nmask = (size_t)batch * n_local * 2 * 640;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nfeat) {
+        uint16_t a, b, c;
+        split3(feat[i] * scale, a, b, c);
+        feat16[i] = a; feat16[f_plane + i] = b; feat16[2 * f_plane + i] = c;
+    }
+    if (i < nmask) {
+        const int chunk = (int)(i % 640);
+        size_t t = i / 640;
+        const int head = (int)(t & 1); t >>= 1;
+        const int s = (int)(t % n_local);
+        const int b = (int)(t / n_local);
+        const uint32_t pre = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)(s_begin + s));
+        const int k0 = chunk * 8, pix = k0 >> 8, c0 = k0 & 255;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) bits |= hnet_mask_keep(pre, (uint32_t)((c0 + e) * 20 + pix), thr) ? (1u << e) : 0u;
+        mask[i] = (uint8_t)bits;
     }
 }
 

@@ -3,6 +3,7 @@
 #include "igemm.h"
 #include "conv_first.h"
 #include "igemm_s3.h"
+#include "conv_b4_fused.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -158,11 +159,49 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
     else {
         if (tile == 1) return run_s3<L, 128, 64, 2, OUT32>(p, s, ws, wsn);
         if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
+        // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
+        const bool big_m = p.M >= 4096;
+        if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32>(p, s, ws, wsn); }
+        if constexpr (CIN == 128 && KS == 5) { if (big_m) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32>(p, s, ws, wsn);
     }
 }
 
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
+
+// block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
+hipError_t launch_block4_fused(const float* x_in, const float* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4f::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int n_tiles = batch * (112 / b4f::TH1) * (160 / b4f::TW1);
+    const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent: 2 workgroups per CU (77 KB of LDS each)
+    hipLaunchKernelGGL(block4_fused_kernel, dim3(blocks), dim3(256), b4f::LDS_BYTES, s, x_in, w0frag, bias0,
+                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles);
+    return hipGetLastError();
+}
+
+// first FC of both heads on the split-bf16 path.  feat fp32 [B][5120]; w1planes [3][512][5120] bf16;
+// scratch: feat16 [3][B][5120] bf16 and mask [B][n_local][2][640] bytes (context-owned)
+hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
+                               uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
+                               uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn) {
+    const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
+    hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
+                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, feat16, f_plane, mask);
+    S3Params p = {};
+    p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
+    p.out32 = hidden;
+    p.M = batch * n_local; p.N = 512; p.Kp = 5120;
+    p.mask = mask; p.n_local = n_local;
+    static const int tile = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
+    if (tile == 1) return run_s3<HeadLoaderS3, 128, 64, 2, true>(p, s, ws, wsn);
+    return run_s3<HeadLoaderS3, 64, 64, 2, true>(p, s, ws, wsn);
+}
 
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,

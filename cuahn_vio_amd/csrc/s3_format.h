@@ -7,10 +7,14 @@
 namespace hnet {
 
 __host__ __device__ inline uint16_t f32_to_bf16_rn(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);      // v_cvt_pk_bf16_f32: round to nearest even
+#else
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);     // round to nearest even (finite inputs)
+    u += 0x7FFFu + ((u >> 16) & 1u);     // round to nearest even (finite inputs), same result as the device instruction
     return (uint16_t)(u >> 16);
+#endif
 }
 __host__ __device__ inline float bf16_to_f32(uint16_t h) {
     uint32_t u = (uint32_t)h << 16;

@@ -274,7 +274,7 @@ def test_device_resident_entry_point_and_timing(blob):
     assert (per > 0).all() and tot >= per.sum() * 0.5
     ms = eng.profile_batch_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, None, 4, 0, mean.data_ptr(), cov.data_ptr(), 2)
     names = [n for n, _ in eng.stages()]
-    assert len(ms) == len(names) == 30 and (ms > 0).all()
+    assert len(ms) == len(names) and len(names) in (29, 30) and (ms > 0).all()   # 29: block_4_0 + block_4_1 fused (split-bf16 mode)
     assert abs(sum(f for _, f in eng.stages()) - 1.0882e9) < 2e6       # 1.0882 GFLOP per pair, N=16
     eng.close()
 
