@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--mc", type=int, default=32, help="MC-dropout samples N")
     ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
+                    help="fp32: exact fp32 MFMA; bf16x3: fp32-grade split-bf16 MFMA (both pass the same parity tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -111,7 +113,9 @@ def main():
     mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
     gathered = torch.zeros(world * B, 72, device=dev) if world > 1 else None
 
-    eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank)
+    prec = {"fp32": 0, "bf16x3": 2}[args.precision]
+    eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank,
+                     precision=prec)
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
 
@@ -146,10 +150,11 @@ def main():
         "metric": "homography preds/sec (frame pairs/s), full 4-block HomographyNet @ 320x224",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "f32 as 3 x bf16 planes (six bf16 MFMAs per product, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
                                f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
-                   "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant,
+                   "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision,
                    "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU",
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
@@ -173,7 +178,8 @@ def main():
                           "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                           "stage_ms": {n: round(float(m), 4) for (n, _), m in zip(stages, ms)}}
         if not args.no_latency:
-            e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank)
+            e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank,
+                            precision=prec)
             e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 20)
             per, _tot = e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 200)
             res["latency_batch1_ms"] = {"p50": round(float(np.percentile(per, 50)), 4), "p95": round(float(np.percentile(per, 95)), 4),

@@ -79,6 +79,7 @@ struct hnet_ctx {
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
+    uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
     uint16_t* feat16 = nullptr;        // [3][max_batch][5120] bf16: feat * 1/(1-p), split
@@ -268,7 +269,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
                 const size_t cnt1 = c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
-                STAGE(launch_block4_fused(in, c->conv_w[13], c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s));
+                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -420,6 +421,24 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const Tensor* w = b.find(pre + "weight", (size_t)d.cout * d.cin * d.ks * d.ks);
         const Tensor* bi = b.find(pre + "bias", d.cout);
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+        if (c->s3 && l == 13) {     // block_4_0 for the fused kernel: K index 8g+j of step st = (kh = 2st + (g>>1), kk = 8(g&1) + j)
+            std::vector<uint16_t> fr((size_t)4 * 3 * 64 * 8, 0);
+            for (int st = 0; st < 4; st++)
+                for (int ln = 0; ln < 64; ln++) {
+                    const int n = ln & 15, gg = ln >> 4, kh = 2 * st + (gg >> 1);
+                    if (kh >= 7) continue;
+                    const int dx = n >> 3, co = n & 7;
+                    for (int j = 0; j < 8; j++) {
+                        const int kk = 8 * (gg & 1) + j, kw = (kk >> 1) - dx, ci = kk & 1;
+                        if (kw < 0 || kw >= 7) continue;
+                        uint16_t sp[3];
+                        split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                        for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
+                    }
+                }
+            CK(hipMalloc((void**)&c->b40_frag, fr.size() * 2));
+            CK(hipMemcpy(c->b40_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        }
         if (conv_is_first_direct(l)) CK(upload(&c->conv_w[l], pack_first_weights(w->data, d.cout)));
         else {
             const std::vector<float> packed = pack_conv(w->data, d, conv_padded_k(l));
@@ -590,7 +609,7 @@ void hnet_destroy(hnet_ctx* c) {
     for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
-    fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);

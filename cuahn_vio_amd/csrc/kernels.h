@@ -29,7 +29,7 @@ bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
                           float* ws = nullptr, size_t ws_floats = 0);
-hipError_t launch_block4_fused(const float* x_in, const float* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s);
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,

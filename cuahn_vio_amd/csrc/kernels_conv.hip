@@ -170,7 +170,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
 
 // block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
-hipError_t launch_block4_fused(const float* x_in, const float* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -179,9 +179,9 @@ hipError_t launch_block4_fused(const float* x_in, const float* w0frag, const flo
         attr_set = true;
     }
     const int n_tiles = batch * (112 / b4f::TH1) * (160 / b4f::TW1);
-    const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent: 2 workgroups per CU (77 KB of LDS each)
-    hipLaunchKernelGGL(block4_fused_kernel, dim3(blocks), dim3(256), b4f::LDS_BYTES, s, x_in, w0frag, bias0,
-                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles);
+    const unsigned blocks = (unsigned)std::min(n_tiles, 256);      // persistent: one 512-thread workgroup per CU (85 KB of LDS)
+    hipLaunchKernelGGL(block4_fused_kernel, dim3(blocks), dim3(b4f::THREADS), b4f::LDS_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
+                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, /*ablate=*/0);
     return hipGetLastError();
 }
 
