@@ -1,0 +1,181 @@
+// conv_patch_s2.h — stride-2 KSxKS convolution, 16 -> 32 channels, straight from an LDS-resident input patch
+// (block_3_1: 5x5 and block_4_2: 3x3, both 112x160x16 -> 56x80x32; reference model_to_trace.py:108,212 via conv() :7-15).
+//
+// These two layers have a large image and few channels: in the implicit-GEMM kernel every input value is staged
+// 6.25 (5x5) / 2.25 (3x3) times and the kernel is bound by that gather traffic (0.33 / 0.19 ms per 256 pairs).
+// Here a workgroup owns an 8 x 16 tile of output pixels, copies the (2*8+KS-2) x (2*16+KS-2) input region ONCE into
+// LDS (three bf16 planes, 16-byte chunks of 8 channels laid out [plane][row][column parity][channel half][column/2]
+// so that consecutive output columns read consecutive chunks) and feeds v_mfma_f32_16x16x32_bf16 directly from it:
+// MFMA step st covers taps 2st, 2st+1; lane group g reads the chunk (tap 2st + (g>>1), channel half g&1).
+// Split-bf16 x3 arithmetic as igemm_s3.h (six MFMAs per step).  Each wave owns one 16-channel half of the outputs
+// and keeps its weight fragments in VGPRs for the lifetime of the workgroup.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_s3.h"
+
+namespace hnet {
+
+template <int KS> struct PatchS2Cfg {
+    static constexpr int CIN = 16, COUT = 32, PAD = (KS - 1) / 2;
+    static constexpr int TH = 8, TW = 16;                       // output tile
+    static constexpr int RH = 2 * TH + KS - 2, RW = 2 * TW + KS - 2;
+    static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, half)
+    static constexpr int PLANE = RH * 2 * 2 * XH * 8;           // bf16 elements per plane
+    static constexpr int NSTEP = (KS * KS + 1) / 2;             // two taps per 32-deep MFMA step
+    static constexpr int STAGE = 4 * 3 * 16 * 16;               // epilogue staging, elements
+    static constexpr int LDS_BYTES = (3 * PLANE + STAGE) * 2;
+};
+
+typedef float f32x4_p __attribute__((ext_vector_type(4)));
+
+// in: S3 planes [3][B][H][W][16];  wfrag: [2 halves of cout][NSTEP][3][64 lanes] x 16 B;  out16: [3][B][H/2][W/2][32]
+template <int KS>
+__global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
+                                                            const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                            uint16_t* __restrict__ out16, size_t o_plane, int H, int W,
+                                                            int n_tiles) {
+    typedef PatchS2Cfg<KS> C;
+    constexpr int TH = C::TH, TW = C::TW, RH = C::RH, RW = C::RW, XH = C::XH, PLANE = C::PLANE, NSTEP = C::NSTEP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint16_t* img = reinterpret_cast<uint16_t*>(lds_raw);
+    uint16_t* stage = img + 3 * PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int nt = wave & 1;                                    // this wave's half of the output channels
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;              // = floor((H + 2*PAD - KS) / 2) + 1 for KS = 3, 5
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+
+    u32x4 wv[NSTEP][3];
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) wv[st][pl] = wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane];
+    const float bv = bias[nt * 16 + m];
+    int tapoff[NSTEP];
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+        const int t = min(2 * st + (g >> 1), KS * KS - 1);      // the padding tap of the last step has zero weights
+        const int kh = t / KS, kw = t - kh * KS;
+        tapoff[st] = ((((kh * 2 + (kw & 1)) * 2) + (g & 1)) * XH + (kw >> 1)) * 8;
+    }
+    uint16_t* st_lds = stage + wave * (3 * 16 * 16);
+    // staging items of one region row: (plane, column, channel half), 3*RW*2 of them, ITEMS per lane
+    constexpr int ROW_ITEMS = 3 * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
+    constexpr int RB = KS == 5 ? 1 : 5;                         // region rows loaded per batch (register budget)
+    int it_pc[ITEMS], it_loff[ITEMS];
+    size_t it_goff[ITEMS];
+    uint32_t it_valid = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {
+        const int item = lane + 64 * q;
+        const int it = item < ROW_ITEMS ? item : 0;
+        const int pl = it / (RW * 2), rem = it - pl * (RW * 2), pc = rem >> 1, hf = rem & 1;
+        it_pc[q] = pc;
+        it_goff[q] = pl * i_plane + hf * 8;
+        it_loff[q] = pl * PLANE + (((pc & 1) * 2 + hf) * XH + (pc >> 1)) * 8;
+        if (item < ROW_ITEMS) it_valid |= 1u << q;
+    }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int bid = tile;
+        const int bx = bid % tiles_x; bid /= tiles_x;
+        const int by = bid % tiles_y;
+        const int b = bid / tiles_y;
+        const int ty0 = by * TH, tx0 = bx * TW;
+        const int Ry0 = 2 * ty0 - C::PAD, Rx0 = 2 * tx0 - C::PAD;
+
+        // ---- stage the input region: 16-byte copies, zero outside the image.  A wave takes whole region rows
+        // (row index wave-uniform); its lanes walk the 3 planes x RW columns x 2 channel halves of the row with
+        // per-lane offsets that were decomposed once, outside the tile loop.
+        __syncthreads();
+        const uint16_t* inb = in + (size_t)b * H * W * 16;
+        // loads are issued RB rows at a time into registers and consumed (zero select + ds_write) afterwards, so that
+        // RB*ITEMS 16-byte loads per lane are in flight instead of one (a select next to its load serialises them)
+        constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
+#pragma unroll
+        for (int r0 = 0; r0 < ROWS_PER_WAVE; r0 += RB) {
+            u32x4 buf[RB][ITEMS];
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++) {
+                const int pr = wave + 4 * (r0 + rr);
+                const int iy = Ry0 + pr;
+                const bool row_ok = pr < RH && iy >= 0 && iy < H;
+                const size_t grow = (size_t)(row_ok ? iy : 0) * W * 16;
+#pragma unroll
+                for (int q = 0; q < ITEMS; q++) {
+                    const int ix = Rx0 + it_pc[q];
+                    const bool ok = row_ok && ix >= 0 && ix < W;
+                    buf[rr][q] = *reinterpret_cast<const u32x4*>(inb + it_goff[q] + (ok ? grow + (size_t)ix * 16 : 0));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rr = 0; rr < RB; rr++) {
+                const int pr = wave + 4 * (r0 + rr);
+                const int iy = Ry0 + pr;
+                const bool row_ok = iy >= 0 && iy < H;
+                const int lrow = pr * 2 * 2 * XH * 8;
+#pragma unroll
+                for (int q = 0; q < ITEMS; q++) {
+                    const int ix = Rx0 + it_pc[q];
+                    const bool ok = row_ok && ix >= 0 && ix < W;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    if (pr < RH && (it_valid & (1u << q))) *reinterpret_cast<u32x4*>(&img[lrow + it_loff[q]]) = ok ? buf[rr][q] : z;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMAs: this wave's M-tiles are output rows (wave>>1), (wave>>1)+2, ... of the tile
+#pragma unroll 1
+        for (int j = 0; j < TH / 2; j++) {
+            const int oy = (wave >> 1) + 2 * j;
+            const int base = ((2 * oy) * 2 * 2 * XH + m) * 8;     // row 2*oy, parity 0, half 0, column m
+            f32x4_p acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const bf16x8*>(&img[pl * PLANE + base + tapoff[st]]);
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, wv[st][0]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, wv[st][1]);
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, wv[st][2]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b0, acc, 0, 0, 0);
+            }
+            // D: col n = lane&15 = cout within the half; row 4g + r = output column
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = acc[r] + bv;
+                v = v > 0.f ? v : v * 0.1f;
+                uint16_t sa, sb, sc;
+                split3(v, sa, sb, sc);
+                const int px = 4 * g + r;
+                st_lds[(0 * 16 + px) * 16 + m] = sa;
+                st_lds[(1 * 16 + px) * 16 + m] = sb;
+                st_lds[(2 * 16 + px) * 16 + m] = sc;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int Y = ty0 + oy;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int piece = q * 64 + lane;                 // 96 pieces of 16 B: [plane][16 px][2 x 8 channels]
+                if (piece < 96) {
+                    const int pl = piece >> 5, rem = piece & 31, px = rem >> 1, hh = rem & 1;
+                    const int X = tx0 + px;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st_lds[(pl * 16 + px) * 16 + hh * 8]);
+                    if (Y < Ho && X < Wo)
+                        *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * Ho + Y) * Wo + X) * 32 + nt * 16 + hh * 8) = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+    }
+}
+
+}  // namespace hnet

@@ -79,6 +79,8 @@ struct hnet_ctx {
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
+    uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
+    bool use_patch = false;
     uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
@@ -278,7 +280,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             const size_t cnt = c->act_count[l];
             float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
-            if (c->s3 && conv_is_s3_layer(l))
+            if (c->use_patch && conv_is_patch_layer(l))
+                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s));
+            else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
                                      c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn));
             else
@@ -386,6 +390,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->cfg = g;
     c->s3 = g.precision == HNET_PREC_BF16X3;
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
+    c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -438,6 +443,25 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                 }
             CK(hipMalloc((void**)&c->b40_frag, fr.size() * 2));
             CK(hipMemcpy(c->b40_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        }
+        if (c->s3 && conv_is_patch_layer(l)) {   // 16 -> 32, KSxKS: step st = taps 2st, 2st+1; lane group g -> tap 2st + (g>>1), ci 8(g&1)+j
+            const int ks = d.ks, nstep = (ks * ks + 1) / 2;
+            std::vector<uint16_t> fr((size_t)2 * nstep * 3 * 64 * 8, 0);
+            for (int nt = 0; nt < 2; nt++)
+                for (int st = 0; st < nstep; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int n = nt * 16 + (ln & 15), gg = ln >> 4, t = 2 * st + (gg >> 1);
+                        if (t >= ks * ks) continue;
+                        const int kh = t / ks, kw = t % ks;
+                        for (int j = 0; j < 8; j++) {
+                            const int ci = 8 * (gg & 1) + j;
+                            uint16_t sp[3];
+                            split3(w->data[(((size_t)n * 16 + ci) * ks + kh) * ks + kw], sp[0], sp[1], sp[2]);
+                            for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * nstep + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
+                        }
+                    }
+            CK(hipMalloc((void**)&c->patch_frag[l], fr.size() * 2));
+            CK(hipMemcpy(c->patch_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
         }
         if (conv_is_first_direct(l)) CK(upload(&c->conv_w[l], pack_first_weights(w->data, d.cout)));
         else {
@@ -606,7 +630,7 @@ void hnet_destroy(hnet_ctx* c) {
     (void)hipSetDevice(c->cfg.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    for (int l = 0; l < 20; l++) { fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
+    for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
     fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
@@ -861,7 +885,10 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         uint16_t *p_in = nullptr, *p_out = nullptr;
         HIPCHK(c, hipMalloc((void**)&p_in, 3 * n_in * 2 + 64));
         HIPCHK(c, hipMalloc((void**)&p_out, 3 * n_out * 2 + 64));
-        if (conv_is_s3_layer(layer)) {
+        if (c->use_patch && conv_is_patch_layer(layer)) {
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream));
+        } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
                                      c->conv_b[layer], p_out, n_out, nullptr, c->stream));

@@ -4,6 +4,7 @@
 #include "conv_first.h"
 #include "igemm_s3.h"
 #include "conv_b4_fused.h"
+#include "conv_patch_s2.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -185,6 +186,34 @@ hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const floa
     return hipGetLastError();
 }
 
+// block_3_1 (5x5) / block_4_2 (3x3): 16 -> 32 channels, stride 2, from an LDS-resident patch (conv_patch_s2.h)
+bool conv_is_patch_layer(int layer) { return layer == 8 || layer == 15; }   // block_3_1 (5x5), block_4_2 (3x3)
+
+template <int KS>
+static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfrag, const float* bias, uint16_t* out16,
+                            size_t o_plane, int batch, int h, int w, hipStream_t s) {
+    typedef PatchS2Cfg<KS> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
+    const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent, 2 workgroups per CU
+    hipLaunchKernelGGL(conv_patch_s2_kernel<KS>, dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
+                       out16, o_plane, h, w, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
+                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s) {
+    if (layer == 8) return run_patch<5>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
+    if (layer == 15) return run_patch<3>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
+    return hipErrorInvalidValue;
+}
+
 // first FC of both heads on the split-bf16 path.  feat fp32 [B][5120]; w1planes [3][512][5120] bf16;
 // scratch: feat16 [3][B][5120] bf16 and mask [B][n_local][2][640] bytes (context-owned)
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
@@ -198,8 +227,8 @@ hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_
     p.out32 = hidden;
     p.M = batch * n_local; p.N = 512; p.Kp = 5120;
     p.mask = mask; p.n_local = n_local;
-    static const int tile = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
-    if (tile == 1) return run_s3<HeadLoaderS3, 128, 64, 2, true>(p, s, ws, wsn);
+    // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
+    if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true>(p, s, ws, wsn);
     return run_s3<HeadLoaderS3, 64, 64, 2, true>(p, s, ws, wsn);
 }
 

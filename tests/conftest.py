@@ -5,6 +5,13 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own libamdhip64; when libhnet_hip.so (linked against /opt/rocm's) is loaded into the process first,
+# a later `import torch` finds "No HIP GPUs".  Tests that hand torch tensors to the C ABI therefore load torch first.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
