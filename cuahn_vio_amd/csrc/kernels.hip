@@ -61,7 +61,7 @@ __device__ inline float warp_sample(const PIX* img, const float* h, int u, int v
 
 // ---------------------------------------------------------------------------------------------
 // prep: block input = AvgPool_k(cat(img1, warp(img2, H)))   (model_to_trace.py:138-139,153-157,171-175,261-263)
-// K lanes cooperate on one output pixel: lane j sums row j of the k x k window, then a k-lane shuffle tree.
+// K/2 lanes cooperate on one output pixel: lane j sums rows 2j, 2j+1 of the k x k window, then a shuffle tree.
 // Output NHWC [B][224/k][320/k][2] — channel 0 = img1, channel 1 = (warped) img2.
 // ---------------------------------------------------------------------------------------------
 template <typename PIX, int K, bool WARP>
@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
     __shared__ float lut[256];
     if (PixRead<PIX>::kNeedLut) fill_lut(lut);
     constexpr int HO = IMG_H / K, WO = IMG_W / K;
-    const long total = (long)batch * HO * WO * K;
+    constexpr int RPL = K >= 2 ? 2 : 1;          // window rows per lane: 2K independent samples in flight per lane
+    constexpr int G = K / RPL;                   // lanes per output pixel
+    const long total = (long)batch * HO * WO * G;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = idx < total;
     const long ii = active ? idx : 0;
-    const int j = (int)(ii % K);
-    const long opix = ii / K;
+    const int j = (int)(ii % G);
+    const long opix = ii / G;
     const int b = (int)(opix / (HO * WO));
     const int rem = (int)(opix - (long)b * HO * WO);
     const int oy = rem / WO, ox = rem - oy * WO;
@@ -86,16 +88,19 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
 #pragma unroll
         for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
     }
-    const int v = oy * K + j;
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int a = 0; a < K; a++) {
-        const int u = ox * K + a;
-        s1 += PixRead<PIX>::get(i1, v * IMG_W + u, lut);
-        s2 += WARP ? warp_sample<PIX>(i2, h, u, v, lut) : PixRead<PIX>::get(i2, v * IMG_W + u, lut);
+    for (int rr = 0; rr < RPL; rr++) {
+        const int v = oy * K + j * RPL + rr;
+#pragma unroll
+        for (int a = 0; a < K; a++) {
+            const int u = ox * K + a;
+            s1 += PixRead<PIX>::get(i1, v * IMG_W + u, lut);
+            s2 += WARP ? warp_sample<PIX>(i2, h, u, v, lut) : PixRead<PIX>::get(i2, v * IMG_W + u, lut);
+        }
     }
 #pragma unroll
-    for (int m = 1; m < K; m <<= 1) {
+    for (int m = 1; m < G; m <<= 1) {
         s1 += __shfl_xor(s1, m);
         s2 += __shfl_xor(s2, m);
     }
@@ -106,9 +111,42 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
     }
 }
 
+// K = 1 (block 4: full resolution, no pooling): four consecutive pixels per thread so that sixteen independent
+// byte gathers are in flight per lane (one pixel per thread left the kernel waiting on memory 80 % of the time);
+// img1 is read as one 4-pixel vector, the output is two float4 stores.
+template <typename PIX>
+__global__ __launch_bounds__(256) void prep_k1_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
+                                                      const float* __restrict__ H, float* __restrict__ out, int batch) {
+    __shared__ float lut[256];
+    if (PixRead<PIX>::kNeedLut) fill_lut(lut);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // group of 4 pixels
+    if (idx >= (long)batch * (NPIX / 4)) return;
+    const int b = (int)(idx / (NPIX / 4));
+    const int pix0 = (int)(idx - (long)b * (NPIX / 4)) * 4;
+    const int v = pix0 / IMG_W, u0 = pix0 - v * IMG_W;                   // IMG_W % 4 == 0: the 4 pixels share a row
+    const PIX* i1 = img1 + (size_t)b * NPIX;
+    const PIX* i2 = img2 + (size_t)b * NPIX;
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+    float a[4], w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = warp_sample<PIX>(i2, h, u0 + i, v, lut);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = PixRead<PIX>::get(i1, pix0 + i, lut);
+    float4* o = reinterpret_cast<float4*>(out + ((size_t)b * NPIX + pix0) * 2);
+    o[0] = make_float4(a[0], w[0], a[1], w[1]);
+    o[1] = make_float4(a[2], w[2], a[3], w[3]);
+}
+
 template <typename PIX>
 static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s) {
-    const long total = (long)batch * NPIX / k;   // (224/k)*(320/k)*k
+    if (k == 1 && H) {
+        const long groups = (long)batch * (NPIX / 4);
+        hipLaunchKernelGGL(prep_k1_kernel<PIX>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, i1, i2, H, out, batch);
+        return hipGetLastError();
+    }
+    const long total = (long)batch * NPIX / k / (k >= 2 ? 2 : 1);   // (224/k)*(320/k) outputs x k/2 lanes each
     const int blocks = (int)((total + 255) / 256);
 #define HNET_PREP(KK)                                                                                     \
     if (H) hipLaunchKernelGGL((prep_kernel<PIX, KK, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, batch); \
