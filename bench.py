@@ -79,6 +79,29 @@ def cpu_baseline(blob, prev, curr, prior, variant, n_mc, budget_s):
             "ms_per_pair": round(1e3 * dt / n, 3)}
 
 
+def measured_traffic(kernel_substr, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    collected separately with tools/profile_round.sh at batch 256); None when no matching profile is committed."""
+    import csv
+    import glob
+    if batch != 256:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+    for r in rows:
+        if kernel_substr in r["kernel"]:
+            return (float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0
+    return None
+
+
+# stage name -> substring of the HIP kernel name in the rocprof tables
+KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "HeadLoaderS3, 128", "block_3_1": "conv_patch_s2_kernel<5>",
+                   "block_2_2": "ConvLoaderS3<64, 5, 2, 32>"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -170,7 +193,8 @@ def main():
         ms = [float(x) for x in ms]
         ach = fl / (ms[k] * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
+                           "traffic": measured_traffic(KERNEL_OF_STAGE.get(stages[k][0], "\0"), B) if args.precision == "bf16x3" else None,
                            "kernel": stages[k][0], "kernel_ms": round(float(ms[k]), 4),
                            "flops_per_launch": fl}
         res["forward"] = {"gflop_per_pair": round(total_flops / B / 1e9, 4),
