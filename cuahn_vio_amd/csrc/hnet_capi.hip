@@ -81,6 +81,7 @@ struct hnet_ctx {
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
+    uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
@@ -284,7 +285,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
-                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn));
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page));
             else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
@@ -541,6 +542,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             else CK(dalloc(&c->act[l], MB * c->act_count[l]));
         }
     }
+    CK(hipMalloc((void**)&c->zero_page, 256));
+    CK(hipMemset(c->zero_page, 0, 256));
     c->ws_floats = (size_t)16 << 20;
     CK(dalloc(&c->ws, c->ws_floats));
     CK(dalloc(&c->hidden, MB * c->n_local * 512));
@@ -633,7 +636,7 @@ void hnet_destroy(hnet_ctx* c) {
     for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
-    fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->zero_page); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);

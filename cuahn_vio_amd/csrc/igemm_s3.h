@@ -44,6 +44,7 @@ struct S3Params {
     // heads only (HeadLoaderS3): keep-mask bits [B][n_local][2 heads][640 bytes], bit i of byte j = element 8j+i (NHWC k)
     const uint8_t* mask;
     int n_local;
+    const uint16_t* zeros; // >= 16 bytes of zeros in global memory: source of padding / out-of-range chunks for the LDS-DMA kernel
 };
 
 template <int CIN_, int KS_, int STRIDE_, int SEG_>
@@ -300,6 +301,159 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         }
     } else {
         // the K loop's last barrier has passed: the staging LDS is free; 6 KB per wave
+        igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
+                               n0 + wn * WN, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: the operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+// no VGPR staging, no ds_write) into an NSTAGE-deep ring, two K-tiles in flight; one raw s_barrier per K-tile and
+// counted vmcnt waits (never __syncthreads(), which would drain the DMAs).  The DMA writes LDS linearly
+// (wave base + lane*16 B), which is exactly the [row][4 chunks] tile: lane l -> row l/4, physical chunk l%4; the XOR
+// swizzle is applied on the SOURCE side (the lane fetches logical chunk phys ^ ((row>>2)&3)).  Padding taps and rows
+// beyond M/N read a zero page instead.  Conv loaders only (the heads apply a per-element mask while staging).
+// ---------------------------------------------------------------------------------------------
+template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE>
+__global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
+    constexpr int BK = IG_BK;
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && !L::HAS_MASK, "DMA variant: 64-row multiples, no mask");
+    constexpr int A_INST = BM / 64, B_INST = BN / 64;        // wave-instructions per wave, plane and stage (16 rows each)
+    constexpr int PER_STAGE = 3 * (A_INST + B_INST);         // DMA instructions a wave issues per K-tile
+    constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
+    constexpr int STAGE = 3 * (TILE_A + TILE_B);             // bf16 elements per ring stage
+    constexpr int SMEM_ELEMS = NSTAGE * STAGE > 4 * 3 * 32 * 32 ? NSTAGE * STAGE : 4 * 3 * 32 * 32;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = lane >> 2, lphys = lane & 3;
+
+    typename L::Row rows[A_INST];
+    int akp[A_INST];                                         // K offset of the logical chunk this lane fetches
+#pragma unroll
+    for (int i = 0; i < A_INST; i++) {
+        const int r = (wave + 4 * i) * 16 + lrow;
+        rows[i] = L::make_row(p, m0 + r, n0);
+        akp[i] = (lphys ^ ((r >> 2) & 3)) * 8;
+    }
+    const uint16_t* wsrc[B_INST];
+    bool wvalid[B_INST];
+#pragma unroll
+    for (int i = 0; i < B_INST; i++) {
+        const int r = (wave + 4 * i) * 16 + lrow;
+        wvalid[i] = n0 + r < p.N;
+        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n0 + r : 0) * p.Kp + (lphys ^ ((r >> 2) & 3)) * 8;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int n_iter = (p.Kp + BK - 1) / BK;                 // no split-K in this variant
+
+    auto issue = [&](int it, int stage) {
+        uint16_t* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_INST; i++) {
+            bool ok;
+            const size_t off = L::offset(p, rows[i], it * BK + akp[i], ok);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const uint16_t* src = ok ? p.A + pl * p.a_plane + off : p.zeros;
+                uint16_t* dst = sbase + pl * TILE_A + (wave + 4 * i) * 16 * BK;      // wave-uniform; the DMA adds lane*16 B
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_INST; i++) {
+            const bool ok = wvalid[i] && (it * BK < p.Kp);   // Kp is a multiple of 8 and chunks never straddle it
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const uint16_t* src = ok ? wsrc[i] + it * BK + pl * p.w_plane : p.zeros;
+                uint16_t* dst = sbase + 3 * TILE_A + pl * TILE_B + (wave + 4 * i) * 16 * BK;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    const int frow = lane & 31, fh = lane >> 5;
+    auto compute = [&](int stage) {
+        const uint16_t* As = smem + stage * STAGE;
+        const uint16_t* Bs = As + 3 * TILE_A;
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz(r, 2 * step + fh)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz(r, 2 * step + fh)]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    issue(0, 0);
+    if (n_iter > 1) issue(1, 1);
+    for (int it = 0; it < n_iter; it++) {
+        // this wave's DMAs of K-tile `it` have landed (the next tile's may still be in flight) ...
+        if (it + 1 < n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's; tile it-1 is no longer read
+        asm volatile("" ::: "memory");
+        if (it + 2 < n_iter) issue(it + 2, (it + 2) % NSTAGE);
+        compute(it % NSTAGE);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // all fragment reads done before the epilogue reuses the LDS
+
+    const int col = lane & 31, rbase = 4 * fh;
+    if constexpr (OUT32) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + j * 32 + col;
+            const float bv = n < p.N ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m < p.M && n < p.N) {
+                        const float v = acc[i][j][r] + bv;
+                        p.out32[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
+                    }
+                }
+        }
+    } else {
         igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
                                n0 + wn * WN, lane);
     }

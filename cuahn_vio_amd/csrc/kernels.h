@@ -28,7 +28,7 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
 bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws = nullptr, size_t ws_floats = 0);
+                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s);
