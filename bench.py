@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="fp32: exact fp32 MFMA; bf16x3: fp32-grade split-bf16 MFMA (both pass the same parity tests)")
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "mc"],
+                    help="pairs (default, the headline metric): frame pairs sharded over the GPUs.  mc (BASELINE config 4): "
+                         "the SAME pairs on every rank, the N MC-dropout samples sharded over the ranks, one all-gather of the "
+                         "per-sample head outputs, two-pass ensemble on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -137,12 +141,29 @@ def main():
     gathered = torch.zeros(world * B, 72, device=dev) if world > 1 else None
 
     prec = {"fp32": 0, "bf16x3": 2}[args.precision]
+    mc_mode = args.mode == "mc"
+    shard = hdist.shard_range(n_mc, world, rank) if mc_mode else None
+    if mc_mode and n_mc % world:
+        raise SystemExit("--mode mc needs N divisible by the number of GPUs")
     eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank,
-                     precision=prec)
+                     precision=prec, mc_shard=shard)
     stream = torch.cuda.current_stream(dev)
     sp = stream.cuda_stream
+    if mc_mode:
+        n_loc = shard[1] - shard[0]
+        ms_loc, lv_loc = torch.zeros(B, n_loc, 8, device=dev), torch.zeros(B, n_loc, 8, device=dev)
+        h1 = torch.zeros(B, 9, device=dev)
 
     def step(i):
+        if mc_mode:   # trunk replicated, heads for this rank's samples, gather, finish in the reference's two-pass order
+            eng.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, i * B, ms_loc.data_ptr(),
+                                        lv_loc.data_ptr(), h1.data_ptr(), sp)
+            if world > 1:
+                ms_all, lv_all, _ = hdist.gather_mc_samples(ms_loc, lv_loc, h1)
+            else:
+                ms_all, lv_all = ms_loc, lv_loc
+            eng.mc_finish_device(ms_all.data_ptr(), lv_all.data_ptr(), n_mc, h1.data_ptr(), B, mean.data_ptr(), cov.data_ptr(), sp)
+            return
         eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, (rank * 1000003 + i) * B,
                                mean.data_ptr(), cov.data_ptr(), None, sp)
         if world > 1:
@@ -167,23 +188,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
-    value = world * B * args.steps / dt
+    value = (1 if mc_mode else world) * B * args.steps / dt     # mc mode: every rank works on the same B pairs
 
     res = {
         "metric": "homography preds/sec (frame pairs/s), full 4-block HomographyNet @ 320x224",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if mc_mode else "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 as 3 x bf16 planes (six bf16 MFMAs per product, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
                                f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
                    "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision,
-                   "parallelism": f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU",
+                   "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
+                                   if mc_mode else
+                                   (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU")),
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
     }
 
-    if rank == 0:
+    if rank == 0 and mc_mode:
+        print(json.dumps(res), flush=True)
+    if rank == 0 and not mc_mode:
         # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on
         stages = eng.stages()
         ms = eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(), cov.data_ptr(), 5)
