@@ -44,6 +44,7 @@ struct IgemmParams {
     uint32_t thr;         // drop threshold (24 bit)
     float scale;          // 1/(1-p)
     uint64_t mc_seed, pair_seq0;
+    const uint64_t* seq_dev;   // optional device-resident addend to pair_seq0 (lets a captured hipGraph be replayed with a new sequence number)
     // split-K (small-M launches): gridDim.z = k_split slices of the K loop, raw partial sums go to
     // partial[z][M][N]; splitk_reduce_kernel adds them in z order (deterministic) and applies bias + LeakyReLU
     int k_split;
@@ -155,7 +156,8 @@ struct HeadLoader {
         int s = p.s_begin + (mm - b * p.n_local);
         int head = n0 >> 8;     // columns 0..255 = mean head, 256..511 = uncertainty head
         r.feat = p.A + (size_t)b * 5120;
-        r.prefix = hnet_mask_prefix(hnet_pair_key(p.mc_seed, p.pair_seq0 + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)s);
+        const uint64_t seq = p.pair_seq0 + (p.seq_dev ? *p.seq_dev : 0ull) + (uint64_t)b;
+        r.prefix = hnet_mask_prefix(hnet_pair_key(p.mc_seed, seq), (uint32_t)(2 * head), (uint32_t)s);
         return r;
     }
     __device__ static inline void load(const IgemmParams& p, const Row& r, int kp, f32x4& raw, uint32_t& mask) {

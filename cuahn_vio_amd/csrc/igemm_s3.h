@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 // reference's NCHW flatten index c*20 + pix (include/hnet_rng.h); stream 0 = mean head, 2 = uncertainty head.
 __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
                                                          uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
+                                                         const uint64_t* __restrict__ seq_dev,
                                                          uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask) {
     const size_t nfeat = (size_t)batch * 5120;
     const size_t nmask = (size_t)batch * n_local * 2 * 640;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict
         const int head = (int)(t & 1); t >>= 1;
         const int s = (int)(t % n_local);
         const int b = (int)(t / n_local);
-        const uint32_t pre = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)(s_begin + s));
+        const uint32_t pre = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b), (uint32_t)(2 * head), (uint32_t)(s_begin + s));
         const int k0 = chunk * 8, pix = k0 >> 8, c0 = k0 & 255;
         uint32_t bits = 0;
 #pragma unroll

@@ -37,14 +37,14 @@ hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const floa
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
-                               float* ws = nullptr, size_t ws_floats = 0);
+                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr);
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s);
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s);
 
 // first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s,
-                            float* ws = nullptr, size_t ws_floats = 0);
+                            float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr);
 
 // cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
@@ -70,7 +70,7 @@ hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float*
 //   hidden [B*n_local][512]
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
-                            hipStream_t s);
+                            hipStream_t s, const uint64_t* seq_dev = nullptr);
 
 // ensemble/transfer from gathered per-sample outputs [B][n][8]
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,

@@ -307,7 +307,7 @@ constexpr int FC2_CHUNK = 4;
 
 __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
                                                         uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
-                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const uint64_t* __restrict__ seq_dev, const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ mean_s, float* __restrict__ logvar_s) {
     __shared__ float w2s[4096];                  // [2][8][256]
     __shared__ float hid[FC2_CHUNK * 512];       // after dropout
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
     const int nc = min(FC2_CHUNK, n_local - c0);
     const int tid = threadIdx.x;
     for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
-    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (uint64_t)b);
+    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
     for (int i = tid; i < FC2_CHUNK * 512; i += 256) {
         const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
         float v = 0.0f;
@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
 
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
-                            hipStream_t s) {
+                            hipStream_t s, const uint64_t* seq_dev) {
     if (n_local < 1 || !mean_s || !logvar_s) return hipErrorInvalidValue;
     const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
     hipLaunchKernelGGL(heads_fc2_kernel, dim3((unsigned)(batch * n_chunks)), dim3(256), 0, s, hidden, n_local, s_begin,
-                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, w2, b2, mean_s, logvar_s);
+                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, seq_dev, w2, b2, mean_s, logvar_s);
     return hipGetLastError();
 }
 

@@ -229,10 +229,11 @@ hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int 
 // scratch: feat16 [3][B][5120] bf16 and mask [B][n_local][2][640] bytes (context-owned)
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
-                               uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn) {
+                               uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
+                               const uint64_t* seq_dev) {
     const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
-                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, feat16, f_plane, mask);
+                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask);
     S3Params p = {};
     p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
     p.out32 = hidden;
@@ -288,7 +289,7 @@ hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float*
 
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s,
-                            float* ws, size_t wsn) {
+                            float* ws, size_t wsn, const uint64_t* seq_dev) {
     IgemmParams p = {};
     p.A = feat; p.Wp = w1packed; p.bias = b1; p.out = hidden;
     p.M = batch * n_local;
@@ -300,6 +301,7 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
     p.scale = 1.0f / (1.0f - p_drop);
     p.mc_seed = mc_seed;
     p.pair_seq0 = pair_seq0;
+    p.seq_dev = seq_dev;
     static const int force = std::getenv("HNET_TILE") ? std::atoi(std::getenv("HNET_TILE")) : -1;   // experiments
     if (force == 1) return run<HeadLoader, 128, 64, 2, 32>(p, s, ws, wsn);
     return run<HeadLoader, 64, 64, 2, 32>(p, s, ws, wsn);
