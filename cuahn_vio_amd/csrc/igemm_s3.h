@@ -55,6 +55,8 @@ struct ConvLoaderS3 {
     static constexpr int SPR = (RL + SEG - 1) / SEG;
     static constexpr int TOTAL_SEGS = KS * SPR;
     static constexpr int KP = TOTAL_SEGS * SEG;
+    static constexpr int SEGMENT = SEG;
+    static constexpr bool WIDE_TAPS = CIN >= 64;        // a 64-wide K tile stays inside one tap: 128 contiguous bytes per row and plane
     static_assert(IG_BK % SEG == 0 && SEG % 8 == 0 && CIN % 8 == 0, "16-byte chunks must stay inside one pixel");
     static_assert(RL % SEG == 0, "no padded segments for Cin >= 8 layers");
 
@@ -94,6 +96,8 @@ struct ConvLoaderS3 {
 // model_to_trace.py:222-225,229-232).
 struct HeadLoaderS3 {
     static constexpr int KP = 5120;
+    static constexpr int SEGMENT = 32;
+    static constexpr bool WIDE_TAPS = true;
     static constexpr bool HAS_MASK = true;
     struct Row { int b; size_t mrow; bool valid; };
     __device__ static inline Row make_row(const S3Params& p, int m, int n0) {
@@ -112,20 +116,28 @@ struct HeadLoaderS3 {
     __device__ static inline uint32_t mask_byte(const S3Params& p, const Row& r, int kp) { return p.mask[r.mrow + (kp >> 3)]; }
 };
 
-__device__ __forceinline__ int s3_swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }   // bf16 elements
+// chunk swizzle of an LDS tile row: 64-byte rows (4 chunks) pair four rows per 256-byte bank row, 128-byte rows (8 chunks) two
+template <int CH>
+__device__ __forceinline__ int s3_swz(int row, int chunk) {
+    return CH == 4 ? (chunk ^ ((row >> 2) & 3)) * 8 : (chunk ^ ((row >> 1) & 7)) * 8;   // bf16 elements
+}
 
 // OUT32 = true: fp32 [M][N] output (feeds an FC);  false: S3 planes
 // NBUF = 2: double-buffered LDS, one barrier per K-tile.  NBUF = 1: single LDS buffer, two barriers per K-tile but half
 // the LDS, i.e. twice the resident workgroups per CU: with 6 MFMAs x 32 cycles per k16-step a K-tile lasts ~400 cycles,
 // less than the latency of its own prefetch, so the latency has to be hidden by more workgroups instead.
-template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1>
+// BKT = K-tile (32 or 64 K-values).  With 64 every staged row is a full 128-byte line per plane: the texture addresser
+// (GRBM_TA_BUSY ~ 90 % on the 32-wide tiles, profiles/r01) handles half as many lines per byte.
+template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1, int BKT = 32>
 __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
-    constexpr int BK = IG_BK;                         // 32 K-values = 4 chunks of 8
+    constexpr int BK = BKT;                           // K-values per tile = CH chunks of 8
+    constexpr int CH = BK / 8, RPP = 256 / CH;        // chunks per row, rows staged per pass of the 256 threads
+    static_assert(BK % L::SEGMENT == 0, "K tile must be a whole number of loader segments");
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
-    constexpr int A_ROWS = (BM + 63) / 64, B_ROWS = (BN + 63) / 64;   // rows staged per thread and plane (256 threads = 64 rows x 4 chunks)
+    constexpr int A_ROWS = (BM + RPP - 1) / RPP, B_ROWS = (BN + RPP - 1) / RPP;   // rows staged per thread and plane
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
 
@@ -138,17 +150,17 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int srow = tid >> 2, schunk = tid & 3;      // staging: 64 rows x 4 chunks
+    const int srow = tid / CH, schunk = tid % CH;     // staging: RPP rows x CH chunks per pass
 
     typename L::Row rows[A_ROWS];
 #pragma unroll
-    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, (srow + i * 64) < BM ? m0 + srow + i * 64 : p.M, n0);
+    for (int i = 0; i < A_ROWS; i++) rows[i] = L::make_row(p, (srow + i * RPP) < BM ? m0 + srow + i * RPP : p.M, n0);
     const uint16_t* wsrc[B_ROWS];
     bool wvalid[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; i++) {
-        const int n = n0 + srow + i * 64;
-        wvalid[i] = n < p.N && (srow + i * 64) < BN;
+        const int n = n0 + srow + i * RPP;
+        wvalid[i] = n < p.N && (srow + i * RPP) < BN;
         wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n : 0) * p.Kp + schunk * 8;
     }
 
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < A_ROWS; i++) {
-            const int r = srow + i * 64;
+            const int r = srow + i * RPP;
             if (r < BM) {
                 u32x4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if constexpr (L::HAS_MASK) {   // byte -> 8 x 16-bit lane masks
@@ -202,17 +214,17 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                 for (int pl = 0; pl < 3; pl++) {
                     u32x4 v = aok[i] ? areg[i][pl] : z;
                     if constexpr (L::HAS_MASK) { v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3]; }
-                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, schunk)]) = v;
+                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, schunk)]) = v;
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++) {
-            const int r = srow + i * 64;
+            const int r = srow + i * RPP;
             if (r < BN) {
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    *reinterpret_cast<u32x4*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz(r, schunk)]) = bok[i] ? breg[i][pl] : z;
+                    *reinterpret_cast<u32x4*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, schunk)]) = bok[i] ? breg[i][pl] : z;
             }
         }
     };
@@ -226,21 +238,21 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         const int buf = NBUF == 2 ? (it & 1) : 0;
         if (it + 1 < n_iter) g_load(it0 + it + 1);
 #pragma unroll
-        for (int step = 0; step < 2; step++) {
+        for (int step = 0; step < BK / 16; step++) {
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 const int r = wm * WM + i * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz(r, 2 * step + fh)]);
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 const int r = wn * WN + j * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz(r, 2 * step + fh)]);
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -399,14 +411,14 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
                 const int r = wm * WM + i * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz(r, 2 * step + fh)]);
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 const int r = wn * WN + j * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz(r, 2 * step + fh)]);
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)

@@ -122,6 +122,21 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
 // ---------------------------------------------------------------------------------------------
 // split-bf16 (S3) path, igemm_s3.h
 // ---------------------------------------------------------------------------------------------
+template <bool OUT32>
+static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hipStream_t s) {
+    if (split > 1) {
+        if (OUT32) {
+            const size_t total4 = (size_t)p.M * p.N / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out32);
+        } else {
+            const size_t total = (size_t)p.M * p.N;
+            hipLaunchKernelGGL(splitk_reduce_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out16, p.o_plane);
+        }
+    }
+    return hipGetLastError();
+}
+#define finish_split(p, split, ws, s) finish_split_impl<OUT32>(p, split, ws, s)
+
 template <class L, int BM, int BN, int WGM, bool OUT32>
 static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
     static const int nbuf = std::getenv("HNET_S3_NBUF") ? std::atoi(std::getenv("HNET_S3_NBUF")) : 1;   // experiments
@@ -140,7 +155,7 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     grid.z = split;
     // LDS-DMA ring (3 stages) by default: 2-8 % faster than register staging on the 64x64 tiles (HNET_S3_DMA=0 disables)
     static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : 3;
-    if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64) {
+    if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
         if (dma && split == 1 && p.zeros) {
             if constexpr (BM * BN <= 128 * 64) {
                 if (dma == 4) { hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
@@ -148,6 +163,12 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
             hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3>), grid, dim3(256), 0, s, p);
             return hipGetLastError();
         }
+    }
+    // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
+    // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
+    static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
+    if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
+        if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
     }
     if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
