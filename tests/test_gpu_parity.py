@@ -291,10 +291,16 @@ def test_error_behaviour(blob):
         eng.infer_batch(prev[:2], curr[:2], None)          # prior missing
     with pytest.raises(HnetError):
         eng.infer_batch(prev[:1], curr[:1], prior[:1], want_err=True)   # no error map in this context
+    with pytest.raises(HnetError) as ei:
+        eng.infer_batch(prev[:0], curr[:0], prior[:0])     # empty batch
+    assert ei.value.status == 1
     eng.close()
     with pytest.raises(HnetError) as ei:
         HnetEngine(b"not a blob at all", variant="full")
     assert ei.value.status == 2
+    with pytest.raises(HnetError) as ei:
+        HnetEngine(blob, variant="full", precision=1)       # plain bf16 is not a supported arithmetic
+    assert ei.value.status == 6
 
 
 def test_properties_at_full_batch(blob):
