@@ -40,47 +40,66 @@ def parse():
                          "per-sample head outputs, two-pass ensemble on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
-def cpu_baseline(blob, prev, curr, prior, variant, n_mc, budget_s):
-    """the oracle's plain-fp32 build (kind "port") timed on this box's host cores on a bounded sample"""
-    from oracle import pyoracle
-    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
-    orc = pyoracle.Oracle(blob, f32=True)
-
-    def one(i):
-        j = i % prev.shape[0]
-        orc.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
-
-    # pick the OpenMP thread count that is fastest on this host (more threads than the small per-layer loops can
-    # feed only add fork/join cost: 256 threads ran 60x slower than 8 on the GPU box)
+def _calibrated_rate(one, set_threads, budget_s):
+    """pairs/s of `one(i)` after picking the thread count that is fastest on this host (more threads than the small
+    per-layer loops can feed only add fork/join cost: 256 threads ran 60x slower than 8 on the GPU box)"""
     avail = os.cpu_count() or 1
     best, cores = None, 1
     for th in [t for t in (4, 8, 16, 32, 64) if t <= avail] or [1]:
-        orc.lib.oracle_set_threads(th)
+        set_threads(th)
         one(0)
         t0 = time.perf_counter()
         one(1)
         dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, cores = dt, th
-    orc.lib.oracle_set_threads(cores)
+    set_threads(cores)
     one(0)
     t0 = time.perf_counter()
     for i in range(2):
         one(i)
     per = (time.perf_counter() - t0) / 2
-    n = int(max(4, min(400, budget_s / max(per, 1e-4))))
+    n = int(max(4, min(5000, budget_s / max(per, 1e-4))))
     t0 = time.perf_counter()
     for i in range(n):
         one(i)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frame pairs, {variant} model, N={n_mc}, one pair at a time (the reference is batch-1), "
-                      f"oracle/liboracle_f32.so with OpenMP on {cores} threads, {dt:.1f} s",
-            "ms_per_pair": round(1e3 * dt / n, 3)}
+    return n, dt, cores
+
+
+def cpu_baseline(blob, state, prev, curr, prior, variant, n_mc, budget_s):
+    """CPU baselines on this box's host cores, on a bounded sample, one pair at a time like the reference:
+    (i) `value`: the forward on libtorch's CPU operators (oracle/torch_cpu.py — our restatement of the computation the
+        reference's TorchScript file runs; the reference's own .pt/.py cannot travel to this box), kind "port";
+    (ii) `c_port`: the oracle's plain-fp32 C build with OpenMP (oracle/liboracle_f32.so)."""
+    import torch
+    from oracle import pyoracle, torch_cpu
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    net = torch_cpu.TorchCpuNet(state)
+
+    def one_t(i):
+        j = i % prev.shape[0]
+        net.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
+
+    n, dt, cores = _calibrated_rate(one_t, torch.set_num_threads, budget_s / 2)
+    res = {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{n} frame pairs, {variant} model, N={n_mc}, one pair at a time (the reference is batch-1), libtorch {torch.__version__} "
+                     f"CPU operators (oracle/torch_cpu.py) on {cores} threads of {os.cpu_count()} host CPUs, {dt:.1f} s",
+           "ms_per_pair": round(1e3 * dt / n, 3)}
+    orc = pyoracle.Oracle(blob, f32=True)
+
+    def one_c(i):
+        j = i % prev.shape[0]
+        orc.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
+
+    n, dt, cores = _calibrated_rate(one_c, orc.lib.oracle_set_threads, budget_s / 2)
+    res["c_port"] = {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores,
+                     "sample": f"{n} frame pairs, oracle/liboracle_f32.so with OpenMP on {cores} threads, {dt:.1f} s"}
+    return res
 
 
 def measured_traffic(kernel_substr, batch):
@@ -235,7 +254,7 @@ def main():
                                         "definition": "device time of one pair, inputs/outputs resident (the reference's 'pure network inference')"}
             e1.close()
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(blob, prev_h, curr_h, prior_h, args.variant, n_mc, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(blob, weights.synthetic_state(0), prev_h, curr_h, prior_h, args.variant, n_mc, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:

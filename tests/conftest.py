@@ -22,7 +22,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # 1.4e-4 px on these weights (torch.inverse inside DLT_solve + fp32 activations), so 1e-4 px against the fp32
 # golden is below the reference's own noise; the gates are:
 TOL_PX_VS_REF32 = 3e-4      # |offset - reference fp32 golden|, px
-TOL_PX_VS_REF64 = 2e-4      # |offset - reference fp64 golden|, px
+TOL_PX_VS_REF64 = 1e-4      # |offset - reference fp64 golden|, px  (north_star's 1e-4 px, against the reference evaluated in double)
 TOL_PX_VS_ORACLE = 2e-4     # |HIP - oracle (double accumulation)|, px
 TOL_COV_REL = 2e-5          # max |cov - ref| / max |ref|
 
