@@ -45,7 +45,27 @@ struct S3Params {
     const uint8_t* mask;
     int n_local;
     const uint16_t* zeros; // >= 16 bytes of zeros in global memory: source of padding / out-of-range chunks for the LDS-DMA kernel
+#ifdef HNET_S3_TRACE
+    unsigned long long* trace;   // tools/trace_s3.hip only: [block < 8][wave][S3T_SLOTS] s_memtime stamps
+#endif
 };
+
+// phase timestamps of the K loop for tools/trace_s3.hip (compiled out of the library)
+#ifdef HNET_S3_TRACE
+#define S3T_SLOTS 512
+#define S3T()                                                                                                             \
+    do {                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        if (blockIdx.y == 0 && blockIdx.x < 8 && tcount < S3T_SLOTS) {                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                   \
+            if (lane == 0) p.trace[(size_t)(blockIdx.x * 4 + wave) * S3T_SLOTS + tcount] = t_;                            \
+            tcount++;                                                                                                     \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    } while (0)
+#else
+#define S3T() do {} while (0)
+#endif
 
 template <int CIN_, int KS_, int STRIDE_, int SEG_>
 struct ConvLoaderS3 {
@@ -234,9 +254,14 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     __syncthreads();
 
     const int frow = lane & 31, fh = lane >> 5;
+#ifdef HNET_S3_TRACE
+    int tcount = 0;
+#endif
     for (int it = 0; it < n_iter; it++) {
         const int buf = NBUF == 2 ? (it & 1) : 0;
+        S3T();                                       // stamp 0: K-tile start
         if (it + 1 < n_iter) g_load(it0 + it + 1);
+        S3T();                                       // 1: prefetch issued
 #pragma unroll
         for (int step = 0; step < BK / 16; step++) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -268,13 +293,20 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the consumers of the prefetched registers behind the MFMAs (see igemm.h)
+        S3T();                                       // 2: MFMAs issued
         if constexpr (NBUF == 2) {
             if (it + 1 < n_iter) s_store(buf ^ 1);
+            S3T();
             __syncthreads();
+            S3T();
+            S3T();
         } else {
             __syncthreads();                 // every wave has read tile `it`
+            S3T();                                   // 3: past barrier 1
             if (it + 1 < n_iter) s_store(0);
+            S3T();                                   // 4: staged registers written to LDS
             __syncthreads();
+            S3T();                                   // 5: past barrier 2
         }
     }
 

@@ -1,3 +1,1 @@
-HNET_PRECISION=2 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
-HNET_PRECISION=0 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
-python bench.py > gpurun_out/bench_full.json 2>gpurun_out/bench_full.err; tail -c 3000 gpurun_out/bench_full.json
+for kp in 5120 5184 5248 5128 5152; do echo "Kp=$kp"; timeout 60 tools/trace_s3.bin 0 0 $kp | head -4 | tail -3; done
