@@ -22,7 +22,7 @@ SYMBOLS = [
     "hnet_infer_batch", "hnet_infer_batch_device", "hnet_infer_mc_partial_device", "hnet_mc_finish_device",
     "hnet_synchronize", "hnet_last_timing", "hnet_time_batch_device", "hnet_stage_count", "hnet_stage_name",
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
-    "hnet_op_prep", "hnet_debug_layer_output", "hnet_debug_h_part1",
+    "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
     L.hnet_op_dlt.argtypes = [vp, fp, C.c_int, fp]
     L.hnet_op_conv.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp]
     L.hnet_op_prep.argtypes = [vp, fp, fp, fp, C.c_int, fp]
+    L.hnet_op_prep_u8.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp, C.c_int, fp]
     L.hnet_debug_layer_output.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t]
     L.hnet_debug_h_part1.argtypes = [vp, C.c_int, fp]
     for name in SYMBOLS:

@@ -1020,6 +1020,25 @@ int hnet_op_prep(hnet_ctx* c, const float* img1, const float* img2, const float*
     return HNET_OK;
 }
 
+int hnet_op_prep_u8(hnet_ctx* c, const uint8_t* img1, const uint8_t* img2, const float* H, int k, float* out) {
+    if (!c || !img1 || !img2 || !out || (k != 1 && k != 2 && k != 4 && k != 8)) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int ho = IMG_H / k, wo = IMG_W / k;
+    uint8_t *d_1 = nullptr, *d_2 = nullptr;
+    float *d_h = nullptr, *d_o = nullptr, *d_t = nullptr;
+    HIPCHK(c, hipMalloc(&d_1, NPIX)); HIPCHK(c, hipMalloc(&d_2, NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
+    HIPCHK(c, dalloc(&d_o, (size_t)2 * ho * wo)); HIPCHK(c, dalloc(&d_t, (size_t)2 * ho * wo));
+    HIPCHK(c, hipMemcpy(d_1, img1, NPIX, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_2, img2, NPIX, hipMemcpyHostToDevice));
+    if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_prep(d_1, d_2, HNET_PIX_U8, H ? d_h : nullptr, k, d_o, 1, c->stream));
+    HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_1); (void)hipFree(d_2); (void)hipFree(d_h); (void)hipFree(d_o); (void)hipFree(d_t);
+    return HNET_OK;
+}
+
 int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t cap) {
     if (!c || !out || layer < 0 || layer >= 20 || pair < 0 || pair >= c->cfg.max_batch) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));

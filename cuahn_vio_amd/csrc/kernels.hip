@@ -4,6 +4,8 @@
 //   block_fc_dlt : Linear(5120,8) + DLT + homography composition, one workgroup per frame pair
 //   heads_fc2    : Dropout -> Linear(256,8) of both heads, per-sample outputs, ensemble + transfer
 // Reference ops are cited at each kernel.
+#include <cstdint>
+#include <cstdlib>
 #include "kernels.h"
 #include "geom.h"
 #include "../../include/hnet.h"
@@ -34,16 +36,22 @@ __device__ inline void fill_lut(float* lut) {
 //   (X,Y,Z) = H (u,v,1); x = X/Z, y = Y/Z; g = x * 2/(W-1) - 1; grid_sample(bilinear, zeros,
 //   align_corners=True) un-normalises i = ((g+1)/2)*(W-1) and blends the 4 neighbours; taps outside the
 //   image contribute 0.  fp32 throughout like the reference; fp32 division is IEEE (hipcc default).
-template <typename PIX>
-__device__ inline float warp_sample(const PIX* img, const float* h, int u, int v, const float* lut) {
+// sampling position of output pixel (u, v) in img2, in pixels: the normalise / un-normalise round trip of
+// grid_sample(align_corners=True) is kept (it is not the identity in fp32)
+__device__ inline void warp_coords(const float* h, int u, int v, float& ix, float& iy, float& Z) {
     const float fu = (float)u, fv = (float)v;
     const float X = fmaf(h[0], fu, fmaf(h[1], fv, h[2]));
     const float Y = fmaf(h[3], fu, fmaf(h[4], fv, h[5]));
-    const float Z = fmaf(h[6], fu, fmaf(h[7], fv, h[8]));
+    Z = fmaf(h[6], fu, fmaf(h[7], fv, h[8]));
     const float gx = (X / Z) * (float)(2.0 / (IMG_W - 1)) - 1.0f;
     const float gy = (Y / Z) * (float)(2.0 / (IMG_H - 1)) - 1.0f;
-    const float ix = ((gx + 1.0f) * 0.5f) * (float)(IMG_W - 1);
-    const float iy = ((gy + 1.0f) * 0.5f) * (float)(IMG_H - 1);
+    ix = ((gx + 1.0f) * 0.5f) * (float)(IMG_W - 1);
+    iy = ((gy + 1.0f) * 0.5f) * (float)(IMG_H - 1);
+}
+
+// bilinear blend of the four taps around (ix, iy) read from global memory; out-of-image taps contribute 0
+template <typename PIX>
+__device__ inline float warp_taps_global(const PIX* img, float ix, float iy, const float* lut) {
     const float x0f = floorf(ix), y0f = floorf(iy);
     // NaN / far-out coordinates: all taps out of range -> 0 (comparisons with NaN are false)
     if (!(x0f >= -1.0f && x0f <= (float)IMG_W && y0f >= -1.0f && y0f <= (float)IMG_H)) return 0.0f;
@@ -57,6 +65,183 @@ __device__ inline float warp_sample(const PIX* img, const float* h, int u, int v
     if (yin1 && xin0) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0, lut), wx0 * wy1, s);
     if (yin1 && xin1) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0 + 1, lut), wx1 * wy1, s);
     return s;
+}
+
+// WarpImg.warpSingleImage_H_Mtrx (warp.py:60-79) for one output pixel (u, v):
+//   (X,Y,Z) = H (u,v,1); x = X/Z, y = Y/Z; g = x * 2/(W-1) - 1; grid_sample(bilinear, zeros,
+//   align_corners=True) un-normalises i = ((g+1)/2)*(W-1) and blends the 4 neighbours; taps outside the
+//   image contribute 0.  fp32 throughout like the reference; fp32 division is IEEE (hipcc default).
+template <typename PIX>
+__device__ inline float warp_sample(const PIX* img, const float* h, int u, int v, const float* lut) {
+    float ix, iy, Z;
+    warp_coords(h, u, v, ix, iy, Z);
+    return warp_taps_global<PIX>(img, ix, iy, lut);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled warp: a workgroup owns a 64 x 32 tile of output pixels.  A projective map takes the tile to a convex
+// quadrilateral (Z keeps its sign), so the taps of every pixel of the tile lie inside the bounding box of the four
+// warped corners (+1 px for the second tap, +1 px of slack for fp32 rounding).  That box of img2 is copied ONCE into
+// LDS as float — coalesced 4-pixel loads, converted through the u8 -> f32 table, positions outside the image stored
+// as 0 — and the four taps of each pixel become LDS reads.  The byte gathers of the direct kernels (64 scattered
+// addresses per wave instruction, 4 per pixel) kept the texture addresser busy ~90 % of the time and the kernels at
+// ~1.9 TB/s; the arithmetic, and therefore every result bit, is unchanged.
+// Tiles whose box does not fit the staging buffer (extreme warps), whose Z changes sign or whose coordinates are
+// not finite fall back to the direct gathers; so does any single pixel whose taps fall outside the staged box.
+// ---------------------------------------------------------------------------------------------
+constexpr int WT_W = 64, WT_H = 32;          // output tile
+constexpr int WT_CAP = 7168;                 // staged floats (28 KB): e.g. 112 x 64
+
+// (float)b / 255.0f without the divide or a table: q = b * (1/255) is off by at most one ulp, one Newton step on the
+// remainder lands on the correctly rounded quotient — verified for all 256 bytes (test_u8_scaling_is_exact)
+__device__ __forceinline__ float u8_to_unit(float f) {
+    constexpr float r = 1.0f / 255.0f;
+    const float q = f * r;
+    return fmaf(fmaf(-255.0f, q, f), r, q);
+}
+template <typename PIX> __device__ __forceinline__ float4 load_px4(const PIX* p);
+template <> __device__ __forceinline__ float4 load_px4<uint8_t>(const uint8_t* p) {
+    const uint32_t q = *reinterpret_cast<const uint32_t*>(p);
+    return make_float4(u8_to_unit((float)(q & 255u)), u8_to_unit((float)((q >> 8) & 255u)), u8_to_unit((float)((q >> 16) & 255u)),
+                       u8_to_unit((float)(q >> 24)));
+}
+template <> __device__ __forceinline__ float4 load_px4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct WarpBox { int gx0, ry0, pitch, rows; bool ok; };
+
+template <typename PIX>
+__device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const float* h, int u0, int v0, float* __restrict__ reg) {
+    WarpBox bx;
+    float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
+    bool pos = true, neg = true, finite = true;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float ix, iy, Z;
+        warp_coords(h, u0 + (c & 1) * (WT_W - 1), v0 + (c >> 1) * (WT_H - 1), ix, iy, Z);
+        pos = pos && Z > 0.0f;
+        neg = neg && Z < 0.0f;
+        finite = finite && fabsf(ix) < 1.0e6f && fabsf(iy) < 1.0e6f;      // false for NaN
+        lo_x = fminf(lo_x, ix); hi_x = fmaxf(hi_x, ix);
+        lo_y = fminf(lo_y, iy); hi_y = fmaxf(hi_y, iy);
+    }
+    bx.ok = (pos || neg) && finite;
+    // taps of pixels that survive the far-out test lie in [-1, W] x [-1, H] (+1): clip the box to that frame
+    const int rx0 = max((int)floorf(bx.ok ? lo_x : 0.0f) - 1, -1), rx1 = min((int)floorf(bx.ok ? hi_x : 0.0f) + 2, IMG_W + 1);
+    const int ry0 = max((int)floorf(bx.ok ? lo_y : 0.0f) - 1, -1), ry1 = min((int)floorf(bx.ok ? hi_y : 0.0f) + 2, IMG_H + 1);
+    bx.gx0 = (rx0 + 4) / 4 * 4 - 4;                                     // rx0 >= -1: round down to a multiple of 4
+    bx.ry0 = ry0;
+    bx.pitch = rx1 >= rx0 ? (rx1 - bx.gx0 + 4) / 4 * 4 : 0;
+    bx.rows = ry1 >= ry0 ? ry1 - ry0 + 1 : 0;
+    if (bx.pitch * bx.rows > WT_CAP) bx.ok = false;
+    if (!bx.ok) return bx;
+    const int groups = bx.pitch >> 2;
+    for (int r = threadIdx.x >> 5; r < bx.rows; r += 8) {
+        const int y = ry0 + r;
+        const bool yin = y >= 0 && y < IMG_H;
+        for (int c = threadIdx.x & 31; c < groups; c += 32) {
+            const int x = bx.gx0 + 4 * c;                                // multiple of 4: the group is all in or all out
+            float4 f = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (yin && x >= 0 && x < IMG_W) f = load_px4<PIX>(img + y * IMG_W + x);
+            *reinterpret_cast<float4*>(&reg[r * bx.pitch + 4 * c]) = f;
+        }
+    }
+    return bx;
+}
+
+// one pixel from the staged box (same arithmetic as warp_taps_global: zeros stand in for the skipped taps).
+// Branch-free: the LDS addresses are clamped into the box and the result is selected afterwards, so that the eight
+// pixels of a thread are independent instruction streams the scheduler can interleave (with a branch per pixel the
+// LDS and v_rcp latencies of each pixel were exposed one after the other).  `fallback` is set when the pixel has
+// taps outside the staged box (or the tile has no box); the caller then recomputes it with warp_taps_global.
+__device__ __forceinline__ float warp_sample_box(const float* h, int u, int v, const WarpBox& bx, const float* reg, bool& fallback,
+                                                 float& ix, float& iy) {
+    float Z;
+    warp_coords(h, u, v, ix, iy, Z);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const bool near = x0f >= -1.0f && x0f <= (float)IMG_W && y0f >= -1.0f && y0f <= (float)IMG_H;   // false for NaN
+    const int cx = (int)(near ? x0f : 0.0f) - bx.gx0, cy = (int)(near ? y0f : 0.0f) - bx.ry0;
+    const bool inbox = bx.ok && cx >= 0 && cx + 1 < bx.pitch && cy >= 0 && cy + 1 < bx.rows;
+    fallback = near && !inbox;
+    const float wx1 = ix - x0f, wx0 = 1.0f - wx1, wy1 = iy - y0f, wy0 = 1.0f - wy1;
+    const float* t = reg + (inbox ? cy * bx.pitch + cx : 0);
+    const int down = inbox ? bx.pitch : 0;
+    float s = 0.0f;
+    s = fmaf(t[0], wx0 * wy0, s);
+    s = fmaf(t[1], wx1 * wy0, s);
+    s = fmaf(t[down], wx0 * wy1, s);
+    s = fmaf(t[down + 1], wx1 * wy1, s);
+    return near && inbox ? s : 0.0f;
+}
+
+// prep with warp, LDS-tiled: AvgPool_K(cat(img1, warp(img2, H))) -> NHWC [B][224/K][320/K][2].
+// Lane = column of the tile, wave w = rows 8w .. 8w+7, eight pixels of one column per thread: the taps of a wave are
+// (nearly) consecutive LDS words, the K = 1 stores are 512 contiguous bytes per wave and row.  Pooling: the rows of a
+// window are summed in the thread, its columns across lanes (xor 1, 2, 4); lane % K == 0 stores.
+template <typename PIX, int K>
+__global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
+                                                              const float* __restrict__ H, float* __restrict__ out) {
+    __shared__ float lut[256];                                          // only the per-pixel fallback path reads it
+    __shared__ __attribute__((aligned(16))) float reg[WT_CAP];
+    __shared__ __attribute__((aligned(16))) float a1[WT_H][WT_W];
+    if (PixRead<PIX>::kNeedLut) fill_lut(lut);
+    constexpr int TX = IMG_W / WT_W, TY = IMG_H / WT_H, HO = IMG_H / K, WO = IMG_W / K;
+    int bid = blockIdx.x;
+    const int tx = bid % TX; bid /= TX;
+    const int ty = bid % TY;
+    const int b = bid / TY;
+    const int u0 = tx * WT_W, v0 = ty * WT_H;
+    const PIX* i1 = img1 + (size_t)b * NPIX;
+    const PIX* i2 = img2 + (size_t)b * NPIX;
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+#pragma unroll
+    for (int g = threadIdx.x; g < WT_H * WT_W / 4; g += 256) {          // img1 tile: 512 groups of 4 pixels
+        const int r = g >> 4, c = (g & 15) * 4;
+        *reinterpret_cast<float4*>(&a1[r][c]) = load_px4<PIX>(i1 + (v0 + r) * IMG_W + u0 + c);
+    }
+    const WarpBox bx = warp_stage_box<PIX>(i2, h, u0, v0, reg);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+    const int u = u0 + lane;
+    float a[8], w[8], fx[8], fy[8];
+    uint32_t fb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        bool f;
+        a[i] = a1[r0 + i][lane];
+        w[i] = warp_sample_box(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
+        fb |= (uint32_t)f << i;
+    }
+    if (__builtin_expect(__any(fb != 0), 0)) {                          // rare: taps outside the staged box -> direct gathers
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (fb & (1u << i)) w[i] = warp_taps_global<PIX>(i2, fx[i], fy[i], lut);
+    }
+    if constexpr (K == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            *reinterpret_cast<float2*>(out + ((size_t)b * NPIX + (size_t)(v0 + r0 + i) * IMG_W + u) * 2) = make_float2(a[i], w[i]);
+    } else {
+        constexpr int NW = 8 / K;                                       // window rows this thread covers
+        float s1[NW], s2[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            s1[j] = 0.0f; s2[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; i++) { s1[j] += a[j * K + i]; s2[j] += w[j * K + i]; }
+        }
+#pragma unroll
+        for (int m = 1; m < K; m <<= 1)
+#pragma unroll
+            for (int j = 0; j < NW; j++) { s1[j] += __shfl_xor(s1[j], m); s2[j] += __shfl_xor(s2[j], m); }
+        if ((lane & (K - 1)) == 0) {
+            constexpr float inv = 1.0f / (float)(K * K);                // power of two: exact
+#pragma unroll
+            for (int j = 0; j < NW; j++)
+                *reinterpret_cast<float2*>(out + (((size_t)b * HO + (v0 + r0) / K + j) * WO + u / K) * 2) = make_float2(s1[j] * inv, s2[j] * inv);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,6 +326,21 @@ __global__ __launch_bounds__(256) void prep_k1_kernel(const PIX* __restrict__ im
 
 template <typename PIX>
 static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s) {
+    static const bool tiled = !(std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 0);   // 0: direct-gather kernels
+    // measured at batch 256 (ms, tiled vs direct): K=1 0.085 / 0.094, K=2 0.076 / 0.080, K=4 0.068 / 0.062 -> tiled for K <= 2
+    // (HNET_PREP_TILED=2 forces it for every K: the parity tests run both)
+    static const bool tiled_all = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 2;
+    if (H && tiled && (k <= 2 || tiled_all) && (((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {   // 4-pixel groups: u8 4 B, f32 16 B loads
+        const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
+        switch (k) {
+            case 1: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
+            case 2: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 2>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
+            case 4: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 4>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
+            case 8: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 8>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (k == 1 && H) {
         const long groups = (long)batch * (NPIX / 4);
         hipLaunchKernelGGL(prep_k1_kernel<PIX>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, i1, i2, H, out, batch);

@@ -150,6 +150,16 @@ class HnetEngine:
         check(self._h, self._L.hnet_op_prep(self._h, _fp(i1), _fp(i2), _fp(hm) if hm is not None else None, k, _fp(out)))
         return out
 
+    def op_prep_u8(self, img1, img2, h, k):
+        i1 = np.ascontiguousarray(img1, dtype=np.uint8).reshape(IMG_H, IMG_W)
+        i2 = np.ascontiguousarray(img2, dtype=np.uint8).reshape(IMG_H, IMG_W)
+        hm = None if h is None else np.ascontiguousarray(h, dtype=np.float32).reshape(9)
+        out = np.zeros((2, IMG_H // k, IMG_W // k), np.float32)
+        u8p = C.POINTER(C.c_uint8)
+        check(self._h, self._L.hnet_op_prep_u8(self._h, i1.ctypes.data_as(u8p), i2.ctypes.data_as(u8p),
+                                               _fp(hm) if hm is not None else None, k, _fp(out)))
+        return out
+
     def debug_layer_output(self, layer, pair=0):
         """[Cout, Ho, Wo] output of conv layer `layer` from the last forward"""
         from .weights import CONV_LAYERS

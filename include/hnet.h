@@ -157,6 +157,8 @@ int hnet_op_conv(hnet_ctx* ctx, int layer, const float* in, int batch, int h, in
 /* cat(img1, warp(img2,H)) -> AvgPool(k): img1,img2 [224][320] f32, H[9] or NULL (no warp), k in {1,2,4,8}
  * -> out [2][224/k][320/k]   (model_to_trace.py:153-157) */
 int hnet_op_prep(hnet_ctx* ctx, const float* img1, const float* img2, const float* H, int k, float* out);
+/* the same on u8 images as load_current_img receives them (u8 -> f32 / 255.0, HomographyNet.cpp:139-146) */
+int hnet_op_prep_u8(hnet_ctx* ctx, const uint8_t* img1, const uint8_t* img2, const float* H, int k, float* out);
 /* after a forward: copies the output of layer `layer` (0..19 convs) of pair `pair` as [Cout][Ho][Wo] */
 int hnet_debug_layer_output(hnet_ctx* ctx, int layer, int pair, float* out, size_t capacity_floats);
 /* after a forward: part-1 homography of pair `pair`, 9 floats */

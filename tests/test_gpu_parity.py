@@ -74,6 +74,64 @@ def test_op_prep(eng_full, k):
     assert np.abs(eng_full.op_prep(f1, f2, None, k)[0] - pyoracle.avgpool(f1[None], k)[0]).max() < 1e-6
 
 
+def _nasty_homographies():
+    g = np.load(os.path.join(GOLDEN_DIR, "warp_s11.npz"))
+    hs = {n: g["H_" + n].astype(np.float32) for n in ("identity", "shift", "oob", "persp")}
+    hs["z_zero"] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 0]], np.float32)                  # NaN coordinates everywhere
+    hs["z_sign_change"] = np.array([[1, 0, 0], [0, 1, 0], [-1 / 160.0, 0, 1]], np.float32)   # Z = 0 on the column u = 160
+    hs["zoom_out_3x"] = np.array([[3, 0, -300], [0, 3, -200], [0, 0, 1]], np.float32)       # source box of a tile > staging buffer
+    hs["rot90"] = np.array([[0, -1, 270], [1, 0, -50], [0, 0, 1]], np.float32)
+    hs["shrink"] = np.array([[0.05, 0, 100], [0, 0.05, 100], [0, 0, 1]], np.float32)        # whole tile inside 4 x 2 source pixels
+    hs["far_shift"] = np.array([[1, 0, 5000], [0, 1, 0], [0, 0, 1]], np.float32)
+    hs["edge_minus_half"] = np.array([[1, 0, -0.5], [0, 1, -0.5], [0, 0, 1]], np.float32)   # taps at -1 on the first row / column
+    return hs
+
+
+def _pool_like_kernel(x, k):
+    """AvgPool in the summation order of prep_warp_tiled_kernel: rows of a window sequentially, then a pairwise tree over its columns"""
+    h, w = x.shape
+    cols = np.zeros((h // k, w), np.float32)
+    for i in range(k):
+        cols = (cols + x[i::k]).astype(np.float32)
+    parts = [cols[:, j::k] for j in range(k)]
+    while len(parts) > 1:
+        parts = [(parts[2 * j] + parts[2 * j + 1]).astype(np.float32) for j in range(len(parts) // 2)]
+    return (parts[0] * np.float32(1.0 / (k * k))).astype(np.float32)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_tiled_warp_is_bitwise_the_direct_warp(eng_full, k):
+    """the LDS-tiled warp + pool kernel (u8 and f32 images) against the direct-gather warp kernel: same arithmetic, so
+    identical bits, for benign and for hostile homographies (fallback paths: box too large, Z sign change, NaN)"""
+    from cuahn_vio_amd import synth
+    from oracle import pyoracle
+    i1, i2, _ = synth.make_pair(21)
+    f1, f2 = pyoracle.as_f32_image(i1), pyoracle.as_f32_image(i2)
+    for name, hm in _nasty_homographies().items():
+        direct = eng_full.op_warp(f2, hm)                         # warp_f32_kernel: per-pixel global gathers
+        want = np.stack([_pool_like_kernel(f1, k), _pool_like_kernel(direct, k)])
+        got_u8 = eng_full.op_prep_u8(i1, i2, hm, k)
+        got_f32 = eng_full.op_prep(f1, f2, hm, k)
+        mode = os.environ.get("HNET_PREP_TILED", "1")
+        if mode != "0" and (k <= 2 or mode == "2"):   # otherwise the direct-gather pooling kernel runs (other summation order)
+            assert np.array_equal(got_u8, want), (name, float(np.abs(got_u8 - want).max()))
+            assert np.array_equal(got_f32, want), (name, float(np.abs(got_f32 - want).max()))
+        else:
+            assert np.abs(got_u8 - want).max() < 1e-6 and np.abs(got_f32 - want).max() < 1e-6, name
+        assert np.isfinite(got_u8).all()
+
+
+def test_u8_scaling_is_exact(eng_full):
+    """u8 -> float32 / 255.0 (HomographyNet.cpp:141) is evaluated without a divide in the tiled kernel: all 256 values, bit for bit"""
+    ramp = (np.arange(224 * 320) % 256).astype(np.uint8).reshape(224, 320)
+    ident = np.eye(3, dtype=np.float32)
+    got = eng_full.op_prep_u8(ramp, ramp[::-1].copy(), ident, 1)
+    assert np.array_equal(got[0], ramp.astype(np.float32) / np.float32(255.0))
+    # (channel 1 is not compared bit for bit: the normalise / un-normalise round trip of grid_sample makes the identity
+    # homography sample at x +- 1e-5, model warp.py:70)
+    assert np.abs(got[1] - ramp[::-1].astype(np.float32) / np.float32(255.0)).max() < 1e-4
+
+
 @pytest.mark.parametrize("layer", list(range(20)))
 def test_op_conv_each_layer(eng_full, state, layer):
     """every conv layer with its real geometry, batch 2 (ragged M: not a multiple of the tile), vs oracle conv"""
