@@ -141,10 +141,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # HNET_BENCH_SHARED_GPU=1: rehearsal of the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo for the
+    # gathers; RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+    shared = os.environ.get("HNET_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     B, n_mc = args.batch, args.mc
     blob = weights.pack_state_dict(weights.synthetic_state(0))
@@ -203,7 +211,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps

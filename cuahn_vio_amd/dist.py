@@ -29,6 +29,11 @@ def pack_outputs(mean: torch.Tensor, cov: torch.Tensor, out: torch.Tensor) -> to
 def _all_gather(dst: torch.Tensor, src: torch.Tensor, group=None):
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":
+        if src.is_cuda:      # single-GPU rehearsal of the multi-rank path (bench.py HNET_BENCH_SHARED_GPU=1): stage through the host
+            host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(host, src.detach().cpu().contiguous(), group=group)
+            dst.reshape(world, *src.shape).copy_(torch.stack(host, 0))
+            return
         chunks = list(dst.reshape(world, *src.shape).unbind(0))
         dist.all_gather(chunks, src.contiguous(), group=group)
     else:

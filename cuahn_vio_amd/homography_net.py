@@ -16,6 +16,8 @@ import numpy as np
 from . import _capi
 from ._capi import PIX_F32, PIX_U8, Config, HnetError, Timing, check, lib  # noqa: F401
 
+HIP_STREAM_LEGACY = 1      # hipStreamLegacy ((hipStream_t)1, hip_runtime_api.h): the NULL / default stream, named explicitly
+
 IMG_H, IMG_W = 224, 320
 VARIANTS = {"full": (0, 3), "prior3": (1, 3), "prior2": (1, 2), "prior1": (1, 1)}
 
@@ -79,19 +81,31 @@ class HnetEngine:
         return (mean, cov, err) if want_err else (mean, cov)
 
     # ---- device-resident entry points (raw device pointers, e.g. torch tensors' data_ptr()) ------
+    @staticmethod
+    def _stream(stream):
+        """stream argument of the device entry points: None -> the context's own stream (C ABI: NULL); a torch.cuda.Stream
+        or a raw hipStream_t handle -> that stream.  The handle 0 is torch's name for the legacy default stream; the C ABI
+        reserves NULL for "context stream", so 0 is passed as hipStreamLegacy ((hipStream_t)1) — the kernels then run in
+        order with torch's default-stream work (tensor fills, RCCL collectives)."""
+        if stream is None:
+            return None
+        h = getattr(stream, "cuda_stream", stream)
+        return HIP_STREAM_LEGACY if int(h) == 0 else int(h)
+
     def infer_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, d_err=None, stream=None):
         check(self._h, self._L.hnet_infer_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
-                                                       d_err, stream))
+                                                       d_err, self._stream(stream)))
 
     def infer_mc_partial_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s, d_logvar_s, d_h1, stream=None):
         check(self._h, self._L.hnet_infer_mc_partial_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s,
-                                                            d_logvar_s, d_h1, stream))
+                                                            d_logvar_s, d_h1, self._stream(stream)))
 
     def mc_finish_device(self, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov, stream=None):
-        check(self._h, self._L.hnet_mc_finish_device(self._h, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov, stream))
+        check(self._h, self._L.hnet_mc_finish_device(self._h, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov,
+                                                     self._stream(stream)))
 
     def synchronize(self, stream=None):
-        check(self._h, self._L.hnet_synchronize(self._h, stream))
+        check(self._h, self._L.hnet_synchronize(self._h, self._stream(stream)))
 
     def time_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, iters):
         per = np.zeros(iters, np.float32)

@@ -109,8 +109,9 @@ int hnet_infer(hnet_ctx* ctx, const double* prior_px, int iteration,
 int hnet_infer_batch(hnet_ctx* ctx, const void* prev, const void* curr, int pix_fmt, const float* prior,
                      int batch, uint64_t pair_seq0, float* mean, float* cov, float* err_map);
 
-/* Same with every buffer resident in device memory; enqueues on `stream` (a hipStream_t, NULL = default
- * stream of the context) and does not synchronise. */
+/* Same with every buffer resident in device memory; enqueues on `stream` (a hipStream_t) and does not synchronise.
+ * NULL = the context's own (non-blocking) stream; to enqueue on HIP's legacy default stream pass hipStreamLegacy
+ * ((hipStream_t)1) — the handle 0 some frameworks report for it cannot be told apart from NULL. */
 int hnet_infer_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
                             const float* d_prior, int batch, uint64_t pair_seq0,
                             float* d_mean, float* d_cov, float* d_err_map, void* stream);

@@ -1,10 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-for t in 1 2; do
-HNET_S3_PC=$t rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_pc$t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency > /dev/null 2>&1
-python3 - <<PY
-import csv, glob, os
-f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/prof_pc$t/**/*kernel_stats.csv', recursive=True)[0]
-for r in list(csv.DictReader(open(f))):
-    if 'pc_kernel' in r['Name'] or 'heads_prep' in r['Name']: print($t, r['Name'][:90], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
-PY
-done
+for i in 1 2 3 4 5; do timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port 2977$i tests/dist_gpu_worker.py /tmp/v.json > /tmp/log.txt 2>&1 || tail -5 /tmp/log.txt; cat /tmp/v.json; echo; done
+HNET_PRECISION=2 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+python bench.py --no-cpu-baseline --steps 20 > gpurun_out/bench_s3.json 2>/dev/null; python -c "
+import json; r=json.load(open('gpurun_out/bench_s3.json')); print(r['value'], r['ms_per_step'], r['latency_batch1_ms'])"
