@@ -206,7 +206,7 @@ class HomographyNet:
 
     def __init__(self, network_model_path, network_model_iterative_path="", use_prior=False, num_of_iteration=1,
                  show_imgs=False, *, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=0, device_id=0,
-                 weights_blob=None):
+                 weights_blob=None, precision=None):
         self.use_prior_4pt_offset = bool(use_prior)
         self.show_phtometric_error = "_showError" in str(network_model_path)
         self.cv_imshow = bool(show_imgs)
@@ -215,7 +215,7 @@ class HomographyNet:
         print("Loading the Network Model (HNETW001 weights) ...")
         self._eng = HnetEngine(weights_blob if weights_blob is not None else network_model_path, variant=variant,
                                mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
-                               emit_error_map=self.show_phtometric_error, device_id=device_id)
+                               emit_error_map=self.show_phtometric_error, device_id=device_id, precision=precision)
         t = self._eng.last_timing()
         print(f"[TIME]: {t['host_ms']:.4f} milliseconds for the first network inference")
         self._pred_mean = np.zeros((8, 1), np.float32)
