@@ -1,0 +1,173 @@
+/* hnet_ekf.h — the filter step that CONSUMES the HomographyNet output, dependency free.
+ *
+ * Restates, in plain C++ (double, no Eigen), what cuahn::UpdaterHNet::update does with the network's 8 corner
+ * offsets and their 8x8 covariance (reference cuahn/src/update/UpdaterHNet.cpp:28-61, constants UpdaterHNet.h:57-64),
+ * the glue around it in VioManager::feed_measurement (cuahn/src/core/VioManager.cpp:227-275: prior = state offsets
+ * x 159.5, iterated EKF loop, offsets reset) and State::reset_4pt_offset (cuahn/src/state/State.cpp:101-111).
+ * It exists so that the drop-in claim of INTEGRATION.md can be exercised end to end without ROS / Eigen / OpenCV:
+ * tests/cpp/iekf_demo.cpp runs adapter -> this update for a few frames on the GPU box, and tests/test_ekf_cpu.py
+ * checks every function against the numpy restatement oracle/ekf_oracle.py.
+ *
+ * State layout (27 error states, State.h:115-123): p 0..2, q 3..5, v 6..8, ba 9..11, bg 12..14, corner offsets
+ * ul 15..17, bl 18..20, br 21..23, ur 24..26 (each corner (x, y, z) in normalised camera coordinates; the network
+ * measures (x, y)).  Quaternion: Hamilton, (w, x, y, z).
+ * Units: the network speaks pixels of the f = 159.5 virtual camera; the filter divides means by 159.5 and
+ * covariances by 159.5^2 = 25440.25 (UpdaterHNet.cpp:31-33).
+ */
+#ifndef HNET_EKF_H
+#define HNET_EKF_H
+
+#include <cmath>
+#include <cstring>
+
+namespace hnet_ekf {
+
+constexpr int NS = 27;                 /* error-state dimension */
+constexpr double F_PIX = 159.5;        /* (320-1)/2 / tan(45 deg), CamBase.h:166-169 */
+
+struct State {
+    double p[3];
+    double q[4];                       /* Hamilton (w, x, y, z) */
+    double v[3];
+    double ba[3];
+    double bg[3];
+    double offset[4][3];               /* ul, bl, br, ur (State.h:110-113 order) */
+    double cov[NS * NS];               /* row major */
+};
+
+/* VioManager.cpp:230-234 — the prior handed to network_inference: (x, y) of the four corner offsets, x 159.5 */
+inline void prior_pixels(const State& s, double prior_px[8], double prior_cam[8]) {
+    for (int c = 0; c < 4; c++)
+        for (int k = 0; k < 2; k++) {
+            prior_cam[2 * c + k] = s.offset[c][k];
+            prior_px[2 * c + k] = s.offset[c][k] * F_PIX;
+        }
+}
+
+/* in-place inverse of an n x n matrix (n <= 8), Gauss-Jordan with partial pivoting; returns false if singular */
+inline bool invert(double* a, int n) {
+    double inv[64];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) inv[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++)
+            if (std::fabs(a[r * n + col]) > std::fabs(a[piv * n + col])) piv = r;
+        if (a[piv * n + col] == 0.0) return false;
+        if (piv != col)
+            for (int j = 0; j < n; j++) {
+                double t = a[col * n + j]; a[col * n + j] = a[piv * n + j]; a[piv * n + j] = t;
+                t = inv[col * n + j]; inv[col * n + j] = inv[piv * n + j]; inv[piv * n + j] = t;
+            }
+        const double d = 1.0 / a[col * n + col];
+        for (int j = 0; j < n; j++) { a[col * n + j] *= d; inv[col * n + j] *= d; }
+        for (int r = 0; r < n; r++) {
+            if (r == col) continue;
+            const double f = a[r * n + col];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; j++) { a[r * n + j] -= f * a[col * n + j]; inv[r * n + j] -= f * inv[col * n + j]; }
+        }
+    }
+    std::memcpy(a, inv, sizeof(double) * n * n);
+    return true;
+}
+
+/* quat_ops.h:526-538 Ham_quat_update(rot_vec) * q, then quatnorm (quat_ops.h:479-484: sign flip on the LAST component) */
+inline void quat_apply_rotvec(const double rv[3], double q[4]) {
+    const double ang = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    const double c = std::cos(0.5 * ang);
+    /* the reference divides by the angle without a guard (0/0 for a zero update); the limit is used here */
+    const double sc = ang > 0.0 ? std::sin(0.5 * ang) / ang : 0.5;
+    const double d[3] = {sc * rv[0], sc * rv[1], sc * rv[2]};
+    /* matrix: [[c, -d^T], [d, c I + skew(-d)]] */
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    double r[4];
+    r[0] = c * w - d[0] * x - d[1] * y - d[2] * z;
+    r[1] = d[0] * w + c * x + d[2] * y - d[1] * z;
+    r[2] = d[1] * w - d[2] * x + c * y + d[0] * z;
+    r[3] = d[2] * w + d[1] * x - d[0] * y + c * z;
+    if (r[3] < 0.0) for (int i = 0; i < 4; i++) r[i] = -r[i];
+    const double n = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    for (int i = 0; i < 4; i++) q[i] = r[i] / n;
+}
+
+/* UpdaterHNet::update (UpdaterHNet.cpp:28-61).  net_mean_px[8], net_cov_px[64]: what get_pred_mean()/get_pred_Cov()
+ * return; propagated[8]: the prior in camera units (prior_pixels() / 159.5); k_net_cov: UpdaterOptions.h:33 (10.0).
+ * Returns false if the innovation covariance is singular (the reference would produce inf/nan). */
+inline bool update(State& s, const double net_mean_px[8], const double net_cov_px[64], const double propagated[8], double k_net_cov,
+                   bool update_offset) {
+    /* H selects (x, y) of each corner: rows 2c+k <- state 15 + 3c + k;  Hn = I8 */
+    int sel[8];
+    for (int c = 0; c < 4; c++) { sel[2 * c] = 15 + 3 * c; sel[2 * c + 1] = 16 + 3 * c; }
+    double S[64], PHt[NS * 8];
+    for (int i = 0; i < NS; i++)
+        for (int j = 0; j < 8; j++) PHt[i * 8 + j] = s.cov[i * NS + sel[j]];
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) S[i * 8 + j] = s.cov[sel[i] * NS + sel[j]] + k_net_cov * net_cov_px[i * 8 + j] / (F_PIX * F_PIX);
+    if (!invert(S, 8)) return false;
+    double K[NS * 8];
+    for (int i = 0; i < NS; i++)
+        for (int j = 0; j < 8; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 8; k++) a += PHt[i * 8 + k] * S[k * 8 + j];
+            K[i * 8 + j] = a;
+        }
+    double inno[8];
+    for (int i = 0; i < 8; i++) inno[i] = net_mean_px[i] / F_PIX - propagated[i];
+    /* Cov <- (I - K H) Cov  (not the Joseph form, as the reference) */
+    double KH_P[NS * NS];
+    for (int i = 0; i < NS; i++)
+        for (int j = 0; j < NS; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 8; k++) a += K[i * 8 + k] * s.cov[sel[k] * NS + j];
+            KH_P[i * NS + j] = a;
+        }
+    for (int i = 0; i < NS * NS; i++) s.cov[i] -= KH_P[i];
+    double dx[NS];
+    const int rows = update_offset ? NS : 15;          /* last IEKF iteration: the offsets are about to be reset anyway */
+    for (int i = 0; i < NS; i++) dx[i] = 0.0;
+    for (int i = 0; i < rows; i++)
+        for (int k = 0; k < 8; k++) dx[i] += K[i * 8 + k] * inno[k];
+    for (int i = 0; i < 3; i++) s.p[i] += dx[i];
+    quat_apply_rotvec(dx + 3, s.q);
+    for (int i = 0; i < 3; i++) { s.v[i] += dx[6 + i]; s.ba[i] += dx[9 + i]; s.bg[i] += dx[12 + i]; }
+    if (update_offset)
+        for (int c = 0; c < 4; c++)
+            for (int k = 0; k < 3; k++) s.offset[c][k] += dx[15 + 3 * c + k];
+    return true;
+}
+
+/* State::reset_4pt_offset (State.cpp:101-111): offsets to zero, covariance keeps only the IMU 15 x 15 block */
+inline void reset_4pt_offset(State& s) {
+    std::memset(s.offset, 0, sizeof s.offset);
+    for (int i = 0; i < NS; i++)
+        for (int j = 0; j < NS; j++)
+            if (i >= 15 || j >= 15) s.cov[i * NS + j] = 0.0;
+}
+
+/* The iterated update of VioManager.cpp:227-275 around any object with the reference's HomographyNet surface
+ * (network_inference / get_pred_mean / get_pred_Cov returning something indexable as (i) resp. (i, j)). */
+template <class Net, class Vec8>
+inline int iterated_update(State& s, Net& net, int max_iekf_iteration, double k_net_cov, Vec8& prior_px_vec) {
+    int done = 0;
+    for (int it = 0; it < max_iekf_iteration; it++) {
+        double prior_px[8], prior_cam[8];
+        prior_pixels(s, prior_px, prior_cam);
+        for (int i = 0; i < 8; i++) prior_px_vec[i] = prior_px[i];
+        net.network_inference(prior_px_vec, it);
+        const auto m = net.get_pred_mean();
+        const auto C = net.get_pred_Cov();
+        double mean[8], cov[64];
+        for (int i = 0; i < 8; i++) {
+            mean[i] = m(i, 0);
+            for (int j = 0; j < 8; j++) cov[i * 8 + j] = C(i, j);
+        }
+        if (!update(s, mean, cov, prior_cam, k_net_cov, it != max_iekf_iteration - 1)) break;
+        done++;
+    }
+    reset_4pt_offset(s);
+    return done;
+}
+
+}  // namespace hnet_ekf
+#endif  /* HNET_EKF_H */

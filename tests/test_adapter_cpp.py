@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "adapter_smoke.bin")
 
 
-def _build():
+def _build(src="adapter_smoke.cpp", out=None):
     from cuahn_vio_amd import _capi
     if not os.path.exists(_capi.LIB_PATH):
         import __graft_entry__ as g
         g.build()
     rocm_lib = "/opt/rocm/lib"
     cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"), "-o", BIN,
+           os.path.join(ROOT, "tests", "cpp", src), "-o", out or BIN,
            "-L", os.path.join(ROOT, "cuahn_vio_amd"), "-lhnet_hip", f"-Wl,-rpath,{os.path.join(ROOT, 'cuahn_vio_amd')}",
            "-L", rocm_lib, "-lamdhip64", f"-Wl,-rpath,{rocm_lib}"]
     subprocess.run(cmd, check=True)
@@ -59,3 +59,57 @@ def test_adapter_runs_like_the_reference_call_sites(blob, tmp_path):
         assert np.array_equal(vals[:8].astype(np.float32), m[0])
         assert np.array_equal(vals[8:].astype(np.float32).reshape(8, 8), c[0])
     eng.close()
+
+
+IEKF_BIN = os.path.join(ROOT, "tests", "cpp", "iekf_demo.bin")
+
+
+def test_iekf_demo_compiles():
+    _build("iekf_demo.cpp", IEKF_BIN)
+    assert os.path.exists(IEKF_BIN)
+
+
+@pytest.mark.gpu
+def test_adapter_feeds_the_iterated_ekf_update(blob, tmp_path):
+    """drop-in end to end: C++ adapter + include/hnet_ekf.h run the reference's per-frame loop
+    (prior from the state, network_inference, UpdaterHNet::update, twice per frame, offsets reset); the same loop in
+    Python (batch entry point + numpy restatement of the update) must land on the same filter state"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from oracle import ekf_oracle
+    _build("iekf_demo.cpp", IEKF_BIN)
+    wpath = tmp_path / "traced_model_3_blocks_using_prior.hnw"
+    wpath.write_bytes(blob)
+    frames = np.stack([synth.make_pair(60 + i)[0] for i in range(4)])
+    fpath = tmp_path / "frames.u8"
+    frames.tofile(fpath)
+    env = dict(os.environ, HNET_MC_SEED="99", HNET_DROPOUT_P="0.05")
+    r = subprocess.run([IEKF_BIN, str(wpath), str(fpath), "4", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("STATE")]
+    assert [int(x[1]) for x in rows] == [1, 2, 3] and all(int(x[2]) == 2 for x in rows)
+
+    eng = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=99, max_batch=1)
+    st = dict(p=np.zeros(3), q=np.array([1.0, 0, 0, 0]), v=np.zeros(3), ba=np.zeros(3), bg=np.zeros(3), offset=np.zeros((4, 3)),
+              cov=np.diag([1e-4] * 15 + [0.0] * 12))
+    seq = 0
+    for x in rows:
+        k = int(x[1])
+        for c in range(4):
+            st["offset"][c, 0] += 0.004 * (c + 1)
+            st["offset"][c, 1] -= 0.003 * (c + 1)
+            for d in range(3):
+                o = 15 + 3 * c + d
+                st["cov"][o, o] += 2.5e-3
+                st["cov"][d, o] = st["cov"][o, d] = 2e-5
+                st["cov"][6 + d, o] = st["cov"][o, 6 + d] = -1e-5
+        for it in range(2):
+            prop = st["offset"][:, :2].reshape(8).copy()
+            m, c = eng.infer_batch(frames[k - 1][None], frames[k][None], (prop * ekf_oracle.F_PIX).astype(np.float32)[None], pair_seq0=seq)
+            seq += 1
+            st = ekf_oracle.update(st, m[0].astype(np.float64), c[0].astype(np.float64), prop, 10.0, it == 0)
+        st = ekf_oracle.reset_4pt_offset(st)
+        got = np.array([float(v) for v in x[3:]])
+        want = np.concatenate([st["p"], st["q"], st["v"], np.diag(st["cov"])[:15]])
+        assert np.abs(got - want).max() < 1e-9, (k, np.abs(got - want).max())
+        assert np.abs(st["p"]).max() > 0 and (np.diag(st["cov"])[:15] > 0).all()
