@@ -91,6 +91,87 @@ inline void quat_apply_rotvec(const double rv[3], double q[4]) {
     for (int i = 0; i < 4; i++) q[i] = r[i] / n;
 }
 
+/* ---- prior generation: the discrete mean propagation that produces the corner offsets the network
+ * receives as prior.  Propagator::predict_and_compute prerequisites (cuahn/src/state/Propagator.cpp:211-220) and
+ * Propagator::predict_mean_discrete (:342-364).  Body frame forward-left-up; the ground plane normal in the world is
+ * (0, 0, -1) (Propagator.h:101).  The covariance propagation (F, Fw Jacobians, :222-330) is NOT restated. */
+struct Extrinsics {
+    double c_R_i[9];                   /* camera <- IMU rotation, row major (State.h:108) */
+    double i_t_i2c[3];                 /* IMU -> camera translation in the IMU frame (State.h:107) */
+};
+
+/* the four image corners in normalised camera coordinates (State.h:110-113), order ul, bl, br, ur */
+inline const double* corner_xy1(int c) {
+    static const double k[4][3] = {{-1.0, -0.69906, 1.0}, {-1.0, 0.69906, 1.0}, {1.0, 0.69906, 1.0}, {1.0, -0.69906, 1.0}};
+    return k[c];
+}
+
+/* quat_ops.h:549-553 Ham_quat_2_Rot: local -> global rotation of a Hamilton quaternion (w, x, y, z) */
+inline void quat_to_rot(const double q[4], double R[9]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double s = w * w - (x * x + y * y + z * z);
+    const double v[3] = {x, y, z};
+    const double sk[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = (i == j ? s : 0.0) + 2.0 * v[i] * v[j] + 2.0 * w * sk[i * 3 + j];
+}
+
+inline void mat3_vec(const double* M, const double* v, double* o) {
+    for (int i = 0; i < 3; i++) o[i] = M[i * 3] * v[0] + M[i * 3 + 1] * v[1] + M[i * 3 + 2] * v[2];
+}
+inline void cross(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+inline void propagate_mean(State& s, const Extrinsics& e, double dt, const double w_hat[3], const double a_hat[3], double gravity_mag = 9.81) {
+    double R[9], Rt[9];
+    quat_to_rot(s.q, R);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Rt[i * 3 + j] = R[j * 3 + i];
+    /* Propagator.cpp:212-215 */
+    double wc[3], vc[3], muc[3], tmp[3], tmp2[3];
+    mat3_vec(e.c_R_i, w_hat, wc);
+    cross(w_hat, e.i_t_i2c, tmp);
+    for (int i = 0; i < 3; i++) tmp[i] += s.v[i];
+    mat3_vec(e.c_R_i, tmp, vc);
+    const double muw[3] = {0.0, 0.0, -1.0};
+    mat3_vec(Rt, muw, tmp);
+    mat3_vec(e.c_R_i, tmp, muc);
+    for (int i = 0; i < 3; i++) tmp[i] = s.p[i] + e.i_t_i2c[i];
+    mat3_vec(R, tmp, tmp2);
+    const double dc = tmp2[2];
+    /* corner dynamics use the state BEFORE the IMU part is advanced (:217-220, :357-362) */
+    double Hm[9];
+    const double skw[9] = {0, -wc[2], wc[1], wc[2], 0, -wc[0], -wc[1], wc[0], 0};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Hm[i * 3 + j] = skw[i * 3 + j] + vc[i] * muc[j] / dc;
+    double new_off[4][3];
+    for (int c = 0; c < 4; c++) {
+        double pt[3], Hp[3];
+        for (int i = 0; i < 3; i++) pt[i] = corner_xy1(c)[i] + s.offset[c][i];
+        mat3_vec(Hm, pt, Hp);
+        /* -(I - pt ez^T) H pt = -(Hp - pt * Hp_z) */
+        for (int i = 0; i < 3; i++) new_off[c][i] = s.offset[c][i] + dt * (-(Hp[i] - pt[i] * Hp[2]));
+    }
+    /* :347-354 (the position / velocity are expressed in the body frame in this filter) */
+    double wdt[3] = {w_hat[0] * dt, w_hat[1] * dt, w_hat[2] * dt};
+    double nq[4] = {s.q[0], s.q[1], s.q[2], s.q[3]};
+    quat_apply_rotvec(wdt, nq);
+    double wxv[3], wxp[3], g[3];
+    cross(w_hat, s.v, wxv);
+    cross(w_hat, s.p, wxp);
+    const double grav[3] = {0.0, 0.0, -gravity_mag};
+    mat3_vec(Rt, grav, g);
+    double nv[3], np[3];
+    for (int i = 0; i < 3; i++) {
+        nv[i] = s.v[i] + dt * (-wxv[i] + a_hat[i] + g[i]);
+        np[i] = s.p[i] + dt * (-wxp[i] + s.v[i]);
+    }
+    for (int i = 0; i < 3; i++) { s.p[i] = np[i]; s.v[i] = nv[i]; }
+    for (int i = 0; i < 4; i++) s.q[i] = nq[i];
+    std::memcpy(s.offset, new_off, sizeof new_off);
+}
+
 /* UpdaterHNet::update (UpdaterHNet.cpp:28-61).  net_mean_px[8], net_cov_px[64]: what get_pred_mean()/get_pred_Cov()
  * return; propagated[8]: the prior in camera units (prior_pixels() / 159.5); k_net_cov: UpdaterOptions.h:33 (10.0).
  * Returns false if the innovation covariance is singular (the reference would produce inf/nan). */

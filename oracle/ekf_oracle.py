@@ -66,3 +66,30 @@ def reset_4pt_offset(state):
     c[:15, :15] = state["cov"][:15, :15]
     out["cov"] = c
     return out
+
+
+# ---- prior generation: Propagator.cpp:211-220 and predict_mean_discrete :342-364 (mean only)
+CORNERS = np.array([[-1.0, -0.69906, 1.0], [-1.0, 0.69906, 1.0], [1.0, 0.69906, 1.0], [1.0, -0.69906, 1.0]])
+
+
+def ham_quat_2_rot(q):
+    v = q[1:]
+    return np.eye(3) * (q[0] ** 2 - v @ v) + 2 * np.outer(v, v) + 2 * q[0] * skew(v)
+
+
+def propagate_mean(state, c_R_i, i_t_i2c, dt, w_hat, a_hat, gravity_mag=9.81):
+    R = ham_quat_2_rot(state["q"])
+    wc = c_R_i @ w_hat
+    vc = c_R_i @ (state["v"] + skew(w_hat) @ i_t_i2c)
+    muc = c_R_i @ R.T @ np.array([0.0, 0.0, -1.0])
+    dc = (R @ (state["p"] + i_t_i2c))[2]
+    Hm = skew(wc) + np.outer(vc, muc) / dc
+    ez = np.array([[0.0, 0.0, 1.0]])
+    out = {k: np.array(v, float).copy() for k, v in state.items()}
+    for c in range(4):
+        pt = CORNERS[c] + state["offset"][c]
+        out["offset"][c] = state["offset"][c] + dt * (-(np.eye(3) - np.outer(pt, ez)) @ Hm @ pt)
+    out["q"] = quatnorm(ham_quat_update(w_hat * dt) @ state["q"])
+    out["v"] = state["v"] + dt * (-skew(w_hat) @ state["v"] + a_hat + R.T @ np.array([0.0, 0.0, -gravity_mag]))
+    out["p"] = state["p"] + dt * (-skew(w_hat) @ state["p"] + state["v"])
+    return out

@@ -2,6 +2,7 @@
 //   in : n_cases, then per case: p3 q4 v3 ba3 bg3 offset12 cov729 | mean8 cov64 propagated8 k_net_cov update_offset
 //   out: per case: ok, p3 q4 v3 ba3 bg3 offset12 cov729, then the same after reset_4pt_offset
 #include <cstdio>
+#include <string>
 #include <vector>
 #include "hnet_ekf.h"
 
@@ -11,7 +12,43 @@ static void put(std::vector<double>& o, const hnet_ekf::State& s) {
     o.insert(o.end(), &s.offset[0][0], &s.offset[0][0] + 12); o.insert(o.end(), s.cov, s.cov + 729);
 }
 
+// mode "prop": in: n, then per case p3 q4 v3 ba3 bg3 offset12 | c_R_i9 t3 dt w3 a3 ; out: p3 q4 v3 offset12
+static int prop_mode(const char* fin, const char* fout) {
+    FILE* f = std::fopen(fin, "rb");
+    if (!f) return 2;
+    double n;
+    if (std::fread(&n, 8, 1, f) != 1) return 2;
+    std::vector<double> out;
+    for (int c = 0; c < (int)n; c++) {
+        double in[28 + 9 + 3 + 1 + 3 + 3];
+        if (std::fread(in, 8, sizeof in / 8, f) != sizeof in / 8) return 3;
+        hnet_ekf::State s = {};
+        const double* d = in;
+        for (int i = 0; i < 3; i++) s.p[i] = *d++;
+        for (int i = 0; i < 4; i++) s.q[i] = *d++;
+        for (int i = 0; i < 3; i++) s.v[i] = *d++;
+        for (int i = 0; i < 3; i++) s.ba[i] = *d++;
+        for (int i = 0; i < 3; i++) s.bg[i] = *d++;
+        for (int i = 0; i < 12; i++) (&s.offset[0][0])[i] = *d++;
+        hnet_ekf::Extrinsics e;
+        for (int i = 0; i < 9; i++) e.c_R_i[i] = *d++;
+        for (int i = 0; i < 3; i++) e.i_t_i2c[i] = *d++;
+        const double dt = *d++;
+        const double* w = d; d += 3;
+        const double* a = d; d += 3;
+        hnet_ekf::propagate_mean(s, e, dt, w, a);
+        out.insert(out.end(), s.p, s.p + 3); out.insert(out.end(), s.q, s.q + 4); out.insert(out.end(), s.v, s.v + 3);
+        out.insert(out.end(), &s.offset[0][0], &s.offset[0][0] + 12);
+    }
+    std::fclose(f);
+    FILE* g = std::fopen(fout, "wb");
+    std::fwrite(out.data(), 8, out.size(), g);
+    std::fclose(g);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 4 && std::string(argv[3]) == "prop") return prop_mode(argv[1], argv[2]);
     if (argc < 3) return 2;
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;

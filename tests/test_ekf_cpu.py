@@ -40,9 +40,13 @@ def _cases(n, rng):
     return out
 
 
-def test_ekf_update_matches_numpy_restatement(tmp_path):
+def _build():
     subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "cpp", "ekf_check.cpp"), "-o", BIN], check=True)
+
+
+def test_ekf_update_matches_numpy_restatement(tmp_path):
+    _build()
     cases = _cases(12, np.random.default_rng(7))
     blob = [np.array([float(len(cases))])]
     for st, mean, ncov, prop, k, upd in cases:
@@ -63,3 +67,37 @@ def test_ekf_update_matches_numpy_restatement(tmp_path):
             before = np.abs(mean / ekf_oracle.F_PIX - prop)
             after = np.abs(mean / ekf_oracle.F_PIX - ref["offset"][:, :2].reshape(8))
             assert after.sum() < before.sum() + 1e-12
+
+
+def test_prior_propagation_matches_numpy_restatement(tmp_path):
+    """Propagator::predict_mean_discrete (the corner-offset prior, SURVEY.md §8 f-2): C++ header vs numpy restatement, and the
+    physics of the restated model: a camera looking straight down, moving forward over the ground plane, sees every corner
+    drift backwards by v/h per second (normalised coordinates)"""
+    _build()
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(10):
+        q = rng.standard_normal(4) * np.array([1.0, 0.2, 0.2, 0.2])
+        q /= np.linalg.norm(q)
+        st = dict(p=np.array([0.0, 0.0, 0.0]) + rng.standard_normal(3) * 0.3 + np.array([0, 0, 1.5]), q=q, v=rng.standard_normal(3), ba=np.zeros(3),
+                  bg=np.zeros(3), offset=rng.standard_normal((4, 3)) * 0.01, cov=np.eye(27))
+        a = rng.standard_normal((3, 3))
+        c_R_i, _ = np.linalg.qr(a)
+        cases.append((st, c_R_i, rng.standard_normal(3) * 0.05, 0.005 + 0.01 * rng.random(), rng.standard_normal(3) * 0.5, rng.standard_normal(3) * 2.0))
+    blob = [np.array([float(len(cases))])]
+    for st, c_R_i, t, dt, w, a in cases:
+        blob += [st["p"], st["q"], st["v"], st["ba"], st["bg"], st["offset"].reshape(-1), c_R_i.reshape(-1), t, np.array([dt]), w, a]
+    fin, fout = tmp_path / "in.f64", tmp_path / "out.f64"
+    np.concatenate(blob).astype("<f8").tofile(fin)
+    subprocess.run([BIN, str(fin), str(fout), "prop"], check=True, timeout=60)
+    got = np.fromfile(fout, "<f8").reshape(len(cases), 22)
+    for (st, c_R_i, t, dt, w, a), g in zip(cases, got):
+        ref = ekf_oracle.propagate_mean(st, c_R_i, t, dt, w, a)
+        want = np.concatenate([ref["p"], ref["q"], ref["v"], ref["offset"].reshape(-1)])
+        assert np.abs(g - want).max() < 1e-13 * max(1.0, np.abs(want).max())
+    # nadir camera, height 2 (dc = (R (p + t))_z with the plane normal (0, 0, -1)), pure forward speed 1 along the camera x axis
+    st = dict(p=np.array([0.0, 0.0, 2.0]), q=np.array([1.0, 0, 0, 0]), v=np.array([1.0, 0.0, 0.0]), ba=np.zeros(3), bg=np.zeros(3),
+              offset=np.zeros((4, 3)), cov=np.eye(27))
+    c_R_i = np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])      # camera z = body -z: looks down
+    out = ekf_oracle.propagate_mean(st, c_R_i, np.zeros(3), 0.01, np.zeros(3), np.array([0.0, 0.0, 9.81]))
+    assert np.allclose(out["offset"][:, 0], -0.01 * 1.0 / 2.0, atol=1e-12) and np.allclose(out["offset"][:, 1:], 0.0, atol=1e-12)
