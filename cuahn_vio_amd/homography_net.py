@@ -32,8 +32,8 @@ class HnetEngine:
     def __init__(self, weights, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1,
                  emit_error_map=False, device_id=0, mc_shard=None, precision=None):
         L = lib()
-        if precision is None:   # HNET_PRECISION=2 runs everything on the split-bf16 (fp32-grade) MFMA path
-            precision = int(os.environ.get("HNET_PRECISION", str(_capi.PREC_FP32)))
+        if precision is None:   # default: split-bf16 (fp32-grade) MFMA path; HNET_PRECISION=0 selects the exact-fp32 MFMA path
+            precision = int(os.environ.get("HNET_PRECISION", str(_capi.PREC_BF16X3)))
         cfg = Config()
         L.hnet_default_config(C.byref(cfg))
         cfg.device_id = device_id

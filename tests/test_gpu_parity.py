@@ -14,18 +14,22 @@ pytestmark = pytest.mark.gpu
 MC_SEED = 0x5EED5EED12345678
 
 
-@pytest.fixture(scope="module")
-def eng_full(blob):
+# both arithmetic modes in every run: the split-bf16 path (default, the one bench.py reports) and the exact-fp32 MFMA path
+PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")]
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def eng_full(blob, request):
     from cuahn_vio_amd.homography_net import HnetEngine
-    e = HnetEngine(blob, variant="full", mc_samples=16, dropout_p=0.0, max_batch=8, emit_error_map=True)
+    e = HnetEngine(blob, variant="full", mc_samples=16, dropout_p=0.0, max_batch=8, emit_error_map=True, precision=request.param)
     yield e
     e.close()
 
 
-def _engine_for(blob, g, max_batch=1):
+def _engine_for(blob, g, max_batch=1, precision=None):
     from cuahn_vio_amd.homography_net import HnetEngine
     return HnetEngine(blob, variant=str(g["variant"]), mc_samples=int(g["n_mc"]), dropout_p=float(g["p"]),
-                      mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0, max_batch=max_batch, emit_error_map=True)
+                      mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0, max_batch=max_batch, emit_error_map=True, precision=precision)
 
 
 # ---------------------------------------------------------------------------------------------- operators
@@ -174,10 +178,11 @@ def test_op_conv_small_ragged_shapes(eng_full, state):
 
 
 # ---------------------------------------------------------------------------------------------- full forward
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", golden_cases())
-def test_forward_golden(blob, oracle, name):
+def test_forward_golden(blob, oracle, name, precision):
     g, i1, i2, prior, btr = load_case(name)
-    eng = _engine_for(blob, g)
+    eng = _engine_for(blob, g, precision=precision)
     seq = int(g["pair_seq"]) if "pair_seq" in g else 0
     mean, cov, err = eng.infer_batch(i1[None], i2[None], None if prior is None else prior[None], pair_seq0=seq, want_err=True)
     o = oracle.forward(i1, i2, prior, btr, int(g["n_mc"]), float(g["p"]), int(g["mc_seed"]) if "mc_seed" in g else 0, seq,
