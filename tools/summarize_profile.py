@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 outputs of tools/profile_round.sh / tools/pmc_pass.sh (under gpurun_out/) into the small
+tracked summaries under profiles/:   tools/summarize_profile.py <tag> [<pmc pass dir for MFMA/LDS counters>]
+  profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats (verbatim)
+  profiles/<tag>_pmc_hbm_traffic.csv   FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes), full-batch launch = max over launches
+  profiles/<tag>_pmc_mfma_lds.csv      per kernel: MFMA busy share of SIMD cycles, LDS busy share of CU cycles, bank-conflict share
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern), recursive=True)
+    return f[0] if f else None
+
+
+st = one("stats/**/*kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(dst, tag + "_kernel_stats.csv"))
+
+
+def per_kernel_max(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (max(v), len(v)) for k, v in acc.items()}
+
+
+fe, wr = one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collection.csv")
+if fe and wr:
+    f, w = per_kernel_max(fe, "FETCH_SIZE"), per_kernel_max(wr, "WRITE_SIZE")
+    with open(os.path.join(dst, tag + "_pmc_hbm_traffic.csv"), "w") as out:
+        out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) of `python3 bench.py --steps 2 --warmup 1`, batch 256, bf16x3 path.\n")
+        out.write("# Values are per launch at batch 256 (max over launches: the batch-1 warm-up launch of hnet_create is excluded). Raw counter values in KiB;\n")
+        out.write("# FETCH_SIZE under-counts wide (16 B/lane) coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM) - not corrected here.\n")
+        cw = csv.writer(out)
+        cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_full_batch_launch", "WRITE_SIZE_KiB_full_batch_launch"])
+        for k in sorted(f):
+            cw.writerow([k, f[k][1], f[k][0], w.get(k, (0, 0))[0]])
+
+if len(sys.argv) > 2:
+    pm = glob.glob(os.path.join(ROOT, "gpurun_out", sys.argv[2], "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(pm)):
+        acc[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    best = {}
+    for (k, g), cs in acc.items():          # keep the largest grid of each kernel (the batch-256 launches)
+        if k not in best or g > best[k][0]:
+            best[k] = (g, {n: sum(v) / len(v) for n, v in cs.items()}, len(next(iter(cs.values()))))
+    with open(os.path.join(dst, tag + "_pmc_mfma_lds.csv"), "w") as out:
+        out.write("# rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE (tools/pmc_pass.sh), batch 256, averages over the full-batch launches.\n")
+        out.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); lds_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES; conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n")
+        cw = csv.writer(out)
+        cw.writerow(["kernel", "grid_threads", "launches", "mfma_busy", "lds_busy", "lds_conflict_share", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"])
+        for k, (g, c, n) in sorted(best.items(), key=lambda kv: -kv[1][1].get("SQ_BUSY_CU_CYCLES", 0)):
+            busy = c.get("SQ_BUSY_CU_CYCLES", 0)
+            if busy <= 0 or "rocclr" in k:
+                continue
+            lds = c.get("SQ_LDS_IDX_ACTIVE", 0)
+            cw.writerow([k, g, n, round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * busy), 4), round(lds / busy, 4),
+                         round(c.get("SQ_LDS_BANK_CONFLICT", 0) / lds, 4) if lds else 0, int(busy), int(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))])
+print("profiles/ updated for", tag)
