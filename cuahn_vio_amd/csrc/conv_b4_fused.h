@@ -63,9 +63,14 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
     for (int st = 0; st < 7; st++)
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) w1[st][pl] = w1frag[(st * 3 + pl) * 64 + lane];
-    const float bv = bias0[lane & 7];
-    const float bv1 = bias1[m];
-    const int dx = m >> 3, co = m & 7;
+    // The MFMAs are issued with the operands swapped (weights as A, pixels as B), i.e. they produce the TRANSPOSED tile:
+    // D row 4g + r = output channel, D column m = pixel.  A lane then holds four consecutive channels of ONE pixel and
+    // stores them with one 8-byte LDS write per plane; with pixels along the rows every value needed its own 2-byte
+    // store and the four lane groups hit the same banks (19 % of this kernel's LDS cycles were conflicts).
+    const int dx = g >> 1, co0 = 4 * (g & 1);            // phase 1: D row 4g + r = (dx, co0 + r)
+    float bv[4], bv1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { bv[r] = bias0[co0 + r]; bv1[r] = bias1[4 * g + r]; }
     // phase-1 A offsets of this lane group: step st covers kernel rows 2st, 2st+1; group g -> row 2st + (g>>1), taps 4(g&1)..
     int aoff[4];
 #pragma unroll
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
         const int kh = t / 5, kw = t - kh * 5;
         tapoff[st] = t < 25 ? ((kh * 2 + (kw & 1)) * XH + (kw >> 1)) * 8 : 0;
     }
-    // phase-1 store position of this lane inside a regular M-tile: column 8g + 2r + dx of a 32-column half
-    const int e_lane = (dx * XH + 4 * g) * 8 + co;
+    // phase-1 store position of this lane inside a regular M-tile: pixel column 2m + dx of a 32-column half, channels co0..co0+3
+    const int e_lane = (dx * XH + m) * 8 + co0;
 
     // patch pixels of the NEXT tile are prefetched into registers while the current tile computes (the workgroup is
     // alone on its CU, so an un-overlapped global load would be fully exposed every tile)
@@ -156,45 +161,37 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, w0[st][0]);
                 const bf16x8 b1 = __builtin_bit_cast(bf16x8, w0[st][1]);
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, w0[st][2]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[0], acc, 0, 0, 0);
             }
-            // D: col n = (dx, co); row 4g + r = pixel pair within the M-tile.  Outside the image = block_4_1's zero padding.
+            // D (transposed): row 4g + r = (dx, co0 + r), column m = pixel pair of the M-tile.  Outside the image = block_4_1's zero padding.
+            auto put = [&](int e, bool ok) {
+                uint16_t sa[4], sb[4], sc[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[r] + bv[r];
+                    v = v > 0.f ? v : v * 0.1f;
+                    split3(ok ? v : 0.f, sa[r], sb[r], sc[r]);
+                }
+                *reinterpret_cast<uint2*>(&img[e]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                *reinterpret_cast<uint2*>(&img[PLANE + e]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                *reinterpret_cast<uint2*>(&img[2 * PLANE + e]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+            };
             if (dbg & 1) { if (acc[0] == 12345.f) img[0] = 1; }
             else if (regular) {
                 const int rrow = mt >> 1, half = mt & 1;
-                const bool row_in = (unsigned)(Ry0 + rrow) < (unsigned)H0;
-                const int ebase = e_lane + (rrow * 2 * XH + half * 16) * 8;
-                const int ix0 = Rx0 + half * 32 + 8 * g + dx;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = acc[r] + bv;
-                    v = v > 0.f ? v : v * 0.1f;
-                    if (!row_in || (unsigned)(ix0 + 2 * r) >= (unsigned)W0) v = 0.f;
-                    uint16_t sa, sb, sc;
-                    split3(v, sa, sb, sc);
-                    const int e = ebase + r * 8;
-                    img[e] = sa; img[PLANE + e] = sb; img[2 * PLANE + e] = sc;
-                }
+                const int ix = Rx0 + half * 32 + 2 * m + dx;
+                put(e_lane + (rrow * 2 * XH + half * 16) * 8, (unsigned)(Ry0 + rrow) < (unsigned)H0 && (unsigned)ix < (unsigned)W0);
             } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int idx = (mt - 2 * RH) * 16 + 4 * g + r;
-                    const int rrow = idx >> 1, rcol = 2 * (32 + (idx & 1)) + dx;
-                    if (rrow < RH && rcol < RW) {
-                        const int iy = Ry0 + rrow, ix = Rx0 + rcol;
-                        float v = acc[r] + bv;
-                        v = v > 0.f ? v : v * 0.1f;
-                        if (iy < 0 || iy >= H0 || ix < 0 || ix >= W0) v = 0.f;
-                        uint16_t sa, sb, sc;
-                        split3(v, sa, sb, sc);
-                        const int e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co;
-                        img[e] = sa; img[PLANE + e] = sb; img[2 * PLANE + e] = sc;
-                    }
+                const int idx = (mt - 2 * RH) * 16 + m;
+                const int rrow = idx >> 1, rcol = 2 * (32 + (idx & 1)) + dx;
+                if (rrow < RH && rcol < RW) {
+                    const int iy = Ry0 + rrow, ix = Rx0 + rcol;
+                    put(((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0, iy >= 0 && iy < H0 && ix >= 0 && ix < W0);
                 }
             }
         }
@@ -218,24 +215,25 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, w1[st][0]);
                 const bf16x8 b1 = __builtin_bit_cast(bf16x8, w1[st][1]);
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, w1[st][2]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[0], acc, 0, 0, 0);
             }
-            // D: col n = lane&15 = cout; row 4g + r = output pixel ox' = half*16 + 4g + r
+            // D (transposed): row 4g + r = cout, column m = output pixel ox' = half*16 + m: 8 bytes (4 channels) per lane and plane
+            {
+                uint16_t sa[4], sb[4], sc[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = acc[r] + bv1;
-                v = v > 0.f ? v : v * 0.1f;
-                uint16_t sa, sb, sc;
-                split3(v, sa, sb, sc);
-                const int px = 4 * g + r;
-                st_lds[(0 * 16 + px) * 16 + m] = sa;
-                st_lds[(1 * 16 + px) * 16 + m] = sb;
-                st_lds[(2 * 16 + px) * 16 + m] = sc;
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[r] + bv1[r];
+                    v = v > 0.f ? v : v * 0.1f;
+                    split3(v, sa[r], sb[r], sc[r]);
+                }
+                *reinterpret_cast<uint2*>(&st_lds[(0 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                *reinterpret_cast<uint2*>(&st_lds[(1 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                *reinterpret_cast<uint2*>(&st_lds[(2 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const size_t orow = ((size_t)b * H1 + ty0 + oy) * W1 + tx0 + half * 16;

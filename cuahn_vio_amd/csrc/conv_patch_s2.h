@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
     for (int st = 0; st < NSTEP; st++)
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) wv[st][pl] = wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane];
-    const float bv = bias[nt * 16 + m];
+    // operands swapped (weights as A): the MFMA yields the transposed tile, D row 4g + r = cout, column m = output pixel,
+    // so that a lane stores four consecutive channels of one pixel with one 8-byte LDS write per plane (conv_b4_fused.h)
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
     int tapoff[NSTEP];
 #pragma unroll
     for (int st = 0; st < NSTEP; st++) {
@@ -141,24 +145,25 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, wv[st][0]);
                 const bf16x8 b1 = __builtin_bit_cast(bf16x8, wv[st][1]);
                 const bf16x8 b2 = __builtin_bit_cast(bf16x8, wv[st][2]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[0], acc, 0, 0, 0);
             }
-            // D: col n = lane&15 = cout within the half; row 4g + r = output column
+            // D (transposed): row 4g + r = cout within the half, column m = output column
+            {
+                uint16_t sa[4], sb[4], sc[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = acc[r] + bv;
-                v = v > 0.f ? v : v * 0.1f;
-                uint16_t sa, sb, sc;
-                split3(v, sa, sb, sc);
-                const int px = 4 * g + r;
-                st_lds[(0 * 16 + px) * 16 + m] = sa;
-                st_lds[(1 * 16 + px) * 16 + m] = sb;
-                st_lds[(2 * 16 + px) * 16 + m] = sc;
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[r] + bv[r];
+                    v = v > 0.f ? v : v * 0.1f;
+                    split3(v, sa[r], sb[r], sc[r]);
+                }
+                *reinterpret_cast<uint2*>(&st_lds[(0 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                *reinterpret_cast<uint2*>(&st_lds[(1 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                *reinterpret_cast<uint2*>(&st_lds[(2 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const int Y = ty0 + oy;

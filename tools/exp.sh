@@ -1,4 +1,3 @@
-bash tools/profile_round.sh r01_v5 > /dev/null 2>&1
-tools/pmc_pass.sh v5_mfma SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE > gpurun_out/pmc_v5_mfma.txt 2>&1
-python bench.py > gpurun_out/bench_v5.json 2>gpurun_out/bench_v5.err
-tail -c 1500 gpurun_out/bench_v5.json
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+python bench.py --no-cpu-baseline --no-latency --steps 20 > gpurun_out/bench_s3.json 2>/dev/null; python -c "
+import json; r=json.load(open('gpurun_out/bench_s3.json')); s=r['forward']['stage_ms']; print(r['value'], r['ms_per_step'], s['block_4_0+4_1'], s['block_3_1'], s['block_4_2'])"
