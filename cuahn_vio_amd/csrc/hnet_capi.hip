@@ -82,6 +82,8 @@ struct hnet_ctx {
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
+    uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
+    bool b30_s3 = true;
     uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
@@ -294,7 +296,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             const size_t cnt = c->act_count[l];
             float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
-            if (c->use_patch && conv_is_patch_layer(l))
+            if (c->s3 && l == 7 && c->b30_s3 && c->b30_frag && o16)
+                STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s));
+            else if (c->use_patch && conv_is_patch_layer(l))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
@@ -472,6 +476,24 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                 }
             CK(hipMalloc((void**)&c->b40_frag, fr.size() * 2));
             CK(hipMemcpy(c->b40_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        }
+        if (c->s3 && l == 7) {      // block_3_0 for conv7_c2_s1_s3_kernel: lane (n = l&31 = (dx, co), hh = l>>5), kk = 8hh + j of kernel row kh
+            std::vector<uint16_t> fr((size_t)7 * 3 * 64 * 8, 0);
+            for (int kh = 0; kh < 7; kh++)
+                for (int ln = 0; ln < 64; ln++) {
+                    const int n = ln & 31, hh = ln >> 5, dx = n >> 4, co = n & 15;
+                    for (int j = 0; j < 8; j++) {
+                        const int kk = 8 * hh + j, kw = (kk >> 1) - dx, ci = kk & 1;
+                        if (kw < 0 || kw >= 7) continue;
+                        uint16_t sp[3];
+                        split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                        for (int pl = 0; pl < 3; pl++) fr[(((size_t)kh * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
+                    }
+                }
+            CK(hipMalloc((void**)&c->b30_frag, fr.size() * 2));
+            CK(hipMemcpy(c->b30_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            const char* e30 = getenv("HNET_B30_S3");
+            c->b30_s3 = !(e30 && atoi(e30) == 0);
         }
         if (c->s3 && conv_is_patch_layer(l)) {   // 16 -> 32, KSxKS: step st = taps 2st, 2st+1; lane group g -> tap 2st + (g>>1), ci 8(g&1)+j
             const int ks = d.ks, nstep = (ks * ks + 1) / 2;
@@ -674,7 +696,7 @@ void hnet_destroy(hnet_ctx* c) {
     if (c->g_batch) (void)hipGraphExecDestroy(c->g_batch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     fr(c->d_seq);
-    fr(c->zero_page); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -990,7 +1012,10 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
                                      c->conv_b[layer], p_out, n_out, nullptr, c->stream));
         } else {
             HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
-            HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
+            if (layer == 7 && c->b30_s3 && c->b30_frag)     // the kernel the forward uses for block_3_0
+                HIPCHK(c, launch_conv_first_s3(d_b, c->b30_frag, c->conv_b[layer], p_out, n_out, batch, h, w, c->stream));
+            else
+                HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
         }
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -218,6 +218,15 @@ hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const floa
     return hipGetLastError();
 }
 
+// block_3_0 on the split-bf16 path (conv_first.h): x_in fp32 [B][h][w][2] -> out16 S3 planes [3][B][h][w][16]
+hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
+                                int h, int w, hipStream_t s) {
+    const int tx = (w + 31) / 32, ty = (h + 15) / 16;
+    hipLaunchKernelGGL(conv7_c2_s1_s3_kernel, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, x_in, (const u32x4*)wfrag, bias, out16,
+                       o_plane, h, w, tx, ty);
+    return hipGetLastError();
+}
+
 // block_3_1 (5x5) / block_4_2 (3x3): 16 -> 32 channels, stride 2, from an LDS-resident patch (conv_patch_s2.h)
 bool conv_is_patch_layer(int layer) { return layer == 8 || layer == 15; }   // block_3_1 (5x5), block_4_2 (3x3)
 
