@@ -213,8 +213,9 @@ hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const floa
     }
     const int n_tiles = batch * (112 / b4f::TH1) * (160 / b4f::TW1);
     const unsigned blocks = (unsigned)std::min(n_tiles, 256);      // persistent: one 512-thread workgroup per CU (85 KB of LDS)
+    static const int dbg = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;   // profiling ablations (wrong results)
     hipLaunchKernelGGL(block4_fused_kernel, dim3(blocks), dim3(b4f::THREADS), b4f::LDS_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
-                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, /*ablate=*/0);
+                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, dbg);
     return hipGetLastError();
 }
 
