@@ -91,9 +91,10 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
     constexpr int PPT = (PH0 * PW0 + THREADS - 1) / THREADS;     // patch pixels per thread (4)
     float2 pre[PPT];
     uint32_t pre_ok = 0;            // validity bits; applied when the registers are consumed, so the loads stay in flight
+    const bool reverse = (dbg & 8) != 0;     // walk the tiles from the end of the batch (Infinity-Cache friendly ordering experiments)
     auto patch_load = [&](int t) {
         pre_ok = 0;
-        int bid = t;
+        int bid = reverse ? n_tiles - 1 - t : t;
         const int bx = bid % (W1 / TW1); bid /= (W1 / TW1);
         const int by = bid % (H1 / TH1);
         const int b = bid / (H1 / TH1);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restri
     if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int bid = tile;
+        int bid = reverse ? n_tiles - 1 - tile : tile;
         const int bx = bid % (W1 / TW1); bid /= (W1 / TW1);
         const int by = bid % (H1 / TH1);
         const int b = bid / (H1 / TH1);

@@ -33,7 +33,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
                                                             const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             uint16_t* __restrict__ out16, size_t o_plane, int H, int W,
-                                                            int n_tiles) {
+                                                            int n_tiles, int reverse) {
     typedef PatchS2Cfg<KS> C;
     constexpr int TH = C::TH, TW = C::TW, RH = C::RH, RW = C::RW, XH = C::XH, PLANE = C::PLANE, NSTEP = C::NSTEP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
     }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int bid = tile;
+        // reverse: walk the tiles from the end of the batch.  The producer wrote this 440 MB input front to back and the
+        // 256 MB Infinity Cache is LRU: what it still holds is the END of the tensor, which the forward order would evict
+        // before reaching it
+        int bid = reverse ? n_tiles - 1 - tile : tile;
         const int bx = bid % tiles_x; bid /= tiles_x;
         const int by = bid % tiles_y;
         const int b = bid / tiles_y;

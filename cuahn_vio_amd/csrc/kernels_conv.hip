@@ -244,8 +244,10 @@ static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfra
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
     const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent, 2 workgroups per CU
+    // bit 0: reverse the 5x5 kernel (block_3_1), bit 1: reverse the 3x3 kernel (block_4_2)
+    static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
     hipLaunchKernelGGL(conv_patch_s2_kernel<KS>, dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
-                       out16, o_plane, h, w, n_tiles);
+                       out16, o_plane, h, w, n_tiles, KS == 5 ? (rev & 1) : ((rev >> 1) & 1));
     return hipGetLastError();
 }
 
