@@ -45,6 +45,7 @@ struct S3Params {
     const uint8_t* mask;
     int n_local;
     const uint16_t* zeros; // >= 16 bytes of zeros in global memory: source of padding / out-of-range chunks for the LDS-DMA kernel
+    int xcd_remap;         // 1: XCD-aware workgroup -> tile mapping (s3_tile_origin)
 #ifdef HNET_S3_TRACE
     unsigned long long* trace;   // tools/trace_s3.hip only: [block < 8][wave][S3T_SLOTS] s_memtime stamps
 #endif
@@ -136,6 +137,22 @@ struct HeadLoaderS3 {
     __device__ static inline uint32_t mask_byte(const S3Params& p, const Row& r, int kp) { return p.mask[r.mrow + (kp >> 3)]; }
 };
 
+// Workgroup -> tile mapping.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
+// 4 MB L2.  With the plain mapping neighbouring M-tiles — which share most of their input rows (a 3x3 / 5x5 window re-reads
+// every value 2.25 / 6.25 times) — land in eight different L2s and each of them fetches its own copy (FETCH_SIZE was
+// 1.8-4.2x the input tensor).  Remapped, XCD k owns a contiguous range of the logical tile order (M-tile major, the N-tiles
+// of one M-tile adjacent), so those re-reads are L2 hits.
+__device__ __forceinline__ void s3_tile_origin(const S3Params& p, int BM, int BN, int& m0, int& n0) {
+    if (!p.xcd_remap) { m0 = blockIdx.x * BM; n0 = blockIdx.y * BN; return; }
+    const int nx = gridDim.x, ny = gridDim.y, total = nx * ny;
+    const int lin = blockIdx.x + blockIdx.y * nx;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int base = total >> 3, rem = total & 7;
+    const int L = xcd * base + min(xcd, rem) + idx;           // XCD k holds base + (k < rem) consecutive tiles
+    m0 = (L / ny) * BM;
+    n0 = (L % ny) * BN;
+}
+
 // chunk swizzle of an LDS tile row: 64-byte rows (4 chunks) pair four rows per 256-byte bank row, 128-byte rows (8 chunks) two
 template <int CH>
 __device__ __forceinline__ int s3_swz(int row, int chunk) {
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    s3_tile_origin(p, BM, BN, m0, n0);
     const int srow = tid / CH, schunk = tid % CH;     // staging: RPP rows x CH chunks per pass
 
     typename L::Row rows[A_ROWS];
@@ -374,7 +392,8 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    s3_tile_origin(p, BM, BN, m0, n0);
     const int lrow = lane >> 2, lphys = lane & 3;
 
     typename L::Row rows[A_INST];

@@ -51,6 +51,7 @@ static hipError_t run(IgemmParams p, hipStream_t s, float* ws, size_t ws_floats)
     p.k_split = split;
     p.partial = ws;
     grid.z = split;
+
     hipLaunchKernelGGL((igemm_kernel<L, BM, BN, WGM, MF>), grid, dim3(256), 0, s, p);
     if (split > 1) {
         const size_t total4 = (size_t)p.M * p.N / 4;
@@ -153,6 +154,9 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     p.k_split = split;
     p.partial = ws;
     grid.z = split;
+    // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel LDS-DMA layers -> wide taps only
+    static const int xcd = std::getenv("HNET_XCD_REMAP") ? std::atoi(std::getenv("HNET_XCD_REMAP")) : -1;
+    p.xcd_remap = xcd >= 0 ? xcd : (L::WIDE_TAPS ? 1 : 0);
     // LDS-DMA ring (3 stages) by default: 2-8 % faster than register staging on the 64x64 tiles (HNET_S3_DMA=0 disables)
     static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : 3;
     if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
