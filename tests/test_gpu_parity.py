@@ -383,3 +383,35 @@ def test_properties_at_full_batch(blob):
         assert np.allclose(cov[b], cov[b].T, atol=1e-7)
         assert np.linalg.eigvalsh(cov[b].astype(np.float64)).min() > -1e-7
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- wider parity cases
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("variant,n_mc,p,batch,prior_px", [
+    ("full", 1, 0.05, 3, 0.0),          # a single MC sample: the ensemble variance is only the aleatoric term
+    ("full", 4, 0.5, 2, 0.0),           # heavy dropout: half of the 5120 features masked
+    ("full", 64, 0.05, 2, 0.0),         # more samples than the reference's 16 / the benchmark's 32
+    ("prior3", 16, 0.05, 37, 30.0),     # ragged batch (not a multiple of any tile) and a prior of +-30 px per corner
+    ("prior2", 16, 0.0, 7, 15.0),
+    ("prior1", 16, 0.05, 5, 8.0),
+])
+def test_parity_edge_configurations(blob, oracle, variant, n_mc, p, batch, prior_px, precision):
+    """configurations the golden vectors do not hold (the reference model needs minutes per case on the CPU; the oracle
+    is pinned against it by tests/test_oracle_golden.py): HIP path vs oracle, every pair of the batch"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, prior, _ = synth.make_batch(700, min(batch, 6))
+    reps = (batch + prev.shape[0] - 1) // prev.shape[0]
+    prev, curr = np.tile(prev, (reps, 1, 1))[:batch], np.tile(curr, (reps, 1, 1))[:batch]
+    rng = np.random.default_rng(batch)
+    prior = (rng.uniform(-1, 1, (batch, 8)) * prior_px).astype(np.float32) if variant != "full" else None
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    eng = HnetEngine(blob, variant=variant, mc_samples=n_mc, dropout_p=p, mc_seed=MC_SEED, max_batch=batch, precision=precision)
+    mean, cov = eng.infer_batch(prev, curr, prior, pair_seq0=900)
+    eng.close()
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    check = range(batch) if batch <= 8 else [0, 1, batch // 2, batch - 2, batch - 1]
+    for b in check:
+        o = oracle.forward(prev[b], curr[b], None if prior is None else prior[b], btr, n_mc, p, MC_SEED, 900 + b)
+        assert np.abs(mean[b] - o["mean"]).max() < TOL_PX_VS_ORACLE, (b, float(np.abs(mean[b] - o["mean"]).max()))
+        assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL
