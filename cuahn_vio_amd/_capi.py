@@ -23,6 +23,7 @@ SYMBOLS = [
     "hnet_synchronize", "hnet_last_timing", "hnet_time_batch_device", "hnet_stage_count", "hnet_stage_name",
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
+    "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
 ]
 
 
@@ -31,6 +32,11 @@ class Config(C.Structure):
                 ("blocks_to_run", C.c_int32), ("mc_samples", C.c_int32), ("dropout_p", C.c_float),
                 ("mc_seed", C.c_uint64), ("emit_error_map", C.c_int32), ("precision", C.c_int32),
                 ("max_batch", C.c_int32), ("mc_sample_begin", C.c_int32), ("mc_sample_end", C.c_int32)]
+
+
+class Camera(C.Structure):
+    """hnet_camera: fisheye flag, raw size, (fx, fy, cx, cy), distortion (k1..k4 or k1, k2, p1, p2)"""
+    _fields_ = [("fisheye", C.c_int32), ("raw_rows", C.c_int32), ("raw_cols", C.c_int32), ("k", C.c_double * 4), ("d", C.c_double * 4)]
 
 
 class Timing(C.Structure):
@@ -69,6 +75,11 @@ def lib():
     L.hnet_last_error.restype = C.c_char_p
     L.hnet_version.restype = C.c_char_p
     L.hnet_push_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.hnet_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.hnet_set_undistort_maps.argtypes = [vp, fp, fp, C.c_int, C.c_int]
+    L.hnet_get_undistort_maps.argtypes = [vp, fp, fp]
+    L.hnet_push_raw_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.hnet_op_undistort.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.hnet_image_count.argtypes = [vp]
     L.hnet_latest_time.argtypes = [vp]
     L.hnet_latest_time.restype = C.c_double

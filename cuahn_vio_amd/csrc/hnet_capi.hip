@@ -100,6 +100,9 @@ struct hnet_ctx {
     uint8_t* d_err_u8 = nullptr;
     void *stage_prev = nullptr, *stage_curr = nullptr;    // batch staging for host-buffer entry points (f32 sized)
     uint8_t* ring[2] = {};                                 // streaming prev / curr
+    float* und_map[2] = {};                                // undistortion maps (x, y), 224x320 floats each (hnet_set_camera)
+    uint8_t* raw_dev = nullptr;                            // staging of one raw frame
+    int raw_rows = 0, raw_cols = 0;
     int curr_slot = 0;
     int img_counter = 0;
     double latest_t = -1.0;
@@ -696,6 +699,7 @@ void hnet_destroy(hnet_ctx* c) {
     if (c->g_batch) (void)hipGraphExecDestroy(c->g_batch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     fr(c->d_seq);
+    fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
@@ -725,6 +729,91 @@ int hnet_push_image(hnet_ctx* c, const uint8_t* data, int rows, int cols, int ro
     c->curr_slot = slot;
     if (c->img_counter >= 2) c->latest_t = t;                       // :148
     return HNET_OK;
+}
+
+// ---- image pre-processing: CamBase.h:165-186
+int hnet_set_undistort_maps(hnet_ctx* c, const float* map_x, const float* map_y, int raw_rows, int raw_cols) {
+    if (!c || !map_x || !map_y || raw_rows < 1 || raw_cols < 1 || raw_rows > 16384 || raw_cols > 16384) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    for (int i = 0; i < 2; i++)
+        if (!c->und_map[i]) HIPCHK(c, dalloc(&c->und_map[i], (size_t)NPIX));
+    HIPCHK(c, hipMemcpy(c->und_map[0], map_x, NPIX * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->und_map[1], map_y, NPIX * 4, hipMemcpyHostToDevice));
+    if (c->raw_dev && (size_t)raw_rows * raw_cols > (size_t)c->raw_rows * c->raw_cols) { (void)hipFree(c->raw_dev); c->raw_dev = nullptr; }
+    if (!c->raw_dev) HIPCHK(c, hipMalloc((void**)&c->raw_dev, (size_t)raw_rows * raw_cols));
+    c->raw_rows = raw_rows;
+    c->raw_cols = raw_cols;
+    return HNET_OK;
+}
+
+int hnet_set_camera(hnet_ctx* c, const hnet_camera* cam) {
+    if (!c || !cam) return HNET_ERR_INVALID_ARG;
+    // the virtual camera every frame is resampled to: 90 deg horizontal field of view on 320 px (CamBase.h:166-169)
+    const double f = (IMG_W - 1.0) / 2.0 / std::tan(45.0 / 180.0 * (2.0 * std::acos(0.0)));
+    const double cx = (IMG_W - 1.0) / 2.0, cy = (IMG_H - 1.0) / 2.0;
+    std::vector<float> mx(NPIX), my(NPIX);
+    for (int v = 0; v < IMG_H; v++)
+        for (int u = 0; u < IMG_W; u++) {
+            const double x = (u - cx) / f, y = (v - cy) / f;          // R = I: the pixel's ray in the virtual camera
+            double xd, yd;
+            if (cam->fisheye) {                                      // cv::fisheye::initUndistortRectifyMap (equidistant)
+                const double r = std::sqrt(x * x + y * y), th = std::atan(r), t2 = th * th;
+                const double thd = th * (1.0 + t2 * (cam->d[0] + t2 * (cam->d[1] + t2 * (cam->d[2] + t2 * cam->d[3]))));
+                const double sc = r == 0.0 ? 1.0 : thd / r;
+                xd = x * sc; yd = y * sc;
+            } else {                                                 // cv::initUndistortRectifyMap, D = (k1, k2, p1, p2)
+                const double r2 = x * x + y * y, kr = 1.0 + r2 * (cam->d[0] + r2 * cam->d[1]);
+                xd = x * kr + 2.0 * cam->d[2] * x * y + cam->d[3] * (r2 + 2.0 * x * x);
+                yd = y * kr + cam->d[2] * (r2 + 2.0 * y * y) + 2.0 * cam->d[3] * x * y;
+            }
+            mx[v * IMG_W + u] = (float)(cam->k[0] * xd + cam->k[2]);
+            my[v * IMG_W + u] = (float)(cam->k[1] * yd + cam->k[3]);
+        }
+    return hnet_set_undistort_maps(c, mx.data(), my.data(), cam->raw_rows, cam->raw_cols);
+}
+
+int hnet_get_undistort_maps(hnet_ctx* c, float* map_x, float* map_y) {
+    if (!c || !map_x || !map_y) return HNET_ERR_INVALID_ARG;
+    if (!c->und_map[0]) return fail(c, HNET_ERR_NOT_READY, "no camera set");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemcpy(map_x, c->und_map[0], NPIX * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(map_y, c->und_map[1], NPIX * 4, hipMemcpyDeviceToHost));
+    return HNET_OK;
+}
+
+static int remap_raw(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int row_stride, uint8_t* d_out) {
+    if (!c->und_map[0]) return fail(c, HNET_ERR_NOT_READY, "hnet_set_camera / hnet_set_undistort_maps first");
+    if (rows != c->raw_rows || cols != c->raw_cols || row_stride < cols) return fail(c, HNET_ERR_INVALID_ARG, "raw image size differs from the camera's");
+    HIPCHK(c, hipMemcpy2DAsync(c->raw_dev, cols, raw, row_stride, cols, rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_undistort(c->raw_dev, rows, cols, cols, c->und_map[0], c->und_map[1], d_out, c->stream));
+    return HNET_OK;
+}
+
+int hnet_push_raw_image(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int row_stride, double t) {
+    if (!c || !raw) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int slot = c->img_counter == 0 ? 0 : (c->curr_slot ^ 1);
+    const int rc = remap_raw(c, raw, rows, cols, row_stride, c->ring[slot]);
+    if (rc != HNET_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                     // `raw` is not retained
+    c->img_counter++;
+    c->curr_slot = slot;
+    if (c->img_counter >= 2) c->latest_t = t;
+    return HNET_OK;
+}
+
+int hnet_op_undistort(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int row_stride, uint8_t* out) {
+    if (!c || !raw || !out) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    uint8_t* d_o = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_o, NPIX));
+    const int rc = remap_raw(c, raw, rows, cols, row_stride, d_o);
+    if (rc == HNET_OK) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(out, d_o, NPIX, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_o);
+    return rc;
 }
 
 int hnet_image_count(const hnet_ctx* c) { return c ? c->img_counter : 0; }

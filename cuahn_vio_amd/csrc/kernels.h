@@ -53,6 +53,8 @@ hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const fl
                        int batch, hipStream_t s);
 
 // |warp(img2,H) - img1| * 255 -> float [B][224][320]  (and optional u8 clamp copy)
+hipError_t launch_undistort(const uint8_t* raw, int rows, int cols, int stride, const float* map_x, const float* map_y, uint8_t* out,
+                            hipStream_t s);
 hipError_t launch_errmap(const void* img1, const void* img2, int pix_fmt, const float* H, float* out,
                          uint8_t* out_u8, int batch, hipStream_t s);
 

@@ -400,6 +400,34 @@ hipError_t launch_errmap(const void* img1, const void* img2, int pix_fmt, const 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// undistort + resize (CamBase::undistort_and_resize_img = cv::remap(INTER_LINEAR, BORDER_CONSTANT 0), CamBase.h:182-186):
+// out(v, u) = bilinear(raw, map_x(v, u), map_y(v, u)).  Sample positions are quantised to 1/32 px as cv::remap does
+// (INTER_BITS = 5, round half to even), the blend is exact integer arithmetic: weights (32-ax)(32-ay) ... sum 1024,
+// result (sum + 512) >> 10.  71 680 output pixels per frame: a latency-bound gather, one pixel per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void undistort_kernel(const uint8_t* __restrict__ raw, int rows, int cols, int stride,
+                                                        const float* __restrict__ map_x, const float* __restrict__ map_y,
+                                                        uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NPIX) return;
+    const float fx = map_x[i] * 32.0f, fy = map_y[i] * 32.0f;
+    // saturate like cv::saturate_cast<short> of the integer part does, and keep NaN / huge positions out of the image
+    const bool sane = fabsf(fx) < 1.0e9f && fabsf(fy) < 1.0e9f;
+    const int sx = sane ? __float2int_rn(fx) : -(1 << 20), sy = sane ? __float2int_rn(fy) : -(1 << 20);
+    const int x0 = sx >> 5, y0 = sy >> 5, ax = sx & 31, ay = sy & 31;
+    auto tap = [&](int y, int x) -> int { return ((unsigned)y < (unsigned)rows && (unsigned)x < (unsigned)cols) ? (int)raw[(size_t)y * stride + x] : 0; };
+    const int v = tap(y0, x0) * (32 - ax) * (32 - ay) + tap(y0, x0 + 1) * ax * (32 - ay) + tap(y0 + 1, x0) * (32 - ax) * ay +
+                  tap(y0 + 1, x0 + 1) * ax * ay;
+    out[i] = (uint8_t)((v + 512) >> 10);
+}
+
+hipError_t launch_undistort(const uint8_t* raw, int rows, int cols, int stride, const float* map_x, const float* map_y, uint8_t* out,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(undistort_kernel, dim3((NPIX + 255) / 256), dim3(256), 0, s, raw, rows, cols, stride, map_x, map_y, out);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void warp_f32_kernel(const float* __restrict__ img, const float* __restrict__ H,
                                                        float* __restrict__ out, int batch) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

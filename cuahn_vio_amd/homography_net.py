@@ -164,6 +164,36 @@ class HnetEngine:
         check(self._h, self._L.hnet_op_prep(self._h, _fp(i1), _fp(i2), _fp(hm) if hm is not None else None, k, _fp(out)))
         return out
 
+    # ---- image pre-processing (CamBase.h:165-186)
+    def set_camera(self, k, d, raw_rows, raw_cols, fisheye=True):
+        cam = _capi.Camera(int(bool(fisheye)), int(raw_rows), int(raw_cols), (C.c_double * 4)(*[float(x) for x in k]),
+                           (C.c_double * 4)(*[float(x) for x in d]))
+        check(self._h, self._L.hnet_set_camera(self._h, C.byref(cam)))
+
+    def set_undistort_maps(self, map_x, map_y, raw_rows, raw_cols):
+        mx = np.ascontiguousarray(map_x, dtype=np.float32).reshape(IMG_H, IMG_W)
+        my = np.ascontiguousarray(map_y, dtype=np.float32).reshape(IMG_H, IMG_W)
+        check(self._h, self._L.hnet_set_undistort_maps(self._h, _fp(mx), _fp(my), int(raw_rows), int(raw_cols)))
+
+    def get_undistort_maps(self):
+        mx, my = np.zeros((IMG_H, IMG_W), np.float32), np.zeros((IMG_H, IMG_W), np.float32)
+        check(self._h, self._L.hnet_get_undistort_maps(self._h, _fp(mx), _fp(my)))
+        return mx, my
+
+    def push_raw_image(self, raw, time_stamp):
+        raw = np.asarray(raw)
+        if raw.dtype != np.uint8 or raw.ndim != 2:
+            raise ValueError("expected a 2-D uint8 image")
+        if raw.strides[1] != 1:
+            raw = np.ascontiguousarray(raw)
+        check(self._h, self._L.hnet_push_raw_image(self._h, raw.ctypes.data, raw.shape[0], raw.shape[1], raw.strides[0], float(time_stamp)))
+
+    def op_undistort(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        out = np.zeros((IMG_H, IMG_W), np.uint8)
+        check(self._h, self._L.hnet_op_undistort(self._h, raw.ctypes.data, raw.shape[0], raw.shape[1], raw.strides[0], out.ctypes.data))
+        return out
+
     def op_prep_u8(self, img1, img2, h, k):
         i1 = np.ascontiguousarray(img1, dtype=np.uint8).reshape(IMG_H, IMG_W)
         i2 = np.ascontiguousarray(img2, dtype=np.uint8).reshape(IMG_H, IMG_W)

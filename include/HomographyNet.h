@@ -142,6 +142,22 @@ public:
 
     const std::vector<uint8_t>& last_error_map() const { return err_map_; }   // extension: the u8 map the reference only displays
 
+    // Extension (not in the reference class): undistortion + resize on the GPU instead of CamBase::undistort_and_resize_img
+    // on the CPU (CamBase.h:165-186, VioManager.cpp:184).  set_camera = initialize_undist_map[_fisheye]; load_raw_img takes the raw
+    // camera frame.  Parity with cv::remap is unpinned (hnet.h).
+    bool set_camera(bool fisheye, int raw_rows, int raw_cols, const double k[4], const double d[4]) {
+        hnet_camera cam;
+        cam.fisheye = fisheye ? 1 : 0; cam.raw_rows = raw_rows; cam.raw_cols = raw_cols;
+        for (int i = 0; i < 4; i++) { cam.k[i] = k[i]; cam.d[i] = d[i]; }
+        return hnet_set_camera(ctx_, &cam) == HNET_OK;
+    }
+    void load_raw_img(const cv::Mat& raw, const double& time_stamp) {
+        if (img_counter == 0) std::printf("First Image Comes into the Network Object!\n");
+        const int rc = hnet_push_raw_image(ctx_, raw.data, raw.rows, raw.cols, (int)raw.step, time_stamp);
+        if (rc != HNET_OK) { std::fprintf(stderr, "load_raw_img: %s (%s)\n", hnet_status_string(rc), hnet_last_error(ctx_)); return; }
+        img_counter = hnet_image_count(ctx_);
+    }
+
     int img_counter = 0;   // public in the reference (HomographyNet.h:33), read by VioManager.cpp:257,288
 
 private:

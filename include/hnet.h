@@ -92,6 +92,34 @@ const char* hnet_version(void);
  * image on. */
 int hnet_push_image(hnet_ctx* ctx, const uint8_t* data, int rows, int cols, int row_stride, double t);
 int hnet_image_count(const hnet_ctx* ctx);             /* the public `img_counter` (HomographyNet.h:33) */
+
+/* ---- image pre-processing ahead of load_current_img --------------------------------------------
+ * The reference undistorts and resizes the raw camera image on the CPU before handing it to the network:
+ * CamBase::initialize_undist_map / initialize_undist_map_fisheye build two 224x320 float maps with
+ * cv::initUndistortRectifyMap / cv::fisheye::initUndistortRectifyMap towards the virtual camera f = 159.5,
+ * c = (159.5, 111.5) (ov_core/src/cam/CamBase.h:165-180) and undistort_and_resize_img is cv::remap(INTER_LINEAR)
+ * (:182-186), called from VioManager.cpp:184.  Here the maps are built once on the host with the published
+ * formulas of those two OpenCV functions and the remap is a HIP kernel that writes straight into the context's image
+ * ring, so a raw frame goes host -> device once and never comes back.
+ * PARITY UNPINNED: OpenCV is neither in this image nor vendored by the reference and the reference holds no vectors
+ * for this step.  The kernel interpolates with sample positions quantised to 1/32 px like cv::remap (INTER_BITS = 5)
+ * in exact integer arithmetic; against cv::remap's coefficient table it may differ by one grey level. */
+typedef struct hnet_camera {
+    int32_t fisheye;           /* 1: equidistant model (cam0_is_fisheye, uzhfpv.launch:77), 0: radial-tangential */
+    int32_t raw_rows, raw_cols;/* size of the raw image (cam0_wh, uzhfpv.launch:75: 640 x 480) */
+    double  k[4];              /* fx, fy, cx, cy (cam0_k) */
+    double  d[4];              /* fisheye: k1..k4; radtan: k1, k2, p1, p2 (cam0_d) */
+} hnet_camera;
+/* builds and uploads the maps for `cam` (initialize_undist_map[_fisheye]) */
+int hnet_set_camera(hnet_ctx* ctx, const hnet_camera* cam);
+/* or supplies them directly (the reference's undist_map1 / undist_map2: 224x320 float each, x and y source coordinates) */
+int hnet_set_undistort_maps(hnet_ctx* ctx, const float* map_x, const float* map_y, int raw_rows, int raw_cols);
+/* copies the maps in use back (224x320 floats each) */
+int hnet_get_undistort_maps(hnet_ctx* ctx, float* map_x, float* map_y);
+/* undistort_and_resize_img + load_current_img: raw 8-bit image (row_stride in bytes) -> remap on the device -> image ring */
+int hnet_push_raw_image(hnet_ctx* ctx, const uint8_t* raw, int rows, int cols, int row_stride, double t);
+/* operator-level: the remapped 224x320 image back on the host (parity tests) */
+int hnet_op_undistort(hnet_ctx* ctx, const uint8_t* raw, int rows, int cols, int row_stride, uint8_t* out);
 double hnet_latest_time(const hnet_ctx* ctx);          /* get_latest_inference_time() (HomographyNet.h:31) */
 
 /* Replaces HomographyNet::network_inference (HomographyNet.cpp:153-252) on (prev, curr).
