@@ -1,6 +1,6 @@
 """large-batch run of the forward; saves mean/cov so that two builds / env settings can be compared (tools/exp.sh)"""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401  (before the HIP library, see tests/conftest.py)
 from cuahn_vio_amd import synth, weights
 from cuahn_vio_amd.homography_net import HnetEngine

@@ -1,5 +1,14 @@
-bash tools/profile_round.sh r01_v6 > /dev/null 2>&1
-tools/pmc_pass.sh v6_mfma SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE > gpurun_out/pmc_v6_mfma.txt 2>&1
-python bench.py > gpurun_out/bench_v6.json 2>gpurun_out/bench_v6.err
-python -c "
-import json; r=json.load(open('gpurun_out/bench_v6.json')); print(r['value'], r['ms_per_step'], r['roofline'], r['latency_batch1_ms']['p50'], r['cpu_baseline']['value'])"
+for b in 1 5; do
+HNET_FUSED_REDUCE=0 python tools/attic/pc_check.py gpurun_out/fr0.npz $b > /dev/null
+HNET_FUSED_REDUCE=1 python tools/attic/pc_check.py gpurun_out/fr1.npz $b > /dev/null
+python - <<PY
+import numpy as np
+a=np.load('gpurun_out/fr0.npz'); b=np.load('gpurun_out/fr1.npz')
+print("batch $b: bitwise mean", np.array_equal(a['mean'], b['mean']), "cov", np.array_equal(a['cov'], b['cov']), float(np.abs(a['mean']-b['mean']).max()))
+PY
+done
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+for f in 0 1; do HNET_FUSED_REDUCE=$f python bench.py --batch 1 --no-cpu-baseline --steps 50 2>/dev/null | python -c "
+import sys, json; r=json.loads(sys.stdin.read()); print('fused_reduce=$f', r['latency_batch1_ms']['p50'], r['latency_batch1_ms']['end_to_end_p50'])"; done
+python bench.py --no-cpu-baseline --no-latency 2>/dev/null | python -c "
+import sys, json; r=json.loads(sys.stdin.read()); print(r['value'], r['ms_per_step'])"
