@@ -165,7 +165,10 @@ __device__ __forceinline__ int s3_swz(int row, int chunk) {
 // less than the latency of its own prefetch, so the latency has to be hidden by more workgroups instead.
 // BKT = K-tile (32 or 64 K-values).  With 64 every staged row is a full 128-byte line per plane: the texture addresser
 // (GRBM_TA_BUSY ~ 90 % on the 32-wide tiles, profiles/r01) handles half as many lines per byte.
-template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1, int BKT = 32>
+// MF = MFMA shape: 32 -> v_mfma_f32_32x32x16_bf16; 16 -> v_mfma_f32_16x16x32_bf16 issued with the weights as A operand
+// (transposed tile: a lane holds four consecutive output channels of one GEMM row).  Same LDS traffic per flop; the
+// 16x16x32 form sustains a higher clock under the package power limit (MI355X_MICROARCH.md: 1.12-1.15x in MFMA-paced loops).
+template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1, int BKT = 32, int MF = 32>
 __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int BK = BKT;                           // K-values per tile = CH chunks of 8
     constexpr int CH = BK / 8, RPP = 256 / CH;        // chunks per row, rows staged per pass of the 256 threads
@@ -173,7 +176,9 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TM16 = WM / 16, TN16 = WN / 16;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
+    static_assert(MF == 32 || (MF == 16 && BK % 32 == 0), "MFMA shape");
     constexpr int A_ROWS = (BM + RPP - 1) / RPP, B_ROWS = (BN + RPP - 1) / RPP;   // rows staged per thread and plane
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
@@ -209,6 +214,13 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    typedef float f32x4_m16 __attribute__((ext_vector_type(4)));
+    f32x4_m16 acc16[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; i++)
+#pragma unroll
+        for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
 
     u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
     bool aok[A_ROWS], bok[B_ROWS];
@@ -280,6 +292,39 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         S3T();                                       // stamp 0: K-tile start
         if (it + 1 < n_iter) g_load(it0 + it + 1);
         S3T();                                       // 1: prefetch issued
+        if constexpr (MF == 16) {
+            const int r16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+            for (int step = 0; step < BK / 32; step++) {
+                bf16x8 af[TM16][3], bf[TN16][3];
+#pragma unroll
+                for (int i = 0; i < TM16; i++) {
+                    const int r = wm * WM + i * 16 + r16;
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN16; j++) {
+                    const int r = wn * WN + j * 16 + r16;
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM16; i++)
+#pragma unroll
+                    for (int j = 0; j < TN16; j++) {
+                        // weights as A operand: D' row 4g + r = output channel, column = GEMM row; smallest partial products first
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][2], acc16[i][j], 0, 0, 0);
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][2], af[i][0], acc16[i][j], 0, 0, 0);
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc16[i][j], 0, 0, 0);
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][1], acc16[i][j], 0, 0, 0);
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][0], acc16[i][j], 0, 0, 0);
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc16[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int step = 0; step < BK / 16; step++) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -328,6 +373,75 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         }
     }
 
+    if constexpr (MF == 16) {
+        // ---- epilogue of the transposed 16x16 tiles: lane (m = lane&15, g = lane>>4) holds channels n = 4g .. 4g+3 of GEMM row m
+        typedef float f32x4_e __attribute__((ext_vector_type(4)));
+        const int em = lane & 15, eg = lane >> 4;
+        if (p.k_split > 1 || OUT32) {
+            float* dst = p.k_split > 1 ? p.partial + (size_t)blockIdx.z * p.M * p.N : p.out32;
+#pragma unroll
+            for (int j = 0; j < TN16; j++) {
+                const int n = n0 + wn * WN + j * 16 + 4 * eg;
+                f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.k_split == 1 && n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
+#pragma unroll
+                for (int i = 0; i < TM16; i++) {
+                    const int m = m0 + wm * WM + i * 16 + em;
+                    if (m < p.M && n < p.N) {
+                        f32x4_e v = acc16[i][j];
+                        if (p.k_split == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
+                        }
+                        *reinterpret_cast<f32x4_e*>(dst + (size_t)m * p.N + n) = v;
+                    }
+                }
+            }
+        } else {
+            // S3 planes: per 32x32 super-tile of the wave, 8-byte pieces (4 channels of one row) into wave-private LDS
+            // [plane][32 rows][32 cols], 16-byte chunks XOR-swizzled with (row >> 1) & 3, then 16 bytes per lane to global
+            uint16_t* st = smem + wave * (3 * 32 * 32);
+#pragma unroll
+            for (int sj = 0; sj < TN16 / 2; sj++)
+#pragma unroll
+                for (int si = 0; si < TM16 / 2; si++) {
+#pragma unroll
+                    for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+                        for (int di = 0; di < 2; di++) {
+                            const int j = 2 * sj + dj, i = 2 * si + di;
+                            const int nloc = dj * 16 + 4 * eg, mloc = di * 16 + em;
+                            const int n = n0 + wn * WN + sj * 32 + nloc;
+                            f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
+                            if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
+                            uint16_t sa[4], sb[4], sc[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                float v = acc16[i][j][e] + bv[e];
+                                v = v > 0.0f ? v : v * 0.1f;
+                                split3(v, sa[e], sb[e], sc[e]);
+                            }
+                            const int chunk = (nloc >> 3) ^ ((mloc >> 1) & 3);
+                            const int e0 = mloc * 32 + chunk * 8 + (nloc & 7);
+                            *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                            *reinterpret_cast<uint2*>(&st[32 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                            *reinterpret_cast<uint2*>(&st[2 * 32 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+                        }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    const int mb = m0 + wm * WM + si * 32, nb = n0 + wn * WN + sj * 32;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const int piece = q * 64 + lane;             // 3 planes x 32 rows x 4 chunks of 16 B
+                        const int pl = piece >> 7, rem = piece & 127, row = rem >> 2, ch = rem & 3;
+                        const int m = mb + row, n = nb + ch * 8;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 32 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
+                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) = v;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                }
+        }
+        return;
+    }
     // ---- epilogue: bias + LeakyReLU(0.1); D layout: col n = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rbase = 4 * fh;
     if (p.k_split > 1) {   // raw partial sums; splitk_reduce*_kernel applies bias / activation / split

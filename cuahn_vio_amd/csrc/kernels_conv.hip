@@ -168,13 +168,17 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
             return hipGetLastError();
         }
     }
+    // MFMA shape 16x16x32 (transposed tiles) by default: -4..-9 % per layer against 32x32x16 at the same LDS traffic (HNET_S3_MF16=0: 32x32x16)
+    static const int mf16 = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 1;
     // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
     // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
     static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
     if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
+        if (bk64 && mf16) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
         if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
     }
     if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
+    else if (mf16) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
     if (split > 1) {
         if (OUT32) {

@@ -1,7 +1,3 @@
-(python bench.py --no-cpu-baseline --no-latency --steps 12000 > /tmp/b.json 2>/dev/null &) 
-sleep 18
-for i in 1 2 3 4 5; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk" | head -6; sleep 1; done
-wait
-sleep 8
-cat /tmp/b.json | python -c "
-import sys, json; r=json.loads(sys.stdin.read()); print(r['value'], r['ms_per_step'])"
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+for d in 0 1; do HNET_S3_MF16=$d python bench.py --no-cpu-baseline --no-latency --steps 20 > gpurun_out/bench_s3.json 2>/dev/null; python -c "
+import json; r=json.load(open('gpurun_out/bench_s3.json')); s=r['forward']['stage_ms']; print('mf16=$d', r['value'], r['ms_per_step'], {k:s[k] for k in ('block_1_2','block_1_3','block_3_2','block_4_2','block_2_2')})"; done
