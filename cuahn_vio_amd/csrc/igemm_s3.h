@@ -165,6 +165,79 @@ __device__ __forceinline__ int s3_swz(int row, int chunk) {
 // less than the latency of its own prefetch, so the latency has to be hidden by more workgroups instead.
 // BKT = K-tile (32 or 64 K-values).  With 64 every staged row is a full 128-byte line per plane: the texture addresser
 // (GRBM_TA_BUSY ~ 90 % on the 32-wide tiles, profiles/r01) handles half as many lines per byte.
+// epilogue of the transposed 16x16x32 tiles (shared by the register-staged and the LDS-DMA kernel): lane (m = lane&15,
+// g = lane>>4) holds channels 4g .. 4g+3 of GEMM row m of every 16x16 tile; (mw, nw) = origin of the wave's tile
+typedef float f32x4_m16 __attribute__((ext_vector_type(4)));
+template <int TM16, int TN16, bool OUT32>
+__device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], const S3Params& p, uint16_t* st_wave, int mw, int nw, int lane) {
+    // ---- epilogue of the transposed 16x16 tiles: lane (m = lane&15, g = lane>>4) holds channels n = 4g .. 4g+3 of GEMM row m
+    typedef float f32x4_e __attribute__((ext_vector_type(4)));
+    const int em = lane & 15, eg = lane >> 4;
+    if (p.k_split > 1 || OUT32) {
+        float* dst = p.k_split > 1 ? p.partial + (size_t)blockIdx.z * p.M * p.N : p.out32;
+#pragma unroll
+        for (int j = 0; j < TN16; j++) {
+            const int n = nw + j * 16 + 4 * eg;
+            f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.k_split == 1 && n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM16; i++) {
+                const int m = mw + i * 16 + em;
+                if (m < p.M && n < p.N) {
+                    f32x4_e v = acc16[i][j];
+                    if (p.k_split == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
+                    }
+                    *reinterpret_cast<f32x4_e*>(dst + (size_t)m * p.N + n) = v;
+                }
+            }
+        }
+    } else {
+        // S3 planes: per 32x32 super-tile of the wave, 8-byte pieces (4 channels of one row) into wave-private LDS
+        // [plane][32 rows][32 cols], 16-byte chunks XOR-swizzled with (row >> 1) & 3, then 16 bytes per lane to global
+        uint16_t* st = st_wave;
+#pragma unroll
+        for (int sj = 0; sj < TN16 / 2; sj++)
+#pragma unroll
+            for (int si = 0; si < TM16 / 2; si++) {
+#pragma unroll
+                for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+                    for (int di = 0; di < 2; di++) {
+                        const int j = 2 * sj + dj, i = 2 * si + di;
+                        const int nloc = dj * 16 + 4 * eg, mloc = di * 16 + em;
+                        const int n = nw + sj * 32 + nloc;
+                        f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
+                        if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
+                        uint16_t sa[4], sb[4], sc[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float v = acc16[i][j][e] + bv[e];
+                            v = v > 0.0f ? v : v * 0.1f;
+                            split3(v, sa[e], sb[e], sc[e]);
+                        }
+                        const int chunk = (nloc >> 3) ^ ((mloc >> 1) & 3);
+                        const int e0 = mloc * 32 + chunk * 8 + (nloc & 7);
+                        *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                        *reinterpret_cast<uint2*>(&st[32 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                        *reinterpret_cast<uint2*>(&st[2 * 32 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const int mb = mw + si * 32, nb = nw + sj * 32;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const int piece = q * 64 + lane;             // 3 planes x 32 rows x 4 chunks of 16 B
+                    const int pl = piece >> 7, rem = piece & 127, row = rem >> 2, ch = rem & 3;
+                    const int m = mb + row, n = nb + ch * 8;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 32 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
+                    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+    }
+}
+
 // MF = MFMA shape: 32 -> v_mfma_f32_32x32x16_bf16; 16 -> v_mfma_f32_16x16x32_bf16 issued with the weights as A operand
 // (transposed tile: a lane holds four consecutive output channels of one GEMM row).  Same LDS traffic per flop; the
 // 16x16x32 form sustains a higher clock under the package power limit (MI355X_MICROARCH.md: 1.12-1.15x in MFMA-paced loops).
@@ -215,7 +288,6 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    typedef float f32x4_m16 __attribute__((ext_vector_type(4)));
     f32x4_m16 acc16[TM16][TN16];
 #pragma unroll
     for (int i = 0; i < TM16; i++)
@@ -374,72 +446,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     }
 
     if constexpr (MF == 16) {
-        // ---- epilogue of the transposed 16x16 tiles: lane (m = lane&15, g = lane>>4) holds channels n = 4g .. 4g+3 of GEMM row m
-        typedef float f32x4_e __attribute__((ext_vector_type(4)));
-        const int em = lane & 15, eg = lane >> 4;
-        if (p.k_split > 1 || OUT32) {
-            float* dst = p.k_split > 1 ? p.partial + (size_t)blockIdx.z * p.M * p.N : p.out32;
-#pragma unroll
-            for (int j = 0; j < TN16; j++) {
-                const int n = n0 + wn * WN + j * 16 + 4 * eg;
-                f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.k_split == 1 && n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
-#pragma unroll
-                for (int i = 0; i < TM16; i++) {
-                    const int m = m0 + wm * WM + i * 16 + em;
-                    if (m < p.M && n < p.N) {
-                        f32x4_e v = acc16[i][j];
-                        if (p.k_split == 1) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
-                        }
-                        *reinterpret_cast<f32x4_e*>(dst + (size_t)m * p.N + n) = v;
-                    }
-                }
-            }
-        } else {
-            // S3 planes: per 32x32 super-tile of the wave, 8-byte pieces (4 channels of one row) into wave-private LDS
-            // [plane][32 rows][32 cols], 16-byte chunks XOR-swizzled with (row >> 1) & 3, then 16 bytes per lane to global
-            uint16_t* st = smem + wave * (3 * 32 * 32);
-#pragma unroll
-            for (int sj = 0; sj < TN16 / 2; sj++)
-#pragma unroll
-                for (int si = 0; si < TM16 / 2; si++) {
-#pragma unroll
-                    for (int dj = 0; dj < 2; dj++)
-#pragma unroll
-                        for (int di = 0; di < 2; di++) {
-                            const int j = 2 * sj + dj, i = 2 * si + di;
-                            const int nloc = dj * 16 + 4 * eg, mloc = di * 16 + em;
-                            const int n = n0 + wn * WN + sj * 32 + nloc;
-                            f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
-                            if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
-                            uint16_t sa[4], sb[4], sc[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                float v = acc16[i][j][e] + bv[e];
-                                v = v > 0.0f ? v : v * 0.1f;
-                                split3(v, sa[e], sb[e], sc[e]);
-                            }
-                            const int chunk = (nloc >> 3) ^ ((mloc >> 1) & 3);
-                            const int e0 = mloc * 32 + chunk * 8 + (nloc & 7);
-                            *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
-                            *reinterpret_cast<uint2*>(&st[32 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
-                            *reinterpret_cast<uint2*>(&st[2 * 32 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
-                        }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    const int mb = m0 + wm * WM + si * 32, nb = n0 + wn * WN + sj * 32;
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        const int piece = q * 64 + lane;             // 3 planes x 32 rows x 4 chunks of 16 B
-                        const int pl = piece >> 7, rem = piece & 127, row = rem >> 2, ch = rem & 3;
-                        const int m = mb + row, n = nb + ch * 8;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 32 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
-                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) = v;
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                }
-        }
+        s3_epilogue_m16<TM16, TN16, OUT32>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
         return;
     }
     // ---- epilogue: bias + LeakyReLU(0.1); D layout: col n = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 // swizzle is applied on the SOURCE side (the lane fetches logical chunk phys ^ ((row>>2)&3)).  Padding taps and rows
 // beyond M/N read a zero page instead.  Conv loaders only (the heads apply a per-element mask while staging).
 // ---------------------------------------------------------------------------------------------
-template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE>
+template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE, int MF = 32>
 __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     constexpr int BK = IG_BK;
     constexpr int WGN = 4 / WGM;
@@ -535,6 +542,13 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
+    constexpr int TM16 = WM / 16, TN16 = WN / 16;
+    f32x4_m16 acc16[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; i++)
+#pragma unroll
+        for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+
     const int n_iter = (p.Kp + BK - 1) / BK;                 // no split-K in this variant
 
     auto issue = [&](int it, int stage) {
@@ -568,6 +582,34 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     auto compute = [&](int stage) {
         const uint16_t* As = smem + stage * STAGE;
         const uint16_t* Bs = As + 3 * TILE_A;
+        if constexpr (MF == 16) {                              // one k32 step of 16x16x32 MFMAs, weights as A operand (igemm_s3_kernel)
+            const int r16 = lane & 15, g16 = lane >> 4;
+            bf16x8 af[TM16][3], bf[TN16][3];
+#pragma unroll
+            for (int i = 0; i < TM16; i++) {
+                const int r = wm * WM + i * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, g16)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN16; j++) {
+                const int r = wn * WN + j * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM16; i++)
+#pragma unroll
+                for (int j = 0; j < TN16; j++) {
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][2], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][2], af[i][0], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][1], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][0], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc16[i][j], 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int step = 0; step < 2; step++) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -613,6 +655,10 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // all fragment reads done before the epilogue reuses the LDS
 
+    if constexpr (MF == 16) {
+        s3_epilogue_m16<TM16, TN16, OUT32>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+        return;
+    }
     const int col = lane & 31, rbase = 4 * fh;
     if constexpr (OUT32) {
 #pragma unroll

@@ -164,7 +164,10 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
             if constexpr (BM * BN <= 128 * 64) {
                 if (dma == 4) { hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
             }
-            hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3>), grid, dim3(256), 0, s, p);
+            // the 16x16x32 shape gains nothing on these short-K (288) 32-channel layers (0.110 vs 0.109 ms): 32x32x16 unless HNET_S3_MF16=2
+            static const int mf16d = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 0;
+            if (mf16d == 2) hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3>), grid, dim3(256), 0, s, p);
             return hipGetLastError();
         }
     }
