@@ -117,7 +117,8 @@ struct hnet_ctx {
     // hipGraph replay of small-batch forwards (29-45 dependent launches: at batch 1 the host launch cost dominates).
     // The sequence number of the MC-dropout masks lives in device memory (d_seq) and is refreshed by a memcpy node
     // from a pinned host word, so one captured graph serves every call.
-    bool use_graph = false;
+    bool use_graph = false;            // hnet_infer replays the forward as one hipGraph (default on; HNET_GRAPH=0: eager launches)
+    bool graph_timing = false;         // hnet_time_batch_device too (HNET_GRAPH=1 only: the bare device time is 3 % better eager)
     uint64_t* d_seq = nullptr;
     struct Pinned { uint64_t seq; float prior[8]; float mean[8]; float cov[64]; uint8_t err[HNET_IMG_ROWS * HNET_IMG_COLS]; };
     Pinned* pinned = nullptr;
@@ -597,7 +598,10 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     }
     // measured on MI355X: graph replay 0.302 ms vs eager 0.292 ms per batch-1 forward - the batch-1 latency is device side
     // (45 short dependent kernels), not host launch cost, so replay is opt-in (HNET_GRAPH=1)
-    c->use_graph = getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) != 0;
+    // streaming entry point: one graph launch instead of ~43 kernel launches per frame: end-to-end p50 0.380 -> 0.334 ms
+    // (device time of the forward 0.289 -> 0.300 ms)
+    c->use_graph = !(getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) == 0);
+    c->graph_timing = getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) == 1;
     CK(hipMalloc((void**)&c->d_seq, 8));
     CK(hipMemset(c->d_seq, 0, 8));
     CK(hipHostMalloc((void**)&c->pinned, sizeof(hnet_ctx::Pinned), hipHostMallocDefault));
@@ -974,7 +978,7 @@ int hnet_time_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, 
     // small batches: replay the forward as one hipGraph (what hnet_infer does); the mask sequence number is refreshed
     // from pinned memory once before the timed loop (every replay then uses the same masks - timing only)
     hipGraphExec_t gx = nullptr;
-    if (c->use_graph && batch <= 8) {
+    if (c->graph_timing && c->use_graph && batch <= 8) {
         hnet_ctx::GraphKey key = {d_prev, d_curr, d_prior, d_mean, d_cov, batch, pix_fmt};
         if (!(c->g_batch && key == c->g_key)) {
             if (c->g_batch) { (void)hipGraphExecDestroy(c->g_batch); c->g_batch = nullptr; }
