@@ -122,6 +122,8 @@ struct hnet_ctx {
     uint64_t* d_seq = nullptr;
     struct Pinned { uint64_t seq; float prior[8]; float mean[8]; float cov[64]; uint8_t err[HNET_IMG_ROWS * HNET_IMG_COLS]; };
     Pinned* pinned = nullptr;
+    uint8_t* pinned_img[2] = {nullptr, nullptr};         // host staging of the pushed frame, one per ring slot
+    hipEvent_t ev_img[2] = {nullptr, nullptr};           // its upload has completed
     hipGraphExec_t g_infer[2] = {nullptr, nullptr};      // hnet_infer, one per ring orientation
     struct GraphKey { const void *prev, *curr, *prior, *mean, *cov; int batch, fmt; bool operator==(const GraphKey& o) const {
         return prev == o.prev && curr == o.curr && prior == o.prior && mean == o.mean && cov == o.cov && batch == o.batch && fmt == o.fmt; } };
@@ -605,6 +607,10 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     CK(hipMalloc((void**)&c->d_seq, 8));
     CK(hipMemset(c->d_seq, 0, 8));
     CK(hipHostMalloc((void**)&c->pinned, sizeof(hnet_ctx::Pinned), hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) {
+        CK(hipHostMalloc((void**)&c->pinned_img[i], NPIX, hipHostMallocDefault));
+        CK(hipEventCreateWithFlags(&c->ev_img[i], hipEventDisableTiming));
+    }
     CK(hipMalloc((void**)&c->zero_page, 256));
     CK(hipMemset(c->zero_page, 0, 256));
     c->ws_floats = (size_t)16 << 20;
@@ -702,6 +708,10 @@ void hnet_destroy(hnet_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->g_infer[i]) (void)hipGraphExecDestroy(c->g_infer[i]);
     if (c->g_batch) (void)hipGraphExecDestroy(c->g_batch);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < 2; i++) {
+        if (c->pinned_img[i]) (void)hipHostFree(c->pinned_img[i]);
+        if (c->ev_img[i]) (void)hipEventDestroy(c->ev_img[i]);
+    }
     fr(c->d_seq);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
@@ -728,8 +738,12 @@ int hnet_push_image(hnet_ctx* c, const uint8_t* data, int rows, int cols, int ro
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     c->img_counter++;                                               // HomographyNet.cpp:134
     const int slot = c->img_counter == 1 ? 0 : (c->curr_slot ^ 1);  // prev <- curr: flip the ring instead of cloning (:143)
-    HIPCHK(c, hipMemcpy2DAsync(c->ring[slot], IMG_W, data, row_stride, IMG_W, IMG_H, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                     // `data` is not retained (cv::Mat may be reused)
+    // `data` is not retained (the cv::Mat may be reused): copy it into a pinned staging frame and upload from there without
+    // waiting; network_inference follows on the same stream.  The staging frame of this slot was last used two pushes ago.
+    HIPCHK(c, hipEventSynchronize(c->ev_img[slot]));
+    for (int r = 0; r < IMG_H; r++) memcpy(c->pinned_img[slot] + (size_t)r * IMG_W, data + (size_t)r * row_stride, IMG_W);
+    HIPCHK(c, hipMemcpyAsync(c->ring[slot], c->pinned_img[slot], NPIX, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_img[slot], c->stream));
     c->curr_slot = slot;
     if (c->img_counter >= 2) c->latest_t = t;                       // :148
     return HNET_OK;
