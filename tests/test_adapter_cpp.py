@@ -113,3 +113,21 @@ def test_adapter_feeds_the_iterated_ekf_update(blob, tmp_path):
         want = np.concatenate([st["p"], st["q"], st["v"], np.diag(st["cov"])[:15]])
         assert np.abs(got - want).max() < 1e-9, (k, np.abs(got - want).max())
         assert np.abs(st["p"]).max() > 0 and (np.diag(st["cov"])[:15] > 0).all()
+
+
+LAT_BIN = os.path.join(ROOT, "tests", "cpp", "adapter_latency.bin")
+
+
+@pytest.mark.gpu
+def test_adapter_latency_from_cpp(blob, tmp_path):
+    """per-frame wall clock of the drop-in class measured in C++ (no Python in the loop); prints the figure DESIGN.md quotes"""
+    _build("adapter_latency.cpp", LAT_BIN)
+    wpath = tmp_path / "w.hnw"
+    wpath.write_bytes(blob)
+    env = dict(os.environ, HNET_MC_SAMPLES="32", HNET_BLOCKS_TO_RUN="3")
+    for use_prior in ("0", "1"):
+        r = subprocess.run([LAT_BIN, str(wpath), "220", use_prior], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        line = [l for l in r.stderr.splitlines() if l.startswith("LATENCY")][0]
+        print(("full" if use_prior == "0" else "prior-3"), line)
+        assert float(line.split()[2]) < 2.0
