@@ -36,6 +36,19 @@ int conv_padded_k(int layer) {
 // Small-M launches (batch-1 latency: a 4x5 feature map is 20 GEMM rows) would run a handful of workgroups through a
 // long serial K loop (72 K-tiles ~ 72 us).  They are cut along K into gridDim.z slices whose raw partial sums are
 // combined in a fixed order by splitk_reduce_kernel: deterministic, one extra launch.
+// split-K policy of the small-M launches: at least `min_iters` K-tiles per slice, about `target` workgroups in total.
+// Measured (HNET_SPLITK_MIN_ITERS / HNET_SPLITK_BLOCKS sweeps): with a handful of tiles (batch 1-4) fewer, longer slices win
+// (4 K-tiles, 192 workgroups: batch-1 p50 0.289 -> 0.278 ms: less partial-sum traffic for the reduce kernel), with 16+ tiles
+// 3 K-tiles and 384 workgroups do (block_1_2 at batch 256: 0.109 vs 0.142 ms).
+static int splitk_min_iters(long tiles) {
+    static const int v = std::getenv("HNET_SPLITK_MIN_ITERS") ? std::max(1, std::atoi(std::getenv("HNET_SPLITK_MIN_ITERS"))) : 0;
+    return v ? v : (tiles < 16 ? 4 : 3);
+}
+static int splitk_target_blocks(long tiles) {
+    static const int v = std::getenv("HNET_SPLITK_BLOCKS") ? std::max(64, std::atoi(std::getenv("HNET_SPLITK_BLOCKS"))) : 0;
+    return v ? v : (tiles < 16 ? 192 : 384);
+}
+
 template <class L, int BM, int BN, int WGM, int MF>
 static hipError_t run(IgemmParams p, hipStream_t s, float* ws, size_t ws_floats) {
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
@@ -43,7 +56,7 @@ static hipError_t run(IgemmParams p, hipStream_t s, float* ws, size_t ws_floats)
     const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
     int split = 1;
     if (ws && tiles < 192 && n_iter >= 8 && (p.N % 4) == 0) {
-        split = (int)std::min<long>(std::min<long>(n_iter / 3, (384 + tiles - 1) / tiles), 64);
+        split = (int)std::min<long>(std::min<long>(n_iter / splitk_min_iters(tiles), (splitk_target_blocks(tiles) + tiles - 1) / tiles), 64);
         const size_t per = (size_t)p.M * p.N;
         if ((size_t)split * per > ws_floats) split = (int)(ws_floats / per);
         if (split < 2) split = 1;
@@ -146,7 +159,7 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
     int split = 1;
     if (ws && tiles < 192 && n_iter >= 8) {
-        split = (int)std::min<long>(std::min<long>(n_iter / 3, (384 + tiles - 1) / tiles), 64);
+        split = (int)std::min<long>(std::min<long>(n_iter / splitk_min_iters(tiles), (splitk_target_blocks(tiles) + tiles - 1) / tiles), 64);
         const size_t per = (size_t)p.M * p.N;
         if ((size_t)split * per > ws_floats) split = (int)(ws_floats / per);
         if (split < 2) split = 1;
