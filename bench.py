@@ -176,7 +176,10 @@ def main():
         raise SystemExit("--mode mc needs N divisible by the number of GPUs")
     eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank,
                      precision=prec, mc_shard=shard)
-    stream = torch.cuda.current_stream(dev)
+    # everything of a step — the forward's kernels, the packing of the outputs and the RCCL gather — is enqueued on ONE
+    # ordinary (non-default) stream: ordered by the stream, no legacy-default-stream semantics involved
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     if mc_mode:
         n_loc = shard[1] - shard[0]
