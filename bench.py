@@ -92,6 +92,16 @@ def cpu_baseline(blob, state, prev, curr, prior, variant, n_mc, budget_s):
            "sample": f"{n} frame pairs, {variant} model, N={n_mc}, one pair at a time (the reference is batch-1), libtorch {torch.__version__} "
                      f"CPU operators (oracle/torch_cpu.py) on {cores} threads of {os.cpu_count()} host CPUs, {dt:.1f} s",
            "ms_per_pair": round(1e3 * dt / n, 3)}
+    # the same on ONE thread (SURVEY.md §8d asks for both; the reference measured 27.7 ms per pair single-threaded)
+    torch.set_num_threads(1)
+    one_t(0)
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 1.5:
+        one_t(n1)
+        n1 += 1
+    res["single_thread"] = {"value": round(n1 / (time.perf_counter() - t0), 2), "unit": "pairs/s", "cores": 1}
+    torch.set_num_threads(cores)
     orc = pyoracle.Oracle(blob, f32=True)
 
     def one_c(i):
