@@ -219,7 +219,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
         const bool big_m = p.M >= 4096;
         if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32>(p, s, ws, wsn); }
-        if constexpr (CIN == 128 && KS == 5) { if (big_m) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
+        if constexpr (CIN == 128 && KS == 5) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32>(p, s, ws, wsn);
     }
 }
