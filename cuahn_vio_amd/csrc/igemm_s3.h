@@ -194,43 +194,42 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
             }
         }
     } else {
-        // S3 planes: per 32x32 super-tile of the wave, 8-byte pieces (4 channels of one row) into wave-private LDS
-        // [plane][32 rows][32 cols], 16-byte chunks XOR-swizzled with (row >> 1) & 3, then 16 bytes per lane to global
+        // S3 planes: per 16 x 32 piece of the wave's tile, 8-byte pieces (4 channels of one row) into wave-private LDS
+        // [plane][16 rows][32 cols], 16-byte chunks XOR-swizzled with (row >> 1) & 3, then 16 bytes per lane to global
+        static_assert(TN16 % 2 == 0, "wave tile width is a multiple of 32");
         uint16_t* st = st_wave;
 #pragma unroll
         for (int sj = 0; sj < TN16 / 2; sj++)
 #pragma unroll
-            for (int si = 0; si < TM16 / 2; si++) {
+            for (int i = 0; i < TM16; i++) {
 #pragma unroll
-                for (int dj = 0; dj < 2; dj++)
+                for (int dj = 0; dj < 2; dj++) {
+                    const int j = 2 * sj + dj;
+                    const int nloc = dj * 16 + 4 * eg;
+                    const int n = nw + sj * 32 + nloc;
+                    f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
+                    uint16_t sa[4], sb[4], sc[4];
 #pragma unroll
-                    for (int di = 0; di < 2; di++) {
-                        const int j = 2 * sj + dj, i = 2 * si + di;
-                        const int nloc = dj * 16 + 4 * eg, mloc = di * 16 + em;
-                        const int n = nw + sj * 32 + nloc;
-                        f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
-                        if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
-                        uint16_t sa[4], sb[4], sc[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            float v = acc16[i][j][e] + bv[e];
-                            v = v > 0.0f ? v : v * 0.1f;
-                            split3(v, sa[e], sb[e], sc[e]);
-                        }
-                        const int chunk = (nloc >> 3) ^ ((mloc >> 1) & 3);
-                        const int e0 = mloc * 32 + chunk * 8 + (nloc & 7);
-                        *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
-                        *reinterpret_cast<uint2*>(&st[32 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
-                        *reinterpret_cast<uint2*>(&st[2 * 32 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+                    for (int e = 0; e < 4; e++) {
+                        float v = acc16[i][j][e] + bv[e];
+                        v = v > 0.0f ? v : v * 0.1f;
+                        split3(v, sa[e], sb[e], sc[e]);
                     }
+                    const int chunk = (nloc >> 3) ^ ((em >> 1) & 3);
+                    const int e0 = em * 32 + chunk * 8 + (nloc & 7);
+                    *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
+                    *reinterpret_cast<uint2*>(&st[16 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
+                    *reinterpret_cast<uint2*>(&st[2 * 16 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+                }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                const int mb = mw + si * 32, nb = nw + sj * 32;
+                const int mb = mw + i * 16, nb = nw + sj * 32;
 #pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    const int piece = q * 64 + lane;             // 3 planes x 32 rows x 4 chunks of 16 B
-                    const int pl = piece >> 7, rem = piece & 127, row = rem >> 2, ch = rem & 3;
+                for (int q = 0; q < 3; q++) {
+                    const int piece = q * 64 + lane;             // 3 planes x 16 rows x 4 chunks of 16 B
+                    const int pl = piece >> 6, rem = piece & 63, row = rem >> 2, ch = rem & 3;
                     const int m = mb + row, n = nb + ch * 8;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 32 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 16 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
                     if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -250,8 +249,8 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int TM16 = WM / 16, TN16 = WN / 16;
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
-    static_assert(MF == 32 || (MF == 16 && BK % 32 == 0), "MFMA shape");
+    static_assert((MF == 32 && WM % 32 == 0 && WN % 32 == 0) || (MF == 16 && WM % 16 == 0 && WN % 32 == 0 && BK % 32 == 0),
+                  "wave tile: multiples of 32x32 (32x32x16 MFMA) or 16x32 (16x16x32 MFMA)");
     constexpr int A_ROWS = (BM + RPP - 1) / RPP, B_ROWS = (BN + RPP - 1) / RPP;   // rows staged per thread and plane
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer

@@ -189,13 +189,21 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
     // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
     static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
+    static const int t96 = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
+    const bool bk64_ok = BM != 96 || t96 == 6;               // 96-row tiles: 32-wide K tiles keep three workgroups per CU (61 KB of LDS at BK 64)
     if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
-        if (bk64 && mf16) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
-        if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+        if (bk64 && mf16 && bk64_ok) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+        if constexpr (BM != 96) {
+            if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+        }
     }
-    if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
-    else if (mf16) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
+    if constexpr (BM == 96) {     // 96-row tiles exist only in the 16x16x32 form (wave tile 48 x 32)
+        hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
+    } else {
+        if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
+        else if (mf16) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
+    }
     if (split > 1) {
         if (OUT32) {
             const size_t total4 = (size_t)p.M * p.N / 4;
@@ -218,6 +226,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
         // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
         const bool big_m = p.M >= 4096;
+        if constexpr (CIN == 128 && KS == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32>(p, s, ws, wsn); }
         if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32>(p, s, ws, wsn); }
         if constexpr (CIN == 128 && KS == 5) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32>(p, s, ws, wsn);
