@@ -415,3 +415,24 @@ def test_parity_edge_configurations(blob, oracle, variant, n_mc, p, batch, prior
         o = oracle.forward(prev[b], curr[b], None if prior is None else prior[b], btr, n_mc, p, MC_SEED, 900 + b)
         assert np.abs(mean[b] - o["mean"]).max() < TOL_PX_VS_ORACLE, (b, float(np.abs(mean[b] - o["mean"]).max()))
         assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL
+
+
+def test_tiled_warp_fuzz_against_direct_warp(eng_full):
+    """200 random homographies (4-corner offsets up to +-80 px, plus rescalings that push whole tiles out of the image or
+    blow the source box past the staging buffer): LDS-tiled kernel == direct-gather kernel, bit for bit"""
+    from cuahn_vio_amd import synth
+    from oracle import pyoracle
+    i1, i2, _ = synth.make_pair(33)
+    f2 = pyoracle.as_f32_image(i2)
+    rng = np.random.default_rng(2026)
+    p4 = np.array([0, 0, 0, 223, 319, 223, 319, 0], np.float32)
+    for it in range(200):
+        amp = [4.0, 20.0, 80.0][it % 3]
+        hm = pyoracle.dlt(p4 + rng.uniform(-amp, amp, 8).astype(np.float32)).astype(np.float32)
+        if it % 7 == 0:
+            hm = (hm.astype(np.float64) @ np.diag([rng.uniform(0.2, 4.0), rng.uniform(0.2, 4.0), 1.0])).astype(np.float32)
+        if it % 11 == 0:
+            hm[2, 0] += np.float32(rng.uniform(-0.01, 0.01))          # strong perspective, possibly a Z sign change
+        direct = eng_full.op_warp(f2, hm)
+        got = eng_full.op_prep_u8(i1, i2, hm, 1)[1]
+        assert np.array_equal(got, direct), (it, hm.tolist(), float(np.abs(got - direct).max()))
