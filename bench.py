@@ -1,30 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — HomographyNet hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md §measurement).
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one forward of the full 4-block HomographyNet (MC-dropout N=32) over one batch of synthetic
-320x224 frame pairs per GPU, inputs resident in HBM, outputs [B,8]+[B,64] left in HBM; with N>1 every rank
-processes its own shard of the pairs (weak scaling) and the per-pair outputs are all-gathered over RCCL
-(288 B per pair, the only exchange the path has).  `value` = frame-pair homography predictions per second over
-all GPUs.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks (torch.distributed.run sets RANK / WORLD_SIZE) or,
+when WORLD_SIZE is unset, this script starts them itself as child processes BEFORE anything touches the GPU and relays
+rank 0's JSON line.
+
+A "step" is one forward of the full 4-block HomographyNet (MC-dropout N=32) over one batch of synthetic 320x224 frame pairs
+per GPU, inputs resident in HBM, outputs [B,8]+[B,64] left in HBM; with N>1 every rank processes its own shard of the pairs
+(weak scaling) and the per-pair outputs are all-gathered over RCCL (288 B per pair, the only exchange the path has).
+`value` = frame-pair homography predictions per second over all GPUs.  After the timed loop (outside it) pairs of the LAST
+step are checked against the CPU oracle; a mismatch makes the run fail.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters / matrix cores (dense; never the 2:1-sparsity figures)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16
 PEAK_HBM_GBS = 8000.0
+TOL_PX = 2e-4                     # |HIP - oracle| gate of the self check (tests/conftest.py TOL_PX_VS_ORACLE)
+
+# precision -> (hnet_config.precision, bf16/fp32 MFMAs issued per multiply-accumulate, peak of the instruction issued, label)
+PRECISIONS = {
+    "fp32": (0, 1, PEAK_FP32_MFMA_TFLOPS, "f32"),
+    "bf16x3": (2, 6, PEAK_BF16_MFMA_TFLOPS, "f32 as 3 x bf16 planes (six bf16 MFMAs per product, fp32 accumulate)"),
+    "bf16": (1, 1, PEAK_BF16_MFMA_TFLOPS, "bf16 operands, fp32 accumulate (REPORTED mode: ~1e-2 px, outside the parity gate)"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -32,118 +45,191 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--mc", type=int, default=32, help="MC-dropout samples N")
     ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="fp32: exact fp32 MFMA; bf16x3: fp32-grade split-bf16 MFMA (both pass the same parity tests)")
+    ap.add_argument("--precision", default="bf16x3", choices=list(PRECISIONS),
+                    help="fp32: exact fp32 MFMA; bf16x3 (default): fp32-grade split-bf16 MFMA, passes the same parity tests; "
+                         "bf16: plain bf16 operands (BASELINE config 2's 'bf16'), reported with its error, not gated")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "mc", "stream"],
                     help="pairs (default, the headline metric): frame pairs sharded over the GPUs.  mc (BASELINE config 4): "
                          "the SAME pairs on every rank, the N MC-dropout samples sharded over the ranks, one all-gather of the "
                          "per-sample head outputs, two-pass ensemble on every rank.  stream (BASELINE config 5, PCIe-inclusive, "
                          "never the headline value): every step's pairs start in pinned HOST memory; H2D of step i+1 on a copy "
                          "stream overlaps the forward of step i, outputs are copied back to pinned host memory")
+    ap.add_argument("--replay", default=None, metavar="SEQ",
+                    help="with --mode stream: the pairs are rendered along the committed UZH-FPV trajectory fixture "
+                         "tests/golden/replay_<SEQ>.npz (tools/make_replay_fixture.py), priors from the EKF mean propagation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    return ap.parse_args()
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0, help="wall-clock budget of the whole cpu_baseline leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank start-up, process-group creation and the max-over-ranks reduction only (gloo, no GPU): the CPU "
+                         "test of the multi-rank launch path")
+    return ap.parse_args(argv)
 
 
-def _calibrated_rate(one, set_threads, budget_s):
-    """pairs/s of `one(i)` after picking the thread count that is fastest on this host (more threads than the small
-    per-layer loops can feed only add fork/join cost: 256 threads ran 60x slower than 8 on the GPU box)"""
-    avail = os.cpu_count() or 1
-    best, cores = None, 1
-    for th in [t for t in (4, 8, 16, 32, 64) if t <= avail] or [1]:
-        set_threads(th)
-        one(0)
-        t0 = time.perf_counter()
-        one(1)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, th
-    set_threads(cores)
+# ------------------------------------------------------------------------------------------------ multi-rank launch
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (torch.distributed.run) before this
+    process has imported torch or touched HIP, relay their output, exit with their status.  Never an exec."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env["HNET_BENCH_SPAWNED"] = "1"
+    proc = subprocess.Popen(cmd, env=env)
+    return proc.wait()
+
+
+def time_budget_rate(one, budget_s, n_max=5000):
+    """runs one(i) until `budget_s` of wall clock is used (at least 2 calls after one warm-up); returns (calls, seconds)"""
     one(0)
     t0 = time.perf_counter()
-    for i in range(2):
-        one(i)
-    per = (time.perf_counter() - t0) / 2
-    n = int(max(4, min(5000, budget_s / max(per, 1e-4))))
-    t0 = time.perf_counter()
-    for i in range(n):
-        one(i)
-    dt = time.perf_counter() - t0
-    return n, dt, cores
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < n_max):
+        one(n + 1)
+        n += 1
+    return n, time.perf_counter() - t0
 
 
 def cpu_baseline(blob, state, prev, curr, prior, variant, n_mc, budget_s):
-    """CPU baselines on this box's host cores, on a bounded sample, one pair at a time like the reference:
+    """CPU baselines on this box's host cores, on a bounded sample (the whole leg stays inside `budget_s`), one pair at a
+    time like the reference:
     (i) `value`: the forward on libtorch's CPU operators (oracle/torch_cpu.py — our restatement of the computation the
         reference's TorchScript file runs; the reference's own .pt/.py cannot travel to this box), kind "port";
     (ii) `c_port`: the oracle's plain-fp32 C build with OpenMP (oracle/liboracle_f32.so)."""
     import torch
     from oracle import pyoracle, torch_cpu
+    t_leg = time.perf_counter()
     btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
     net = torch_cpu.TorchCpuNet(state)
+    avail = os.cpu_count() or 1
 
     def one_t(i):
         j = i % prev.shape[0]
         net.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
 
-    n, dt, cores = _calibrated_rate(one_t, torch.set_num_threads, budget_s / 2)
+    # thread count: more threads than the small per-layer loops can feed only add fork/join cost (256 threads ran 60x slower
+    # than 8 on the GPU box): try a few, two calls each
+    best, cores = None, 1
+    for th in [t for t in (8, 16, 32) if t <= avail] or [1]:
+        torch.set_num_threads(th)
+        one_t(0)
+        t0 = time.perf_counter()
+        one_t(1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, th
+    torch.set_num_threads(cores)
+    n, dt = time_budget_rate(one_t, budget_s * 0.5)
     res = {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores, "kind": "port",
            "sample": f"{n} frame pairs, {variant} model, N={n_mc}, one pair at a time (the reference is batch-1), libtorch {torch.__version__} "
-                     f"CPU operators (oracle/torch_cpu.py) on {cores} threads of {os.cpu_count()} host CPUs, {dt:.1f} s",
+                     f"CPU operators (oracle/torch_cpu.py) on {cores} threads of {avail} host CPUs, {dt:.1f} s",
            "ms_per_pair": round(1e3 * dt / n, 3)}
     # the same on ONE thread (SURVEY.md §8d asks for both; the reference measured 27.7 ms per pair single-threaded)
     torch.set_num_threads(1)
-    one_t(0)
-    t0 = time.perf_counter()
-    n1 = 0
-    while time.perf_counter() - t0 < 1.5:
-        one_t(n1)
-        n1 += 1
-    res["single_thread"] = {"value": round(n1 / (time.perf_counter() - t0), 2), "unit": "pairs/s", "cores": 1}
+    n1, dt1 = time_budget_rate(one_t, budget_s * 0.1)
+    res["single_thread"] = {"value": round(n1 / dt1, 2), "unit": "pairs/s", "cores": 1}
     torch.set_num_threads(cores)
     orc = pyoracle.Oracle(blob, f32=True)
+    c_threads = min(16, avail)
+    orc.lib.oracle_set_threads(c_threads)
 
     def one_c(i):
         j = i % prev.shape[0]
         orc.forward(prev[j], curr[j], None if variant == "full" else prior[j], btr, n_mc, 0.05, 1, i)
 
-    n, dt, cores = _calibrated_rate(one_c, orc.lib.oracle_set_threads, budget_s / 2)
-    res["c_port"] = {"value": round(n / dt, 2), "unit": "pairs/s", "cores": cores,
-                     "sample": f"{n} frame pairs, oracle/liboracle_f32.so with OpenMP on {cores} threads, {dt:.1f} s"}
+    left = max(1.0, budget_s - (time.perf_counter() - t_leg) - 0.5)
+    n, dt = time_budget_rate(one_c, min(left, budget_s * 0.25))
+    res["c_port"] = {"value": round(n / dt, 2), "unit": "pairs/s", "cores": c_threads,
+                     "sample": f"{n} frame pairs, oracle/liboracle_f32.so with OpenMP on {c_threads} threads, {dt:.1f} s"}
+    res["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
     return res
 
 
-def measured_traffic(kernel_substr, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    collected separately with tools/profile_round.sh at batch 256); None when no matching profile is committed."""
+def committed_traffic(kernel_substr, batch):
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    collected separately with tools/profile_round.sh at batch 256).  Not measured in this run: returned with its source so
+    that a reader can see which build it belongs to; (None, None) when no matching profile is committed."""
     import csv
     import glob
     if batch != 256:
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
     for r in rows:
         if kernel_substr in r["kernel"]:
-            return (float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0
-    return None
+            return ((float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0,
+                    "profiles/" + os.path.basename(files[-1]))
+    return None, None
 
 
 # stage name -> substring of the HIP kernel name in the rocprof tables
-KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "HeadLoaderS3, 128", "block_3_1": "conv_patch_s2_kernel<5>",
+KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "HeadLoaderS3, 128", "block_3_1": "conv_patch_s2_kernel<5",
                    "block_2_2": "ConvLoaderS3<64, 5, 2, 32>"}
+# stages whose contraction runs on the fp32 MFMA even in the split-bf16 mode (Cin = 2 first layers of blocks 1 and 2, and the small FCs)
+FP32_STAGES = ("block_1_1", "block_2_1", "fc_dlt_b1", "fc_dlt_b2", "fc_dlt_b3", "heads_fc2")
+
+
+def verify_last_step(blob, prev_h, curr_h, prior_h, variant, n_mc, seq_of_slot, mean, cov, slots):
+    """the oracle (test infrastructure, CPU) on `slots` of the last step's batch; returns (n, max px err, max cov rel err)"""
+    import numpy as np
+    from oracle import pyoracle
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    orc = pyoracle.Oracle(blob)
+    worst, worst_c = 0.0, 0.0
+    for b in slots:
+        j = b % prev_h.shape[0]
+        o = orc.forward(prev_h[j], curr_h[j], None if variant == "full" else prior_h[j], btr, n_mc, 0.05, 1, seq_of_slot(b))
+        worst = max(worst, float(np.abs(mean[b] - o["mean"]).max()))
+        worst_c = max(worst_c, float(np.abs(cov[b].reshape(8, 8) - o["cov"]).max() / np.abs(o["cov"]).max()))
+    return len(slots), worst, worst_c
+
+
+def dry_run(args, rank, world):
+    """the multi-rank plumbing without a GPU: process group (gloo), barrier, max-over-ranks of a timer, one JSON line"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = time.perf_counter() - t0
+    backend, ranks = None, 1
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        backend, ranks = dist.get_backend(), dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": backend, "steps": args.steps,
+                          "warmup": args.warmup, "max_over_ranks_s": round(dt, 4), "value": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N`: no launcher set the rank environment.  Start the ranks ourselves, as children,
+        # before this process initialises the GPU (nothing below this line has run yet: torch is not imported).
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -160,16 +246,26 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         if shared:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
 
     B, n_mc = args.batch, args.mc
+    prec, mfma_per_mac, peak_tf, dtype_label = PRECISIONS[args.precision]
     blob = weights.pack_state_dict(weights.synthetic_state(0))
+    replay = None
+    if args.replay:
+        from cuahn_vio_amd import replay as hreplay
+        replay = hreplay.load_fixture(args.replay)
     n_distinct = min(B, 32)
-    prev_h, curr_h, prior_h, _ = synth.make_batch(1000 + rank * n_distinct, n_distinct)
+    if replay is not None:      # consecutive frames of the trajectory; rank r starts further along it
+        prev_h, curr_h, prior_h = hreplay.render_pairs(replay, first=rank * n_distinct, count=n_distinct)
+    else:
+        prev_h, curr_h, prior_h, _ = synth.make_batch(1000 + rank * n_distinct, n_distinct)
     reps = (B + n_distinct - 1) // n_distinct
     prev = torch.from_numpy(np.tile(prev_h, (reps, 1, 1))[:B]).to(dev)
     curr = torch.from_numpy(np.tile(curr_h, (reps, 1, 1))[:B]).to(dev)
@@ -179,7 +275,6 @@ def main():
     mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
     gathered = torch.zeros(world * B, 72, device=dev) if world > 1 else None
 
-    prec = {"fp32": 0, "bf16x3": 2}[args.precision]
     mc_mode = args.mode == "mc"
     shard = hdist.shard_range(n_mc, world, rank) if mc_mode else None
     if mc_mode and n_mc % world:
@@ -220,6 +315,9 @@ def main():
             ev_free[k].record(comp_stream)
         upload(0)
 
+    def seq0_of_step(i):
+        return i * B if mc_mode else (rank * 1000003 + i) * B
+
     def step(i):
         if stream_mode:
             k = i % 2
@@ -227,7 +325,7 @@ def main():
             comp_stream.wait_event(ev_ready[k])
             if skip != "compute":
                 eng.infer_batch_device(dbuf[k][0].data_ptr(), dbuf[k][1].data_ptr(), PIX_U8, dbuf[k][2].data_ptr() if args.variant != "full" else None,
-                                       B, (rank * 1000003 + i) * B, mean.data_ptr(), cov.data_ptr(), None, comp_stream)
+                                       B, seq0_of_step(i), mean.data_ptr(), cov.data_ptr(), None, comp_stream)
             ev_free[k].record(comp_stream)
             with torch.cuda.stream(comp_stream):
                 hdist.pack_outputs(mean, cov, out)
@@ -238,7 +336,7 @@ def main():
                 upload(i + 1)
             return
         if mc_mode:   # trunk replicated, heads for this rank's samples, gather, finish in the reference's two-pass order
-            eng.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, i * B, ms_loc.data_ptr(),
+            eng.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), ms_loc.data_ptr(),
                                         lv_loc.data_ptr(), h1.data_ptr(), sp)
             if world > 1:
                 ms_all, lv_all, _ = hdist.gather_mc_samples(ms_loc, lv_loc, h1)
@@ -246,7 +344,7 @@ def main():
                 ms_all, lv_all = ms_loc, lv_loc
             eng.mc_finish_device(ms_all.data_ptr(), lv_all.data_ptr(), n_mc, h1.data_ptr(), B, mean.data_ptr(), cov.data_ptr(), sp)
             return
-        eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, (rank * 1000003 + i) * B,
+        eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i),
                                mean.data_ptr(), cov.data_ptr(), None, sp)
         if world > 1:
             hdist.gather_outputs(mean, cov, out, gathered)
@@ -276,8 +374,7 @@ def main():
         "metric": "homography preds/sec (frame pairs/s), full 4-block HomographyNet @ 320x224",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if mc_mode else "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f32 as 3 x bf16 planes (six bf16 MFMAs per product, fp32 accumulate)",
-        "data": "synthetic",
+        "dtype": dtype_label, "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
                                f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
                    "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision,
@@ -286,31 +383,73 @@ def main():
                                    (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU")),
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
     }
-
+    if replay is not None:
+        res["config"]["workload"] += f"; frames rendered along UZH-FPV {replay['name']} (tests/golden/replay_{args.replay}.npz), priors from the EKF mean propagation"
+        res["config"]["sequence"] = replay["name"]
     if stream_mode:
         res["config"]["workload"] += "; STREAMED: inputs start in pinned host memory, H2D overlapped with compute, outputs back to host"
         res["config"]["parallelism"] = "host -> device streaming, double-buffered (PCIe-inclusive; not the headline metric)"
+
+    # ---- self check, outside the timed region: pairs of the LAST step against the CPU oracle (every rank checks its own shard)
+    ok = True
+    if not args.no_verify:
+        last = args.warmup + args.steps - 1
+        slots = sorted({0, 1, B // 2, B - 1} & set(range(B)))
+        s0 = seq0_of_step(last)
+        n_v, err_px, err_cov = verify_last_step(blob, prev_h, curr_h, prior_h, args.variant, n_mc, lambda b: s0 + b,
+                                                mean.cpu().numpy(), cov.cpu().numpy(), slots)
+        gated = args.precision != "bf16"        # plain bf16 is a reported mode: its error is printed, not gated
+        ok = (err_px < TOL_PX and err_cov < 1e-4) or not gated
+        if world > 1:
+            v = torch.tensor([err_px, err_cov, 0.0 if ok else 1.0], device="cpu" if shared else dev, dtype=torch.float64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            err_px, err_cov, ok = float(v[0]), float(v[1]), float(v[2]) == 0.0
+        res["verified_pairs"] = n_v * world
+        res["max_px_err"] = float(f"{err_px:.3e}")
+        res["max_cov_rel_err"] = float(f"{err_cov:.3e}")
+        res["verify"] = {"against": "oracle/ (CPU restatement, double accumulation)", "slots_per_rank": slots, "step": last,
+                         "gate_px": TOL_PX if gated else None, "passed": bool(ok)}
+
     if rank == 0 and (mc_mode or stream_mode):
         print(json.dumps(res), flush=True)
     if rank == 0 and not mc_mode and not stream_mode:
-        # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on
+        # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on.
+        # executed FLOP = 2 x MACs x (MFMAs per MAC): six bf16 MFMAs stand behind every MAC of the split-bf16 mode;
+        # peak = dense peak of the instruction actually issued.  The fp32-equivalent rate (2 x MACs / time) is a separate field.
         stages = eng.stages()
-        ms = eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(), cov.data_ptr(), 5)
+        ms = [float(x) for x in eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(),
+                                                         cov.data_ptr(), 5)]
         k = int(np.argmax(ms))
-        total_flops = sum(f for _, f in stages) * B
-        fl = stages[k][1] * B
-        ms = [float(x) for x in ms]
-        ach = fl / (ms[k] * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
-                           "traffic": measured_traffic(KERNEL_OF_STAGE.get(stages[k][0], "\0"), B) if args.precision == "bf16x3" else None,
-                           "kernel": stages[k][0], "kernel_ms": round(float(ms[k]), 4),
-                           "flops_per_launch": fl}
-        res["forward"] = {"gflop_per_pair": round(total_flops / B / 1e9, 4),
-                          "tflops_whole_forward": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
-                          "frac_of_fp32_mfma_peak": round(total_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
-                          "stage_ms": {n: round(float(m), 4) for (n, _), m in zip(stages, ms)}}
+
+        def issued(name, flops):     # (executed flops, peak of the issuing instruction)
+            if name in FP32_STAGES or args.precision == "fp32":
+                return flops, PEAK_FP32_MFMA_TFLOPS
+            return flops * mfma_per_mac, peak_tf
+
+        alg = stages[k][1] * B
+        exe, pk = issued(stages[k][0], alg)
+        ach = exe / (ms[k] * 1e-3) / 1e12
+        traffic, traffic_src = committed_traffic(KERNEL_OF_STAGE.get(stages[k][0], "\0"), B) if args.precision == "bf16x3" else (None, None)
+        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "kernel": stages[k][0], "kernel_ms": round(ms[k], 4),
+                           "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
+                           "mfma_per_mac": mfma_per_mac if pk == peak_tf else 1,
+                           "fp32_equivalent_tflops": round(alg / (ms[k] * 1e-3) / 1e12, 2),
+                           "peak_of": "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)" if pk == PEAK_BF16_MFMA_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+        alg_total = sum(f for _, f in stages) * B
+        exe_bf16 = sum(issued(n, f)[0] for n, f in stages if issued(n, f)[1] == PEAK_BF16_MFMA_TFLOPS) * B
+        exe_fp32 = sum(issued(n, f)[0] for n, f in stages if issued(n, f)[1] == PEAK_FP32_MFMA_TFLOPS) * B
+        t_step = ms_per_step * 1e-3
+        res["forward"] = {"gflop_per_pair_algorithmic": round(alg_total / B / 1e9, 4),
+                          "fp32_equivalent_tflops": round(alg_total / t_step / 1e12, 2),
+                          "executed_tflops_bf16_mfma": round(exe_bf16 / t_step / 1e12, 1),
+                          "executed_tflops_fp32_mfma": round(exe_fp32 / t_step / 1e12, 2),
+                          # time the step would take with every MFMA issued at its instruction's dense peak / the measured step
+                          "frac_of_mfma_peak": round((exe_bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + exe_fp32 / (PEAK_FP32_MFMA_TFLOPS * 1e12)) / t_step, 4),
+                          "stage_ms": {n: round(m, 4) for (n, _), m in zip(stages, ms)}}
         if not args.no_latency:
             e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank,
                             precision=prec)
@@ -345,6 +484,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"bench.py: the last step's outputs do not match the oracle (max {res.get('max_px_err')} px)")
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@ SYMBOLS = [
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
+    "hnet_op_block4_fused",
 ]
 
 
@@ -41,7 +42,7 @@ class Camera(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("device_ms", C.c_double), ("host_ms", C.c_double), ("n_inferences", C.c_int64),
-                ("sum_device_ms_after_100", C.c_double)]
+                ("sum_device_ms_after_100", C.c_double), ("n_main_inferences", C.c_int64)]
 
 
 class HnetError(RuntimeError):
@@ -100,6 +101,7 @@ def lib():
     L.hnet_op_warp.argtypes = [vp, fp, fp, fp]
     L.hnet_op_dlt.argtypes = [vp, fp, C.c_int, fp]
     L.hnet_op_conv.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp]
+    L.hnet_op_block4_fused.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.hnet_op_prep.argtypes = [vp, fp, fp, fp, C.c_int, fp]
     L.hnet_op_prep_u8.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp, C.c_int, fp]
     L.hnet_debug_layer_output.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t]

@@ -42,7 +42,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void block4_fused_kernel(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
                                                            const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
                                                            const float* __restrict__ bias1, uint16_t* __restrict__ out16,
-                                                           size_t o_plane, int n_tiles, int dbg /* profiling ablation switches, 0 in production: 1 = drop phase-1 stores, 2 = drop phase-2 MFMAs, 4 = drop phase-1 MFMAs */) {
+                                                           size_t o_plane, int n_tiles, int dbg /* bit 3: walk the tiles from the end of the batch; bits 0-2 (only ever set by a -DHNET_B4_ABLATE profiling build): 1 = drop phase-1 stores, 2 = drop phase-2 MFMAs, 4 = drop phase-1 MFMAs */) {
     using namespace b4f;
     constexpr int H0 = 224, W0 = 320, H1 = 112, W1 = 160;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

@@ -24,9 +24,10 @@ struct Tensor { std::vector<uint32_t> dims; const float* data; size_t count; };
 
 struct Blob {
     std::vector<std::pair<std::string, Tensor>> t;
-    const Tensor* find(const std::string& n, size_t expect) const {
+    // the tensor must have exactly the reference's shape (state_dict of model_to_trace.py:88-115, :210-235), not just its size
+    const Tensor* find(const std::string& n, std::initializer_list<uint32_t> shape) const {
         for (auto& e : t)
-            if (e.first == n) return e.second.count == expect ? &e.second : nullptr;
+            if (e.first == n) return e.second.dims == std::vector<uint32_t>(shape) ? &e.second : nullptr;
         return nullptr;
     }
 };
@@ -38,7 +39,6 @@ bool parse_blob(const uint8_t* p, size_t len, Blob& out) {
     size_t pos = 12;
     struct Ent { std::string name; std::vector<uint32_t> dims; uint64_t off; size_t count; };
     std::vector<Ent> ents;
-    size_t data_bytes = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (pos + 4 > len) return false;
         uint32_t ln; memcpy(&ln, p + pos, 4); pos += 4;
@@ -47,15 +47,23 @@ bool parse_blob(const uint8_t* p, size_t len, Blob& out) {
         uint32_t nd; memcpy(&nd, p + pos, 4); pos += 4;
         if (nd > 8 || pos + 4 * nd + 8 > len) return false;
         e.count = 1;
-        for (uint32_t d = 0; d < nd; d++) { uint32_t v; memcpy(&v, p + pos, 4); pos += 4; e.dims.push_back(v); e.count *= v; }
+        for (uint32_t d = 0; d < nd; d++) {
+            uint32_t v; memcpy(&v, p + pos, 4); pos += 4;
+            e.dims.push_back(v);
+            if (v != 0 && e.count > (len / 4) / v) return false;     // the product cannot exceed the file (no 64-bit wrap)
+            e.count *= v;
+        }
         memcpy(&e.off, p + pos, 8); pos += 8;
         if (e.off % 4) return false;
-        data_bytes = std::max(data_bytes, (size_t)e.off + e.count * 4);
         ents.push_back(e);
     }
-    size_t data0 = (pos + 63) / 64 * 64;
-    if (data0 + data_bytes > len) return false;
-    for (auto& e : ents) out.t.push_back({e.name, Tensor{e.dims, (const float*)(p + data0 + e.off), e.count}});
+    const size_t data0 = (pos + 63) / 64 * 64;
+    if (data0 > len) return false;
+    const size_t room = len - data0;                                  // bytes of the data section
+    for (auto& e : ents) {                                            // offsets come from the file: every check without overflow
+        if (e.off > room || e.count > (room - (size_t)e.off) / 4) return false;
+        out.t.push_back({e.name, Tensor{e.dims, (const float*)(p + data0 + e.off), e.count}});
+    }
     return true;
 }
 
@@ -79,6 +87,7 @@ struct hnet_ctx {
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
+    int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
@@ -156,6 +165,18 @@ int fail(hnet_ctx* c, int code, const std::string& msg) {
 
 template <typename T>
 hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+
+// Device temporaries of the operator-level entry points: freed on every return path (HIPCHK returns early).
+struct DevTemps {
+    std::vector<void*> ptrs;
+    template <typename T>
+    hipError_t alloc(T** p, size_t count) {
+        const hipError_t e = dalloc(p, count);
+        if (e == hipSuccess) ptrs.push_back((void*)*p);
+        return e;
+    }
+    ~DevTemps() { for (void* q : ptrs) (void)hipFree(q); }
+};
 
 hipError_t upload(float** dst, const std::vector<float>& v) {
     hipError_t e = dalloc(dst, v.size());
@@ -293,7 +314,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
                 const size_t cnt1 = c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
-                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s));
+                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s, c->b4_flags));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -430,6 +451,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->s3 = g.precision == HNET_PREC_BF16X3;
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
+    c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -442,6 +464,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         }                                                                           \
     } while (0)
     CK(hipSetDevice(g.device_id));
+    CK(conv_kernels_init_device());      // dynamic-LDS limits of the patch / fused kernels: per device, so set at every create
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
@@ -462,8 +485,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     for (int l = 0; l < 20; l++) {
         const ConvDesc& d = kConvs[l];
         const std::string pre = std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.";
-        const Tensor* w = b.find(pre + "weight", (size_t)d.cout * d.cin * d.ks * d.ks);
-        const Tensor* bi = b.find(pre + "bias", d.cout);
+        const Tensor* w = b.find(pre + "weight", {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
+        const Tensor* bi = b.find(pre + "bias", {(uint32_t)d.cout});
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
         if (c->s3 && l == 13) {     // block_4_0 for the fused kernel: K index 8g+j of step st = (kh = 2st + (g>>1), kk = 8(g&1) + j)
             std::vector<uint16_t> fr((size_t)4 * 3 * 64 * 8, 0);
@@ -552,8 +575,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     }
     for (int k = 0; k < 3; k++) {
         const std::string pre = "model_part1.fc_block_" + std::to_string(k + 1) + ".";
-        const Tensor* w = b.find(pre + "weight", 8 * 5120);
-        const Tensor* bi = b.find(pre + "bias", 8);
+        const Tensor* w = b.find(pre + "weight", {8, 5120});
+        const Tensor* bi = b.find(pre + "bias", {8});
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
         CK(upload(&c->fc_w[k], permute_fc(w->data, 8)));
         CK(upload(&c->fc_b[k], std::vector<float>(bi->data, bi->data + 8)));
@@ -563,10 +586,10 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         std::vector<float> w1, b1, w2, b2;
         for (int h = 0; h < 2; h++) {
             const std::string pre = std::string("model_last_block_list.0.") + heads[h] + ".";
-            const Tensor* tw1 = b.find(pre + "1.weight", 256 * 5120);
-            const Tensor* tb1 = b.find(pre + "1.bias", 256);
-            const Tensor* tw2 = b.find(pre + "4.weight", 8 * 256);
-            const Tensor* tb2 = b.find(pre + "4.bias", 8);
+            const Tensor* tw1 = b.find(pre + "1.weight", {256, 5120});
+            const Tensor* tb1 = b.find(pre + "1.bias", {256});
+            const Tensor* tw2 = b.find(pre + "4.weight", {8, 256});
+            const Tensor* tb2 = b.find(pre + "4.bias", {8});
             if (!tw1 || !tb1 || !tw2 || !tb2) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
             std::vector<float> p = permute_fc(tw1->data, 256);
             w1.insert(w1.end(), p.begin(), p.end());
@@ -594,6 +617,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
             c->act_c[l] = kConvs[l].cout; c->act_h[l] = h; c->act_w[l] = w;
             c->act_count[l] = (size_t)h * w * kConvs[l].cout;
+            if (c->fuse_b4 && l == 13) continue;                   // block_4_0's output lives in LDS only (conv_b4_fused.h): 880 MB at batch 256 saved
             if (c->s3 && l != last[blk]) CK(hipMalloc((void**)&c->act16[l], 3 * MB * c->act_count[l] * 2));   // feeds a conv: S3 planes
             else CK(dalloc(&c->act[l], MB * c->act_count[l]));
         }
@@ -823,29 +847,33 @@ int hnet_push_raw_image(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int
 int hnet_op_undistort(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int row_stride, uint8_t* out) {
     if (!c || !raw || !out) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    DevTemps t;
     uint8_t* d_o = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_o, NPIX));
+    HIPCHK(c, t.alloc(&d_o, (size_t)NPIX));
     const int rc = remap_raw(c, raw, rows, cols, row_stride, d_o);
     if (rc == HNET_OK) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(out, d_o, NPIX, hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_o);
     return rc;
 }
 
 int hnet_image_count(const hnet_ctx* c) { return c ? c->img_counter : 0; }
 double hnet_latest_time(const hnet_ctx* c) { return c ? c->latest_t : -1.0; }
 
-static void note_timing(hnet_ctx* c, float dev_ms, double host_ms) {
+// `main_model`: the call the reference times (num_of_inference == 0, HomographyNet.cpp:174-189); IEKF re-runs (iteration > 0)
+// advance the mask sequence number (n_inferences) but not the timing statistics (:245-251 sit under `num_of_inference == 0`)
+static void note_timing(hnet_ctx* c, float dev_ms, double host_ms, bool main_model = true) {
     c->timing.device_ms = dev_ms;
     c->timing.host_ms = host_ms;
     c->timing.n_inferences++;
-    if (c->timing.n_inferences > 100) c->timing.sum_device_ms_after_100 += dev_ms;   // HomographyNet.cpp:245-251
+    if (main_model) {
+        c->timing.n_main_inferences++;                                                    // inference_counting, :189
+        if (c->timing.n_main_inferences > 100) c->timing.sum_device_ms_after_100 += dev_ms;   // :245-251
+    }
 }
 
 int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_out[8], float cov_out[64], uint8_t* err_map_out) {
-    (void)iteration;
     if (!c || !mean_out || !cov_out) return HNET_ERR_INVALID_ARG;
     if (c->img_counter < 2) return fail(c, HNET_ERR_NOT_READY, "HNet cannot inference! Only has one image!");   // :155-158
     if (err_map_out && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
@@ -884,7 +912,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             if (err_map_out) memcpy(err_map_out, pin->err, NPIX);
             float gms = 0;
             HIPCHK(c, hipEventElapsedTime(&gms, c->ev0, c->ev1));
-            note_timing(c, gms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            note_timing(c, gms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), iteration == 0);
             return HNET_OK;
         }
     }
@@ -907,7 +935,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), iteration == 0);
     return HNET_OK;
 }
 
@@ -1040,16 +1068,21 @@ int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_cur
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t ns = c->stages.size();
     std::vector<double> acc(ns, 0.0);
-    c->prof_ev.resize(ns);
+    // the per-stage events live in the context only for the duration of this call: whatever happens, they are destroyed
+    // and the list is emptied again (a non-empty list makes every later forward single-stream and event-recording)
+    struct Cleanup {
+        hnet_ctx* c;
+        ~Cleanup() { for (auto e : c->prof_ev) if (e) (void)hipEventDestroy(e); c->prof_ev.clear(); c->prof_pos = 0; }
+    } cleanup{c};
+    c->prof_ev.assign(ns, nullptr);
     for (auto& e : c->prof_ev) HIPCHK(c, hipEventCreate(&e));
-    int rc = HNET_OK;
-    for (int it = 0; it < iters && rc == HNET_OK; it++) {
+    for (int it = 0; it < iters; it++) {
         c->prof_pos = 0;
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        rc = hnet_infer_batch_device(c, d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
-                                     c->cfg.emit_error_map ? c->d_err : nullptr, nullptr);
-        if (rc != HNET_OK) break;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, HNET_ERR_DEVICE, "sync"); break; }
+        const int rc = hnet_infer_batch_device(c, d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
+                                               c->cfg.emit_error_map ? c->d_err : nullptr, nullptr);
+        if (rc != HNET_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         hipEvent_t prev = c->ev0;
         for (size_t i = 0; i < c->prof_pos; i++) {
             float ms = 0;
@@ -1058,38 +1091,35 @@ int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_cur
             prev = c->prof_ev[i];
         }
     }
-    for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
-    c->prof_ev.clear();
-    c->prof_pos = 0;
     for (size_t i = 0; i < ns; i++) stage_ms_avg[i] = (float)(acc[i] / iters);
-    return rc;
+    return HNET_OK;
 }
 
 /* ---- operator-level entry points (host buffers) ---- */
 int hnet_op_warp(hnet_ctx* c, const float* img, const float* H, float* out) {
     if (!c || !img || !H || !out) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    DevTemps t;
     float *d_i = nullptr, *d_o = nullptr, *d_h = nullptr;
-    HIPCHK(c, dalloc(&d_i, (size_t)NPIX)); HIPCHK(c, dalloc(&d_o, (size_t)NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
+    HIPCHK(c, t.alloc(&d_i, (size_t)NPIX)); HIPCHK(c, t.alloc(&d_o, (size_t)NPIX)); HIPCHK(c, t.alloc(&d_h, (size_t)9));
     HIPCHK(c, hipMemcpy(d_i, img, NPIX * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
     HIPCHK(c, launch_warp_f32(d_i, d_h, d_o, 1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_o, NPIX * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_i); (void)hipFree(d_o); (void)hipFree(d_h);
     return HNET_OK;
 }
 
 int hnet_op_dlt(hnet_ctx* c, const float* dst, int n, float* H) {
     if (!c || !dst || !H || n < 1) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    DevTemps t;
     float *d_d = nullptr, *d_h = nullptr;
-    HIPCHK(c, dalloc(&d_d, (size_t)n * 8)); HIPCHK(c, dalloc(&d_h, (size_t)n * 9));
+    HIPCHK(c, t.alloc(&d_d, (size_t)n * 8)); HIPCHK(c, t.alloc(&d_h, (size_t)n * 9));
     HIPCHK(c, hipMemcpy(d_d, dst, (size_t)n * 32, hipMemcpyHostToDevice));
     HIPCHK(c, launch_dlt(d_d, d_h, n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(H, d_h, (size_t)n * 36, hipMemcpyDeviceToHost));
-    (void)hipFree(d_d); (void)hipFree(d_h);
     return HNET_OK;
 }
 
@@ -1099,8 +1129,9 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
     const ConvDesc& d = kConvs[layer];
     const int ho = conv_out_dim(h, d.ks, d.stride), wo = conv_out_dim(w, d.ks, d.stride);
     const size_t n_in = (size_t)batch * d.cin * h * w, n_out = (size_t)batch * d.cout * ho * wo;
+    DevTemps t;
     float *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_d = nullptr;
-    HIPCHK(c, dalloc(&d_a, n_in)); HIPCHK(c, dalloc(&d_b, n_in)); HIPCHK(c, dalloc(&d_c, n_out)); HIPCHK(c, dalloc(&d_d, n_out));
+    HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_c, n_out)); HIPCHK(c, t.alloc(&d_d, n_out));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
     if (!c->s3) {
         HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
@@ -1108,8 +1139,8 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         HIPCHK(c, launch_nhwc_to_nchw(d_c, d_d, batch, d.cout, ho, wo, c->stream));
     } else {   // split-bf16 mode: the layer reads / writes three bf16 planes, exactly as inside the forward
         uint16_t *p_in = nullptr, *p_out = nullptr;
-        HIPCHK(c, hipMalloc((void**)&p_in, 3 * n_in * 2 + 64));
-        HIPCHK(c, hipMalloc((void**)&p_out, 3 * n_out * 2 + 64));
+        HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32));
+        HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
         if (c->use_patch && conv_is_patch_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream));
@@ -1125,50 +1156,57 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
                 HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
         }
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(p_in); (void)hipFree(p_out);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_c); (void)hipFree(d_d);
+    return HNET_OK;
+}
+
+int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, float* out) {
+    if (!c || !in || !out || batch < 1) return HNET_ERR_INVALID_ARG;
+    if (!c->fuse_b4 || !c->b40_frag || !c->b41_frag) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_4_0 + block_4_1 kernel exists in the split-bf16 mode only");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t n_in = (size_t)batch * 2 * NPIX, n_out = (size_t)batch * 16 * (IMG_H / 2) * (IMG_W / 2);
+    DevTemps t;
+    float *d_a = nullptr, *d_b = nullptr, *d_d = nullptr;
+    uint16_t* p_out = nullptr;
+    HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
+    HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, IMG_H, IMG_W, c->stream));
+    HIPCHK(c, launch_block4_fused(d_b, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0));
+    HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
+    return HNET_OK;
+}
+
+static int op_prep_impl(hnet_ctx* c, const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out) {
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int ho = IMG_H / k, wo = IMG_W / k;
+    const size_t px = pix_fmt == HNET_PIX_U8 ? 1 : 4;
+    DevTemps t;
+    uint8_t *d_1 = nullptr, *d_2 = nullptr;
+    float *d_h = nullptr, *d_o = nullptr, *d_t = nullptr;
+    HIPCHK(c, t.alloc(&d_1, NPIX * px)); HIPCHK(c, t.alloc(&d_2, NPIX * px)); HIPCHK(c, t.alloc(&d_h, (size_t)9));
+    HIPCHK(c, t.alloc(&d_o, (size_t)2 * ho * wo)); HIPCHK(c, t.alloc(&d_t, (size_t)2 * ho * wo));
+    HIPCHK(c, hipMemcpy(d_1, img1, NPIX * px, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_2, img2, NPIX * px, hipMemcpyHostToDevice));
+    if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_prep(d_1, d_2, pix_fmt, H ? d_h : nullptr, k, d_o, 1, c->stream));
+    HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
     return HNET_OK;
 }
 
 int hnet_op_prep(hnet_ctx* c, const float* img1, const float* img2, const float* H, int k, float* out) {
     if (!c || !img1 || !img2 || !out || (k != 1 && k != 2 && k != 4 && k != 8)) return HNET_ERR_INVALID_ARG;
-    HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const int ho = IMG_H / k, wo = IMG_W / k;
-    float *d_1 = nullptr, *d_2 = nullptr, *d_h = nullptr, *d_o = nullptr, *d_t = nullptr;
-    HIPCHK(c, dalloc(&d_1, (size_t)NPIX)); HIPCHK(c, dalloc(&d_2, (size_t)NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
-    HIPCHK(c, dalloc(&d_o, (size_t)2 * ho * wo)); HIPCHK(c, dalloc(&d_t, (size_t)2 * ho * wo));
-    HIPCHK(c, hipMemcpy(d_1, img1, NPIX * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(d_2, img2, NPIX * 4, hipMemcpyHostToDevice));
-    if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
-    HIPCHK(c, launch_prep(d_1, d_2, HNET_PIX_F32, H ? d_h : nullptr, k, d_o, 1, c->stream));
-    HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_1); (void)hipFree(d_2); (void)hipFree(d_h); (void)hipFree(d_o); (void)hipFree(d_t);
-    return HNET_OK;
+    return op_prep_impl(c, img1, img2, HNET_PIX_F32, H, k, out);
 }
 
 int hnet_op_prep_u8(hnet_ctx* c, const uint8_t* img1, const uint8_t* img2, const float* H, int k, float* out) {
     if (!c || !img1 || !img2 || !out || (k != 1 && k != 2 && k != 4 && k != 8)) return HNET_ERR_INVALID_ARG;
-    HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const int ho = IMG_H / k, wo = IMG_W / k;
-    uint8_t *d_1 = nullptr, *d_2 = nullptr;
-    float *d_h = nullptr, *d_o = nullptr, *d_t = nullptr;
-    HIPCHK(c, hipMalloc(&d_1, NPIX)); HIPCHK(c, hipMalloc(&d_2, NPIX)); HIPCHK(c, dalloc(&d_h, (size_t)9));
-    HIPCHK(c, dalloc(&d_o, (size_t)2 * ho * wo)); HIPCHK(c, dalloc(&d_t, (size_t)2 * ho * wo));
-    HIPCHK(c, hipMemcpy(d_1, img1, NPIX, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(d_2, img2, NPIX, hipMemcpyHostToDevice));
-    if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
-    HIPCHK(c, launch_prep(d_1, d_2, HNET_PIX_U8, H ? d_h : nullptr, k, d_o, 1, c->stream));
-    HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_1); (void)hipFree(d_2); (void)hipFree(d_h); (void)hipFree(d_o); (void)hipFree(d_t);
-    return HNET_OK;
+    return op_prep_impl(c, img1, img2, HNET_PIX_U8, H, k, out);
 }
 
 int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t cap) {
@@ -1176,16 +1214,15 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t n = (size_t)c->act_c[layer] * c->act_h[layer] * c->act_w[layer];
     if (cap < n) return fail(c, HNET_ERR_INVALID_ARG, "buffer too small");
+    DevTemps t;
     float* d_t = nullptr;
-    HIPCHK(c, dalloc(&d_t, n));
+    HIPCHK(c, t.alloc(&d_t, n));
     if (c->fuse_b4 && layer == 13) {   // the fused kernel keeps block_4_0's output in LDS: recompute it unfused for inspection
         uint16_t* tmp = nullptr;
-        HIPCHK(c, hipMalloc((void**)&tmp, 3 * n * 2));
+        HIPCHK(c, t.alloc(&tmp, 3 * n));
         HIPCHK(c, launch_conv(13, c->x_in[3] + (size_t)pair * NPIX * 2, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
                               nullptr, 0, tmp, n));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(tmp);
     } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
                                              c->act_h[layer], c->act_w[layer], c->stream));
@@ -1193,7 +1230,6 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_t, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_t);
     return HNET_OK;
 }
 

@@ -35,7 +35,9 @@ hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int 
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 int h, int w, hipStream_t s);
 hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */);
+// dynamic-LDS limits of the kernels that use more than 64 KB; once per device (hnet_create)
+hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,

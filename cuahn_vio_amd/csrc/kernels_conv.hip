@@ -235,20 +235,25 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
 
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
 
+hipError_t conv_kernels_init_device() {
+    hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4f::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3>::LDS_BYTES);
+    return e;
+}
+
 // block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
 hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, b4f::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
     const int n_tiles = batch * (112 / b4f::TH1) * (160 / b4f::TW1);
     const unsigned blocks = (unsigned)std::min(n_tiles, 256);      // persistent: one 512-thread workgroup per CU (85 KB of LDS)
-    static const int dbg = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;   // profiling ablations (wrong results)
+    int dbg = 0;
+#ifdef HNET_B4_ABLATE   // profiling build only (make FLAGS+=-DHNET_B4_ABLATE): HNET_B4_DBG drops phases of the kernel, results are wrong
+    static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
+    dbg = dbg_env & 7;
+#endif
     hipLaunchKernelGGL(block4_fused_kernel, dim3(blocks), dim3(b4f::THREADS), b4f::LDS_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
-                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, dbg);
+                       (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, dbg | ((flags & 1) ? 8 : 0));
     return hipGetLastError();
 }
 
@@ -268,12 +273,6 @@ template <int KS>
 static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfrag, const float* bias, uint16_t* out16,
                             size_t o_plane, int batch, int h, int w, hipStream_t s) {
     typedef PatchS2Cfg<KS> C;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
     const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent, 2 workgroups per CU

@@ -128,7 +128,7 @@ class HnetEngine:
         t = Timing()
         check(self._h, self._L.hnet_last_timing(self._h, C.byref(t)))
         return {"device_ms": t.device_ms, "host_ms": t.host_ms, "n_inferences": t.n_inferences,
-                "sum_device_ms_after_100": t.sum_device_ms_after_100}
+                "sum_device_ms_after_100": t.sum_device_ms_after_100, "n_main_inferences": t.n_main_inferences}
 
     # ---- operator-level entry points (NCHW host arrays, like the reference tensors) ---------------
     def op_warp(self, img, h):
@@ -154,6 +154,15 @@ class HnetEngine:
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         out = np.zeros((b, cout, ho, wo), np.float32)
         check(self._h, self._L.hnet_op_conv(self._h, layer, _fp(x), b, h, w, _fp(out)))
+        return out
+
+    def op_block4_fused(self, x, reverse=False):
+        """the fused block_4_0 + block_4_1 kernel alone: x [B,2,224,320] -> [B,16,112,160]"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        b = x.shape[0]
+        assert x.shape[1:] == (2, IMG_H, IMG_W)
+        out = np.zeros((b, 16, IMG_H // 2, IMG_W // 2), np.float32)
+        check(self._h, self._L.hnet_op_block4_fused(self._h, _fp(x), b, int(bool(reverse)), _fp(out)))
         return out
 
     def op_prep(self, img1, img2, h, k):
@@ -288,8 +297,8 @@ class HomographyNet:
         self.last_error_map = err
         if num_of_inference == 0:
             t = self._eng.last_timing()
-            if t["n_inferences"] > 100:
-                avg = t["sum_device_ms_after_100"] / (t["n_inferences"] - 100)
+            if t["n_main_inferences"] > 100:
+                avg = t["sum_device_ms_after_100"] / (t["n_main_inferences"] - 100)
                 print(f"[TIME]: {t['device_ms']:.3f} (avg. = {avg:.3f}) milliseconds for pure network inference")
 
     def get_pred_mean(self):

@@ -134,9 +134,9 @@ public:
         if (num_of_inference == 0) {                                        // :245-251
             hnet_timing t;
             hnet_last_timing(ctx_, &t);
-            if (t.n_inferences > 100)
+            if (t.n_main_inferences > 100)                                  // inference_counting: iteration-0 calls only (:189)
                 std::printf(HNET_BLUE "[TIME]: %.3f (avg. = %.3f) milliseconds for pure network inference\n" HNET_RESET,
-                            t.device_ms, t.sum_device_ms_after_100 / (double)(t.n_inferences - 100));
+                            t.device_ms, t.sum_device_ms_after_100 / (double)(t.n_main_inferences - 100));
         }
     }
 

@@ -69,11 +69,14 @@ typedef struct hnet_ctx hnet_ctx;
 typedef struct hnet_timing {
     double device_ms;          /* "pure network inference": device time of the last forward (HomographyNet.cpp:178-188) */
     double host_ms;            /* wall time of the last hnet_infer / hnet_infer_batch call, incl. H2D and D2H */
-    int64_t n_inferences;
-    double sum_device_ms_after_100;   /* running sum that skips the first 100 calls (HomographyNet.cpp:245-251) */
+    int64_t n_inferences;      /* every forward of hnet_infer / hnet_infer_batch (also the mask sequence number of hnet_infer) */
+    double sum_device_ms_after_100;   /* running sum over the iteration == 0 calls that skips the first 100 (HomographyNet.cpp:245-251) */
+    int64_t n_main_inferences; /* `inference_counting` (HomographyNet.cpp:189): calls with iteration == 0 only */
 } hnet_timing;
 
-/* fills `cfg` with the reference's launch defaults: full model, N=16, p=0.05, fp32, max_batch 1 */
+/* fills `cfg` with the reference's launch defaults — full model, N=16, p=0.05, max_batch 1 — and precision =
+ * HNET_PREC_BF16X3 (fp32-grade results on the bf16 matrix cores; passes the same parity gates as HNET_PREC_FP32, which is
+ * the reference's own fp32 arithmetic and stays selectable) */
 void hnet_default_config(hnet_config* cfg);
 
 /* Replaces HomographyNet::load_network_model (HomographyNet.cpp:81-103): `weights_path` names an HNETW001
@@ -183,6 +186,10 @@ int hnet_op_dlt(hnet_ctx* ctx, const float* dst, int n, float* H);
 /* conv layer `layer` (0..19, execution order of cuahn_vio_amd/weights.py CONV_LAYERS) with its own weights:
  * in [B][Cin][H][W] -> out [B][Cout][Ho][Wo], + bias + LeakyReLU(0.1)   (model_to_trace.py:7-15) */
 int hnet_op_conv(hnet_ctx* ctx, int layer, const float* in, int batch, int h, int w, float* out);
+/* the fused block_4_0 + block_4_1 kernel of the split-bf16 mode (csrc/conv_b4_fused.h) on its own:
+ * in [B][2][224][320] -> out [B][16][112][160] = conv_lrelu(conv_lrelu(in, block_4_0), block_4_1)   (model_to_trace.py:210-211).
+ * reverse != 0 walks the tiles from the end of the batch.  HNET_ERR_UNSUPPORTED in the other arithmetic modes. */
+int hnet_op_block4_fused(hnet_ctx* ctx, const float* in, int batch, int reverse, float* out);
 /* cat(img1, warp(img2,H)) -> AvgPool(k): img1,img2 [224][320] f32, H[9] or NULL (no warp), k in {1,2,4,8}
  * -> out [2][224/k][320/k]   (model_to_trace.py:153-157) */
 int hnet_op_prep(hnet_ctx* ctx, const float* img1, const float* img2, const float* H, int k, float* out);

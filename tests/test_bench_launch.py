@@ -1,0 +1,39 @@
+"""bench.py's multi-rank launch path, on CPU: `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start two
+ranks itself — as child processes, before anything touches a GPU — create the process group and have rank 0 print ONE
+JSON line that says n_gpus = 2.  --dry-run stops after the process-group plumbing (gloo; the real run uses RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout          # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"] == "gloo" and r["dry_run"] is True
+    assert r["steps"] == 3 and r["warmup"] == 1
+    assert r["max_over_ranks_s"] >= 0.02       # rank 1 sleeps 20 ms, rank 0 10 ms: the MAX over ranks is reported
+
+
+def test_bench_single_rank_dry_run():
+    r = _run("--dry-run")
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1
+
+
+def test_bench_refuses_a_mismatched_world():
+    env = {k: v for k, v in os.environ.items()}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -1,0 +1,166 @@
+"""Correctness gates on the shapes bench.py reports (BASELINE.json configs 2-4) — the large-M tile variants, the persistent
+tile loops, the XCD-aware tile mapping and the split-K policy all depend on the batch, so the benchmarked batch itself is
+checked: selected pairs against the CPU oracle, and every pair against the same pair computed in another slot (bitwise).
+
+Reference semantics: a batch is the batch-1 function applied to each pair (the reference is batch-1 only, warp.py:64)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE
+
+pytestmark = pytest.mark.gpu
+
+MC_SEED = 0x5EED5EED12345678
+PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")]
+
+
+def _batch(first_seed, n_distinct, batch):
+    from cuahn_vio_amd import synth
+    prev, curr, prior, _ = synth.make_batch(first_seed, n_distinct)
+    reps = (batch + n_distinct - 1) // n_distinct
+    return (np.tile(prev, (reps, 1, 1))[:batch].copy(), np.tile(curr, (reps, 1, 1))[:batch].copy(),
+            np.tile(prior, (reps, 1))[:batch].copy())
+
+
+def _check_batch(blob, oracle, variant, batch, n_mc, precision, check_pairs, n_distinct, rot):
+    """the benchmark's own call (hnet_infer_batch_device semantics via the host entry point) at `batch` pairs:
+    (1) pairs `check_pairs` vs oracle.forward, (2) the same batch rotated by `rot` slots with the sequence numbers moved
+    along: every pair that does not wrap must reproduce its result bit for bit in its new slot"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    btr = {"full": 3, "prior3": 3}[variant]
+    prev, curr, prior = _batch(4000 + batch, n_distinct, batch)
+    if variant == "full":
+        prior = None
+    s0 = 5000
+    eng = HnetEngine(blob, variant=variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=batch, precision=precision)
+    mean, cov = eng.infer_batch(prev, curr, prior, pair_seq0=s0)
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    worst = 0.0
+    for b in check_pairs:
+        o = oracle.forward(prev[b], curr[b], None if prior is None else prior[b], btr, n_mc, 0.05, MC_SEED, s0 + b)
+        d = float(np.abs(mean[b] - o["mean"]).max())
+        worst = max(worst, d)
+        assert d < TOL_PX_VS_ORACLE, (b, d)
+        assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
+    print(f"{variant} B={batch} N={n_mc} precision={precision}: max |hip - oracle| over pairs {list(check_pairs)} = {worst:.2e} px")
+    # slot invariance at the benchmarked batch: pair b sits in slot b + rot with the same mask sequence number
+    idx = (np.arange(batch) - rot) % batch                    # slot j holds pair idx[j]
+    m2, c2 = eng.infer_batch(prev[idx], curr[idx], None if prior is None else prior[idx], pair_seq0=s0 - rot)
+    keep = np.arange(rot, batch)                              # slots whose pair did not wrap (sequence number unchanged)
+    assert np.array_equal(m2[keep], mean[idx[keep]]) and np.array_equal(c2[keep], cov[idx[keep]])
+    # and run to run
+    m3, c3 = eng.infer_batch(prev, curr, prior, pair_seq0=s0)
+    assert np.array_equal(m3, mean) and np.array_equal(c3, cov)
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_benchmark_batch_256_full_n32(blob, oracle, precision):
+    """bench.py's default workload: full model, 256 pairs, MC-dropout N = 32, p = 0.05 (BENCH_rNN.json `value`)"""
+    _check_batch(blob, oracle, "full", 256, 32, precision, (0, 1, 31, 32, 127, 254, 255), n_distinct=48, rot=37)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_config3_prior3_batch_64(blob, oracle, precision):
+    """BASELINE.json config 3: 3-block net with the EKF prior, 64 pairs"""
+    _check_batch(blob, oracle, "prior3", 64, 16, precision, (0, 1, 31, 32, 62, 63), n_distinct=64, rot=5)
+
+
+# ---------------------------------------------------------------------------------------------- the dominant kernel, element by element
+def _conv2(state, x):
+    from oracle import pyoracle
+    pre = "model_last_block_list.0."
+    y = pyoracle.conv_lrelu(x, state[pre + "block_4_0.0.weight"], state[pre + "block_4_0.0.bias"], 1)
+    return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("batch", [1, 3, 5])
+def test_block4_fused_kernel_elementwise(blob, state, batch, reverse):
+    """block4_fused_kernel (block_4_0 + block_4_1 in one launch, the 8-channel map never leaves LDS) against
+    conv_lrelu(conv_lrelu(.)) of the oracle, every element of every pair, random inputs that are non-zero up to the image
+    border (so the zero padding of BOTH layers matters), forward and reverse tile walk, batches that give every persistent
+    workgroup 1 tile (70, 210 tiles) and more than one (350 tiles over 256 workgroups)"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    rng = np.random.default_rng(100 + batch)
+    x = rng.standard_normal((batch, 2, 224, 320)).astype(np.float32)
+    x[:, :, :3, :] += 2.0          # make the borders stand out: a wrong border / padding rule cannot hide
+    x[:, :, :, -3:] -= 2.0
+    got = eng.op_block4_fused(x, reverse=reverse)
+    eng.close()
+    for b in range(batch):
+        ref = _conv2(state, x[b])
+        assert got[b].shape == ref.shape
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (b, err)
+
+
+@pytest.mark.parametrize("layer", [7, 8, 15])
+def test_patch_kernels_real_geometry_multi_pair(eng_s3, state, layer):
+    """block_3_0 (conv7_c2_s1_s3_kernel) and the LDS-patch kernels of block_3_1 / block_4_2 (conv_patch_s2_kernel<5|3>) at
+    their real 112x160 geometry with 16 pairs: 560 tiles for the 512 persistent workgroups of the patch kernels (tile ->
+    image mapping across pairs, reverse tile walk, more than one tile per workgroup), every element vs the oracle conv"""
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    from oracle import pyoracle
+    name, cin, cout, k, s = CONV_LAYERS[layer]
+    prefix = "model_last_block_list.0." if name[6] == "4" else "model_part1."
+    rng = np.random.default_rng(layer)
+    x = rng.standard_normal((16, cin, 112, 160)).astype(np.float32)
+    got = eng_s3.op_conv(layer, x)
+    for b in range(16):
+        ref = pyoracle.conv_lrelu(x[b], state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"], s)
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
+
+
+@pytest.fixture(scope="module")
+def eng_s3(blob):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    e = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    yield e
+    e.close()
+
+
+def test_multi_stream_chunks_equal_single_stream(blob):
+    """HNET_STREAMS=2: the batch is cut into two chunks of independent pairs on two HIP streams (fork / join with events).
+    Concurrent chunks cannot share the split-K workspace, so the small-M layers sum in one pass instead of in K slices:
+    same math, other summation order (like batch 1 vs batch 5 in test_gpu_parity.py) - equal to 3e-5 px, and the
+    two-stream run itself is deterministic"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, prior = _batch(4500, 8, 48)
+    one = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=48)
+    m1, c1 = one.infer_batch(prev, curr, prior, pair_seq0=11)
+    one.close()
+    old = os.environ.get("HNET_STREAMS")
+    os.environ["HNET_STREAMS"] = "2"
+    try:
+        two = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=48)
+    finally:
+        if old is None:
+            del os.environ["HNET_STREAMS"]
+        else:
+            os.environ["HNET_STREAMS"] = old
+    m2, c2 = two.infer_batch(prev, curr, prior, pair_seq0=11)
+    m3, c3 = two.infer_batch(prev, curr, prior, pair_seq0=11)
+    two.close()
+    assert np.array_equal(m2, m3) and np.array_equal(c2, c3)
+    assert np.abs(m1 - m2).max() < 3e-5 and np.abs(c1 - c2).max() / np.abs(c1).max() < 1e-6
+
+
+def test_iekf_reruns_do_not_enter_the_timing_average(blob):
+    """HomographyNet.cpp:189,245-251: `inference_counting` and the running average only see calls with num_of_inference == 0;
+    IEKF re-runs (iteration > 0) advance the mask sequence number but not those statistics"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HomographyNet
+    net = HomographyNet("w.hnw", use_prior=True, weights_blob=blob, mc_seed=3)
+    i1, i2, _ = synth.make_pair(5)
+    net.load_current_img(i1, 0.0)
+    net.load_current_img(i2, 1.0)
+    prior = np.zeros(8)
+    for it in (0, 1, 2, 0, 1):
+        net.network_inference(prior, it)
+    t = net._eng.last_timing()
+    assert t["n_inferences"] == 5 and t["n_main_inferences"] == 2
