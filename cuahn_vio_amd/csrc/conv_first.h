@@ -195,12 +195,14 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restric
 // wfrag: [7 kernel rows][3 planes][64 lanes] x 16 B; lane (n = l&31 = (dx, co), hh = l>>5) holds kk = 8hh .. 8hh+7 of
 // W'[kh][kk = 2 kw' + ci][n] = W[co][ci][kh][kw' - dx] (pack in hnet_capi.hip).
 // ---------------------------------------------------------------------------------------------
+// NP = number of bf16 planes (3 = split-bf16, 1 = plain bf16 operands)
+template <int NP>
 __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __restrict__ in, const u32x4* __restrict__ wfrag,
                                                              const float* __restrict__ bias, uint16_t* __restrict__ out16, size_t o_plane,
                                                              int H, int W, int tiles_x, int tiles_y) {
     constexpr int TH = 16, TW = 32, PH = TH + 6, PW = TW + 8, PROW = PW * 2, PPLANE = PH * PROW;
-    __shared__ __attribute__((aligned(16))) uint16_t patch[3 * PPLANE];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4 * 3 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) uint16_t patch[NP * PPLANE];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4 * NP * 64 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
     const int b = bid / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    u32x4 wv[7][3];
+    bf16x8 wv[7][3];
 #pragma unroll
     for (int kh = 0; kh < 7; kh++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) wv[kh][pl] = wfrag[(kh * 3 + pl) * 64 + lane];
+        for (int pl = 0; pl < NP; pl++) wv[kh][pl] = __builtin_bit_cast(bf16x8, wfrag[(kh * 3 + pl) * 64 + lane]);
 
     // ---- stage the patch: unconditional float2 loads from a clamped address, zero selected afterwards, split into planes
     const float* inb = in + (size_t)b * H * W * 2;
@@ -234,13 +236,17 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
         const int i = tid + q * 256;
         if (i < PH * PW) {
             const bool ok = (okbits >> q) & 1u;
-            uint16_t a0, a1, a2, b0, b1, b2;
-            split3(ok ? px[q].x : 0.f, a0, a1, a2);
-            split3(ok ? px[q].y : 0.f, b0, b1, b2);
+            uint16_t pa[3], pb[3];
+            if constexpr (NP == 3) {
+                split3(ok ? px[q].x : 0.f, pa[0], pa[1], pa[2]);
+                split3(ok ? px[q].y : 0.f, pb[0], pb[1], pb[2]);
+            } else {
+                pa[0] = f32_to_bf16_rn(ok ? px[q].x : 0.f);
+                pb[0] = f32_to_bf16_rn(ok ? px[q].y : 0.f);
+            }
             const int e = i * 2;                                // [row][column][2 ch], rows of PROW elements: i = pr*PW + pc
-            *reinterpret_cast<uint32_t*>(&patch[e]) = (uint32_t)a0 | ((uint32_t)b0 << 16);
-            *reinterpret_cast<uint32_t*>(&patch[PPLANE + e]) = (uint32_t)a1 | ((uint32_t)b1 << 16);
-            *reinterpret_cast<uint32_t*>(&patch[2 * PPLANE + e]) = (uint32_t)a2 | ((uint32_t)b2 << 16);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = (uint32_t)pa[pl] | ((uint32_t)pb[pl] << 16);
         }
     }
     __syncthreads();
@@ -248,6 +254,8 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
     // M-tile = 2 output rows x 16 pixel pairs; lane column = (row-of-pair, pixel pair), lane half hh = taps 4hh..4hh+3
     const int pcol = lane & 31, hh = lane >> 5;
     const int prow = pcol >> 4, pair = pcol & 15;
+    int hi4 = 4;                                                // opaque: two ds_read_b64 (2 + 2 LDS cycles) instead of one ds_read2_b64 (8)
+    asm volatile("" : "+v"(hi4));
     float bv[4][4];                                             // D row (r&3) + 8(r>>2) + 4hh = n = (dx, co): group q = r>>2
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -264,45 +272,46 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
         for (int kh = 0; kh < 7; kh++) {
             bf16x8 a[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {                    // 8 bf16 = 4 taps x 2 ch, 8-byte aligned
+            for (int pl = 0; pl < NP; pl++) {                   // 8 bf16 = 4 taps x 2 ch, 8-byte aligned
                 const uint16_t* src = &patch[pl * PPLANE + abase + kh * PROW];
                 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
                 const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(src);
-                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(src + 4);
+                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(src + hi4);
                 a[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-            const bf16x8 w0 = __builtin_bit_cast(bf16x8, wv[kh][0]);
-            const bf16x8 w1 = __builtin_bit_cast(bf16x8, wv[kh][1]);
-            const bf16x8 w2 = __builtin_bit_cast(bf16x8, wv[kh][2]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[0], acc, 0, 0, 0);
+            if constexpr (NP == 3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][2], a[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][1], a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][1], a[0], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[0], acc, 0, 0, 0);
         }
         // stage the wave's 64 pixels x 16 channels per plane in LDS ([plane][row-of-pair][x 0..31][16 ch]) as 8-byte pieces,
         // then write 16 bytes per lane: one plane of one output row of the tile is 1 KiB of contiguous global memory
-        uint16_t* st = stage + wave * (3 * 64 * 16);
+        uint16_t* st = stage + wave * (NP * 64 * 16);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int dx = q >> 1, co0 = 8 * (q & 1) + 4 * hh;
-            uint16_t sa[4], sb[4], sc[4];
+            uint16_t sp[3][4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float v = acc[4 * q + i] + bv[q][i];
                 v = v > 0.f ? v : v * 0.1f;
-                split3(v, sa[i], sb[i], sc[i]);
+                if constexpr (NP == 3) split3(v, sp[0][i], sp[1][i], sp[2][i]);
+                else sp[0][i] = f32_to_bf16_rn(v);
             }
             const int e = (prow * 32 + 2 * pair + dx) * 16 + co0;
-            *reinterpret_cast<uint2*>(&st[e]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
-            *reinterpret_cast<uint2*>(&st[64 * 16 + e]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
-            *reinterpret_cast<uint2*>(&st[2 * 64 * 16 + e]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                *reinterpret_cast<uint2*>(&st[pl * 64 * 16 + e]) =
+                    make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS writes have landed
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int piece = q * 64 + lane;                    // 384 pieces of 16 B: [plane][row-of-pair][x][half]
+        for (int q = 0; q < 2 * NP; q++) {
+            const int piece = q * 64 + lane;                    // NP x 128 pieces of 16 B: [plane][row-of-pair][x][half]
             const int pl = piece >> 7, rem = piece & 127, pr = rem >> 6, xx = (rem >> 1) & 31, hf = rem & 1;
             const int y = y0 + mt * 2 + pr, x = x0 + xx;
             const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 64 + pr * 32 + xx) * 16 + hf * 8]);

@@ -9,36 +9,45 @@
 // MFMA step st covers taps 2st, 2st+1; lane group g reads the chunk (tap 2st + (g>>1), channel half g&1).
 // Split-bf16 x3 arithmetic as igemm_s3.h (six MFMAs per step).  Each wave owns one 16-channel half of the outputs
 // and keeps its weight fragments in VGPRs for the lifetime of the workgroup.
+//
+// Round 2: the operand chunk of a lane is read as two ds_read_b64 — even lane groups low half first, odd groups (the
+// other channel half, XH chunks further) high half first — instead of one ds_read_b128.  A ds_read_b128 serves lanes
+// {0-3,12-15,20-27} in one LDS cycle, i.e. parts of two 16-chunk windows that would have to start on the same bank to
+// not collide: every fragment read was 2-way bank-conflicted (profiles/r01_v7: conflict share 0.49-0.53 of the LDS
+// cycles).  With the halves swapped the 32 lanes of a b64 access cover all 64 banks exactly once.  Odd groups so hold
+// their channels in the order (4..7, 0..3); their weight fragments are packed to match (hnet_capi.hip).
+// NP = number of bf16 planes (3 = split-bf16, 1 = plain bf16 operands).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_s3.h"
 
 namespace hnet {
 
-template <int KS> struct PatchS2Cfg {
+template <int KS, int NP = 3> struct PatchS2Cfg {
     static constexpr int CIN = 16, COUT = 32, PAD = (KS - 1) / 2;
     static constexpr int TH = 8, TW = 16;                       // output tile
     static constexpr int RH = 2 * TH + KS - 2, RW = 2 * TW + KS - 2;
     static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, half)
     static constexpr int PLANE = RH * 2 * 2 * XH * 8;           // bf16 elements per plane
     static constexpr int NSTEP = (KS * KS + 1) / 2;             // two taps per 32-deep MFMA step
-    static constexpr int STAGE = 4 * 3 * 16 * 16;               // epilogue staging, elements
-    static constexpr int LDS_BYTES = (3 * PLANE + STAGE) * 2;
+    static constexpr int STAGE = 4 * NP * 16 * 16;              // epilogue staging, elements
+    static constexpr int LDS_BYTES = (NP * PLANE + STAGE) * 2;
 };
 
 typedef float f32x4_p __attribute__((ext_vector_type(4)));
+typedef short bf16x4_p __attribute__((ext_vector_type(4)));
 
 // in: S3 planes [3][B][H][W][16];  wfrag: [2 halves of cout][NSTEP][3][64 lanes] x 16 B;  out16: [3][B][H/2][W/2][32]
-template <int KS>
-__global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
+template <int KS, int NP>
+__global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
                                                             const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             uint16_t* __restrict__ out16, size_t o_plane, int H, int W,
                                                             int n_tiles, int reverse) {
-    typedef PatchS2Cfg<KS> C;
+    typedef PatchS2Cfg<KS, NP> C;
     constexpr int TH = C::TH, TW = C::TW, RH = C::RH, RW = C::RW, XH = C::XH, PLANE = C::PLANE, NSTEP = C::NSTEP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint16_t* img = reinterpret_cast<uint16_t*>(lds_raw);
-    uint16_t* stage = img + 3 * PLANE;
+    uint16_t* stage = img + NP * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -46,40 +55,29 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;              // = floor((H + 2*PAD - KS) / 2) + 1 for KS = 3, 5
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
 
-    u32x4 wv[NSTEP][3];
+    bf16x8 wv[NSTEP][3];
 #pragma unroll
     for (int st = 0; st < NSTEP; st++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) wv[st][pl] = wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane];
+        for (int pl = 0; pl < NP; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
     // operands swapped (weights as A): the MFMA yields the transposed tile, D row 4g + r = cout, column m = output pixel,
     // so that a lane stores four consecutive channels of one pixel with one 8-byte LDS write per plane (conv_b4_fused.h)
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
-    int tapoff[NSTEP];
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-        const int t = min(2 * st + (g >> 1), KS * KS - 1);      // the padding tap of the last step has zero weights
-        const int kh = t / KS, kw = t - kh * KS;
-        tapoff[st] = ((((kh * 2 + (kw & 1)) * 2) + (g & 1)) * XH + (kw >> 1)) * 8;
-    }
-    uint16_t* st_lds = stage + wave * (3 * 16 * 16);
-    // staging items of one region row: (plane, column, channel half), 3*RW*2 of them, ITEMS per lane
-    constexpr int ROW_ITEMS = 3 * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
+    // element offset of tap t inside a plane (channel half 0): compile-time constants, selected per lane group when used
+    // (a 13-entry per-lane table cost 13 VGPRs: with the 156 weight registers of the 5x5 kernel that was one wave per SIMD less)
+    auto tap_elem = [](int t) constexpr {
+        const int tt = t < KS * KS ? t : KS * KS - 1;            // the padding tap of the last step has zero weights
+        const int kh = tt / KS, kw = tt - kh * KS;
+        return (((kh * 2 + (kw & 1)) * 2) * XH + (kw >> 1)) * 8;
+    };
+    const int lane_off = (g & 1) * (XH * 8 + 4);                 // channel half of the group; odd groups: high 8 bytes first
+    const int second = 4 - 8 * (g & 1);                         // element offset from the first to the second 8-byte read
+    uint16_t* st_lds = stage + wave * (NP * 16 * 16);
+    // staging items of one region row: (plane, column, channel half), NP*RW*2 of them, ITEMS per lane
+    constexpr int ROW_ITEMS = NP * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
     constexpr int RB = KS == 5 ? 1 : 5;                         // region rows loaded per batch (register budget)
-    int it_pc[ITEMS], it_loff[ITEMS];
-    size_t it_goff[ITEMS];
-    uint32_t it_valid = 0;
-#pragma unroll
-    for (int q = 0; q < ITEMS; q++) {
-        const int item = lane + 64 * q;
-        const int it = item < ROW_ITEMS ? item : 0;
-        const int pl = it / (RW * 2), rem = it - pl * (RW * 2), pc = rem >> 1, hf = rem & 1;
-        it_pc[q] = pc;
-        it_goff[q] = pl * i_plane + hf * 8;
-        it_loff[q] = pl * PLANE + (((pc & 1) * 2 + hf) * XH + (pc >> 1)) * 8;
-        if (item < ROW_ITEMS) it_valid |= 1u << q;
-    }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // reverse: walk the tiles from the end of the batch.  The producer wrote this 440 MB input front to back and the
@@ -96,6 +94,25 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
         // (row index wave-uniform); its lanes walk the 3 planes x RW columns x 2 channel halves of the row with
         // per-lane offsets that were decomposed once, outside the tile loop.
         __syncthreads();
+        // per-lane decomposition of the staging items, formed per tile on an opaque lane id so that these 16 registers are
+        // not live across the MFMA phase (the 5x5 kernel holds 156 weight registers)
+        int it_pc[ITEMS], it_loff[ITEMS];
+        size_t it_goff[ITEMS];
+        uint32_t it_valid = 0;
+        {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const int item = lv + 64 * q;
+                const int it = item < ROW_ITEMS ? item : 0;
+                const int pl = it / (RW * 2), rem = it - pl * (RW * 2), pc = rem >> 1, hf = rem & 1;
+                it_pc[q] = pc;
+                it_goff[q] = pl * i_plane + hf * 8;
+                it_loff[q] = pl * PLANE + (((pc & 1) * 2 + hf) * XH + (pc >> 1)) * 8;
+                if (item < ROW_ITEMS) it_valid |= 1u << q;
+            }
+        }
         const uint16_t* inb = in + (size_t)b * H * W * 16;
         // loads are issued RB rows at a time into registers and consumed (zero select + ds_write) afterwards, so that
         // RB*ITEMS 16-byte loads per lane are in flight instead of one (a select next to its load serialises them)
@@ -138,42 +155,51 @@ __global__ __launch_bounds__(256) void conv_patch_s2_kernel(const uint16_t* __re
 #pragma unroll 1
         for (int j = 0; j < TH / 2; j++) {
             const int oy = (wave >> 1) + 2 * j;
-            const int base = ((2 * oy) * 2 * 2 * XH + m) * 8;     // row 2*oy, parity 0, half 0, column m
+            const int base = ((2 * oy) * 2 * 2 * XH + m) * 8 + lane_off;   // row 2*oy, parity 0, this group's half, column m
+            int gv = g;                                           // opaque per M-tile: the 13 tap addresses are formed next to their
+            asm volatile("" : "+v"(gv));                          // reads instead of being hoisted into 13 registers
+            const bool odd_tap = (gv >> 1) != 0;                  // lane groups 2, 3 take the odd tap of a step
             f32x4_p acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < NSTEP; st++) {
                 bf16x8 a[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const bf16x8*>(&img[pl * PLANE + base + tapoff[st]]);
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, wv[st][0]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, wv[st][1]);
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, wv[st][2]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[0], acc, 0, 0, 0);
+                for (int pl = 0; pl < NP; pl++) {
+                    const uint16_t* src = &img[pl * PLANE + base + (odd_tap ? tap_elem(2 * st + 1) : tap_elem(2 * st))];
+                    const bf16x4_p first = *reinterpret_cast<const bf16x4_p*>(src);
+                    const bf16x4_p other = *reinterpret_cast<const bf16x4_p*>(src + second);
+                    a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if constexpr (NP == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][2], a[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[0], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[0], acc, 0, 0, 0);
             }
             // D (transposed): row 4g + r = cout within the half, column m = output column
             {
-                uint16_t sa[4], sb[4], sc[4];
+                uint16_t sp[3][4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float v = acc[r] + bv[r];
                     v = v > 0.f ? v : v * 0.1f;
-                    split3(v, sa[r], sb[r], sc[r]);
+                    if constexpr (NP == 3) split3(v, sp[0][r], sp[1][r], sp[2][r]);
+                    else sp[0][r] = f32_to_bf16_rn(v);
                 }
-                *reinterpret_cast<uint2*>(&st_lds[(0 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
-                *reinterpret_cast<uint2*>(&st_lds[(1 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
-                *reinterpret_cast<uint2*>(&st_lds[(2 * 16 + m) * 16 + 4 * g]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    *reinterpret_cast<uint2*>(&st_lds[(pl * 16 + m) * 16 + 4 * g]) =
+                        make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const int Y = ty0 + oy;
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int piece = q * 64 + lane;                 // 96 pieces of 16 B: [plane][16 px][2 x 8 channels]
-                if (piece < 96) {
+            for (int q = 0; q < (NP * 32 + 63) / 64; q++) {
+                const int piece = q * 64 + lane;                 // NP x 32 pieces of 16 B: [plane][16 px][2 x 8 channels]
+                if (piece < NP * 32) {
                     const int pl = piece >> 5, rem = piece & 31, px = rem >> 1, hh = rem & 1;
                     const int X = tx0 + px;
                     const u32x4 v = *reinterpret_cast<const u32x4*>(&st_lds[(pl * 16 + px) * 16 + hh * 8]);

@@ -88,6 +88,8 @@ struct hnet_ctx {
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
     int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments)
+    int b4_cfg = 1;                    // fused-kernel geometry (s3_dispatch.h run_b4): 0 = 8x32 tiles / 512 threads, 1 = 7x32 / 256, two workgroups per CU (HNET_B4_CFG)
+    int n_planes = 3;                  // bf16 planes the matrix-core layers read and write: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
@@ -314,7 +316,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
                 const size_t cnt1 = c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
-                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s, c->b4_flags));
+                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s, c->b4_flags, c->b4_cfg, c->n_planes));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -324,12 +326,12 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
             if (c->s3 && l == 7 && c->b30_s3 && c->b30_frag && o16)
-                STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s));
+                STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s, c->n_planes));
             else if (c->use_patch && conv_is_patch_layer(l))
-                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s));
+                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
-                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page));
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes));
             else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
@@ -346,7 +348,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     float* hidden = c->hidden + P0 * c->n_local * 512;
     if (c->s3)
         STAGE(launch_heads_fc1_s3(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1_16, c->b1, hidden,
-                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev));
+                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes));
     else
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
     if (a.partial) {
@@ -437,7 +439,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
-    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3) return HNET_ERR_UNSUPPORTED;
+    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16) return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
     if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
         return HNET_ERR_INVALID_ARG;
@@ -448,10 +450,12 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
     hnet_ctx* c = new hnet_ctx();
     c->cfg = g;
-    c->s3 = g.precision == HNET_PREC_BF16X3;
+    c->s3 = g.precision == HNET_PREC_BF16X3 || g.precision == HNET_PREC_BF16;   // the bf16-matrix-core kernels; plain bf16 = their one-plane form
+    c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : 3;
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
+    c->b4_cfg = getenv("HNET_B4_CFG") ? (atoi(getenv("HNET_B4_CFG")) == 0 ? 0 : 1) : 1;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -534,7 +538,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                         if (t >= ks * ks) continue;
                         const int kh = t / ks, kw = t % ks;
                         for (int j = 0; j < 8; j++) {
-                            const int ci = 8 * (gg & 1) + j;
+                            // odd lane groups read their 16-byte chunk high half first (conv_patch_s2.h): element j = channel (j + 4) % 8 of the half
+                            const int ci = 8 * (gg & 1) + ((gg & 1) ? (j + 4) % 8 : j);
                             uint16_t sp[3];
                             split3(w->data[(((size_t)n * 16 + ci) * ks + kh) * ks + kw], sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * nstep + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
@@ -551,13 +556,15 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                 std::vector<uint16_t> fr((size_t)7 * 3 * 64 * 8, 0);
                 for (int st = 0; st < 7; st++)
                     for (int ln = 0; ln < 64; ln++) {
-                        const int n = ln & 15, t = 4 * st + (ln >> 4);
+                        const int n = ln & 15, gg = ln >> 4, t = 4 * st + gg;
                         if (t >= 25) continue;
                         const int kh = t / 5, kw = t % 5;
-                        for (int ci = 0; ci < 8; ci++) {
+                        for (int j = 0; j < 8; j++) {
+                            // odd lane groups read their 16-byte chunk high half first (conv_b4_fused.h): element j = channel (j + 4) % 8
+                            const int ci = (gg & 1) ? (j + 4) % 8 : j;
                             uint16_t sp[3];
                             split3(w->data[(((size_t)n * 8 + ci) * 5 + kh) * 5 + kw], sp[0], sp[1], sp[2]);
-                            for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + ci] = sp[pl];
+                            for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                         }
                     }
                 CK(hipMalloc((void**)&c->b41_frag, fr.size() * 2));
@@ -1143,19 +1150,19 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
         if (c->use_patch && conv_is_patch_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
-            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream));
+            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
         } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
-                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream));
+                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes));
         } else {
             HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
             if (layer == 7 && c->b30_s3 && c->b30_frag)     // the kernel the forward uses for block_3_0
-                HIPCHK(c, launch_conv_first_s3(d_b, c->b30_frag, c->conv_b[layer], p_out, n_out, batch, h, w, c->stream));
+                HIPCHK(c, launch_conv_first_s3(d_b, c->b30_frag, c->conv_b[layer], p_out, n_out, batch, h, w, c->stream, c->n_planes));
             else
                 HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
         }
-        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream, c->n_planes));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
@@ -1173,8 +1180,8 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
     HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
     HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, IMG_H, IMG_W, c->stream));
-    HIPCHK(c, launch_block4_fused(d_b, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0));
-    HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream));
+    HIPCHK(c, launch_block4_fused(d_b, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0, c->b4_cfg, c->n_planes));
+    HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
     return HNET_OK;
@@ -1222,10 +1229,10 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, t.alloc(&tmp, 3 * n));
         HIPCHK(c, launch_conv(13, c->x_in[3] + (size_t)pair * NPIX * 2, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
                               nullptr, 0, tmp, n));
-        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));   // three planes: written by the fp32-MFMA kernel
     } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
-                                             c->act_h[layer], c->act_w[layer], c->stream));
+                                             c->act_h[layer], c->act_w[layer], c->stream, (layer == 0 || layer == 3) ? 3 : c->n_planes));   // block_1_1 / block_2_1 come from the fp32-MFMA kernel: three planes
     else
         HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

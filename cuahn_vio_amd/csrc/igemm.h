@@ -231,7 +231,7 @@ template <> struct AccT<32> { typedef f32x16 type; };
 template <> struct AccT<16> { typedef f32x4 type; };
 
 template <class L, int BM, int BN, int WGM, int MF>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+static __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     constexpr int BK = IG_BK, BKP = IG_BKP;
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 }
 
 // out[m][n] = LeakyReLU(bias[n] + sum_z partial[z][m][n]), z ascending (fixed order => reproducible)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int k_split, int M, int N,
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int k_split, int M, int N,
                                                             const float* __restrict__ bias, float* __restrict__ out) {
     const size_t total4 = (size_t)M * N / 4;     // N is a multiple of 4 for every layer
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -168,7 +168,7 @@ __device__ __forceinline__ int s3_swz(int row, int chunk) {
 // epilogue of the transposed 16x16x32 tiles (shared by the register-staged and the LDS-DMA kernel): lane (m = lane&15,
 // g = lane>>4) holds channels 4g .. 4g+3 of GEMM row m of every 16x16 tile; (mw, nw) = origin of the wave's tile
 typedef float f32x4_m16 __attribute__((ext_vector_type(4)));
-template <int TM16, int TN16, bool OUT32>
+template <int TM16, int TN16, bool OUT32, int NP = 3>
 __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], const S3Params& p, uint16_t* st_wave, int mw, int nw, int lane) {
     // ---- epilogue of the transposed 16x16 tiles: lane (m = lane&15, g = lane>>4) holds channels n = 4g .. 4g+3 of GEMM row m
     typedef float f32x4_e __attribute__((ext_vector_type(4)));
@@ -209,24 +209,26 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
                     const int n = nw + sj * 32 + nloc;
                     f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
                     if (n < p.N) bv = *reinterpret_cast<const f32x4_e*>(p.bias + n);
-                    uint16_t sa[4], sb[4], sc[4];
+                    uint16_t sp[3][4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float v = acc16[i][j][e] + bv[e];
                         v = v > 0.0f ? v : v * 0.1f;
-                        split3(v, sa[e], sb[e], sc[e]);
+                        if constexpr (NP == 3) split3(v, sp[0][e], sp[1][e], sp[2][e]);
+                        else sp[0][e] = f32_to_bf16_rn(v);
                     }
                     const int chunk = (nloc >> 3) ^ ((em >> 1) & 3);
                     const int e0 = em * 32 + chunk * 8 + (nloc & 7);
-                    *reinterpret_cast<uint2*>(&st[e0]) = make_uint2((uint32_t)sa[0] | ((uint32_t)sa[1] << 16), (uint32_t)sa[2] | ((uint32_t)sa[3] << 16));
-                    *reinterpret_cast<uint2*>(&st[16 * 32 + e0]) = make_uint2((uint32_t)sb[0] | ((uint32_t)sb[1] << 16), (uint32_t)sb[2] | ((uint32_t)sb[3] << 16));
-                    *reinterpret_cast<uint2*>(&st[2 * 16 * 32 + e0]) = make_uint2((uint32_t)sc[0] | ((uint32_t)sc[1] << 16), (uint32_t)sc[2] | ((uint32_t)sc[3] << 16));
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++)
+                        *reinterpret_cast<uint2*>(&st[pl * 16 * 32 + e0]) =
+                            make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 const int mb = mw + i * 16, nb = nw + sj * 32;
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const int piece = q * 64 + lane;             // 3 planes x 16 rows x 4 chunks of 16 B
+                for (int q = 0; q < NP; q++) {
+                    const int piece = q * 64 + lane;             // NP planes x 16 rows x 4 chunks of 16 B
                     const int pl = piece >> 6, rem = piece & 63, row = rem >> 2, ch = rem & 3;
                     const int m = mb + row, n = nb + ch * 8;
                     const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 16 + row) * 32 + (ch ^ ((row >> 1) & 3)) * 8]);
@@ -237,11 +239,26 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
     }
 }
 
+// product group of the transposed 16x16x32 tiles (weights as A operand): six split-bf16 partial products, smallest first;
+// NP = 1: the single plain-bf16 product
+template <int NP>
+__device__ __forceinline__ f32x4_m16 s3_mfma16(f32x4_m16 acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+    if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], a[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[0], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[0], acc, 0, 0, 0);
+}
+
 // MF = MFMA shape: 32 -> v_mfma_f32_32x32x16_bf16; 16 -> v_mfma_f32_16x16x32_bf16 issued with the weights as A operand
 // (transposed tile: a lane holds four consecutive output channels of one GEMM row).  Same LDS traffic per flop; the
 // 16x16x32 form sustains a higher clock under the package power limit (MI355X_MICROARCH.md: 1.12-1.15x in MFMA-paced loops).
-template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1, int BKT = 32, int MF = 32>
-__global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
+// NP = number of bf16 planes: 3 = split-bf16, 1 = plain bf16 operands (HNET_PREC_BF16; 16x16x32 form only)
+template <class L, int BM, int BN, int WGM, bool OUT32, int NBUF = 1, int BKT = 32, int MF = 32, int NP = 3>
+static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int BK = BKT;                           // K-values per tile = CH chunks of 8
     constexpr int CH = BK / 8, RPP = 256 / CH;        // chunks per row, rows staged per pass of the 256 threads
     static_assert(BK % L::SEGMENT == 0, "K tile must be a whole number of loader segments");
@@ -254,12 +271,13 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int A_ROWS = (BM + RPP - 1) / RPP, B_ROWS = (BN + RPP - 1) / RPP;   // rows staged per thread and plane
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
+    static_assert(NP == 3 || (NP == 1 && MF == 16), "plain bf16 exists in the transposed 16x16x32 form");
 
     // [buf][plane][rows][32]; the epilogue reuses it as a store staging area
-    constexpr int SMEM_ELEMS = NBUF * 3 * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NBUF * 3 * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
+    constexpr int SMEM_ELEMS = NBUF * NP * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NBUF * NP * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
     uint16_t* As = smem;
-    uint16_t* Bs = smem + NBUF * 3 * TILE_A;
+    uint16_t* Bs = smem + NBUF * NP * TILE_A;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         for (int i = 0; i < A_ROWS; i++) {
             const size_t off = L::offset(p, rows[i], kp, aok[i]);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) areg[i][pl] = *reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane + off);
+            for (int pl = 0; pl < NP; pl++) areg[i][pl] = *reinterpret_cast<const u32x4*>(p.A + pl * p.a_plane + off);
             if constexpr (L::HAS_MASK) amask[i] = L::mask_byte(p, rows[i], kp < p.Kp ? kp : 0);
         }
 #pragma unroll
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
             bok[i] = wvalid[i] && kp < p.Kp;
             const uint16_t* src = bok[i] ? wsrc[i] + it * BK : p.Wp;
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) breg[i][pl] = *reinterpret_cast<const u32x4*>(src + pl * p.w_plane);
+            for (int pl = 0; pl < NP; pl++) breg[i][pl] = *reinterpret_cast<const u32x4*>(src + pl * p.w_plane);
         }
     };
     auto s_store = [&](int buf) {
@@ -332,10 +350,10 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                     }
                 }
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) {
+                for (int pl = 0; pl < NP; pl++) {
                     u32x4 v = aok[i] ? areg[i][pl] : z;
                     if constexpr (L::HAS_MASK) { v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3]; }
-                    *reinterpret_cast<u32x4*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, schunk)]) = v;
+                    *reinterpret_cast<u32x4*>(&As[(buf * NP + pl) * TILE_A + r * BK + s3_swz<CH>(r, schunk)]) = v;
                 }
             }
         }
@@ -344,8 +362,8 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
             const int r = srow + i * RPP;
             if (r < BN) {
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    *reinterpret_cast<u32x4*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, schunk)]) = bok[i] ? breg[i][pl] : z;
+                for (int pl = 0; pl < NP; pl++)
+                    *reinterpret_cast<u32x4*>(&Bs[(buf * NP + pl) * TILE_B + r * BK + s3_swz<CH>(r, schunk)]) = bok[i] ? breg[i][pl] : z;
             }
         }
     };
@@ -372,28 +390,21 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                 for (int i = 0; i < TM16; i++) {
                     const int r = wm * WM + i * 16 + r16;
 #pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                    for (int pl = 0; pl < NP; pl++)
+                        af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * NP + pl) * TILE_A + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
                 }
 #pragma unroll
                 for (int j = 0; j < TN16; j++) {
                     const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                    for (int pl = 0; pl < NP; pl++)
+                        bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * NP + pl) * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM16; i++)
 #pragma unroll
-                    for (int j = 0; j < TN16; j++) {
-                        // weights as A operand: D' row 4g + r = output channel, column = GEMM row; smallest partial products first
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][2], acc16[i][j], 0, 0, 0);
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][2], af[i][0], acc16[i][j], 0, 0, 0);
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc16[i][j], 0, 0, 0);
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][1], acc16[i][j], 0, 0, 0);
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][0], acc16[i][j], 0, 0, 0);
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc16[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < TN16; j++)   // weights as A operand: D' row 4g + r = output channel, column = GEMM row
+                        acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
             }
         } else
 #pragma unroll
@@ -404,14 +415,14 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                 const int r = wm * WM + i * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * 3 + pl) * TILE_A + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[(buf * NP + pl) * TILE_A + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 const int r = wn * WN + j * 32 + frow;
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * 3 + pl) * TILE_B + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * NP + pl) * TILE_B + r * BK + s3_swz<CH>(r, 2 * step + fh)]);
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     }
 
     if constexpr (MF == 16) {
-        s3_epilogue_m16<TM16, TN16, OUT32>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+        s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
         return;
     }
     // ---- epilogue: bias + LeakyReLU(0.1); D layout: col n = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -496,17 +507,18 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 // swizzle is applied on the SOURCE side (the lane fetches logical chunk phys ^ ((row>>2)&3)).  Padding taps and rows
 // beyond M/N read a zero page instead.  Conv loaders only (the heads apply a per-element mask while staging).
 // ---------------------------------------------------------------------------------------------
-template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE, int MF = 32>
-__global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
+template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE, int MF = 32, int NP = 3>
+static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     constexpr int BK = IG_BK;
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && !L::HAS_MASK, "DMA variant: 64-row multiples, no mask");
     constexpr int A_INST = BM / 64, B_INST = BN / 64;        // wave-instructions per wave, plane and stage (16 rows each)
-    constexpr int PER_STAGE = 3 * (A_INST + B_INST);         // DMA instructions a wave issues per K-tile
+    static_assert(NP == 3 || (NP == 1 && MF == 16), "plain bf16 exists in the transposed 16x16x32 form");
+    constexpr int PER_STAGE = NP * (A_INST + B_INST);        // DMA instructions a wave issues per K-tile
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
-    constexpr int STAGE = 3 * (TILE_A + TILE_B);             // bf16 elements per ring stage
+    constexpr int STAGE = NP * (TILE_A + TILE_B);            // bf16 elements per ring stage
     constexpr int SMEM_ELEMS = NSTAGE * STAGE > 4 * 3 * 32 * 32 ? NSTAGE * STAGE : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
 
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
             bool ok;
             const size_t off = L::offset(p, rows[i], it * BK + akp[i], ok);
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NP; pl++) {
                 const uint16_t* src = ok ? p.A + pl * p.a_plane + off : p.zeros;
                 uint16_t* dst = sbase + pl * TILE_A + (wave + 4 * i) * 16 * BK;      // wave-uniform; the DMA adds lane*16 B
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
@@ -568,9 +580,9 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
         for (int i = 0; i < B_INST; i++) {
             const bool ok = wvalid[i] && (it * BK < p.Kp);   // Kp is a multiple of 8 and chunks never straddle it
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NP; pl++) {
                 const uint16_t* src = ok ? wsrc[i] + it * BK + pl * p.w_plane : p.zeros;
-                uint16_t* dst = sbase + 3 * TILE_A + pl * TILE_B + (wave + 4 * i) * 16 * BK;
+                uint16_t* dst = sbase + NP * TILE_A + pl * TILE_B + (wave + 4 * i) * 16 * BK;
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                                  (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
             }
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     const int frow = lane & 31, fh = lane >> 5;
     auto compute = [&](int stage) {
         const uint16_t* As = smem + stage * STAGE;
-        const uint16_t* Bs = As + 3 * TILE_A;
+        const uint16_t* Bs = As + NP * TILE_A;
         if constexpr (MF == 16) {                              // one k32 step of 16x16x32 MFMAs, weights as A operand (igemm_s3_kernel)
             const int r16 = lane & 15, g16 = lane >> 4;
             bf16x8 af[TM16][3], bf[TN16][3];
@@ -588,25 +600,18 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
             for (int i = 0; i < TM16; i++) {
                 const int r = wm * WM + i * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, g16)]);
+                for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, g16)]);
             }
 #pragma unroll
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
+                for (int pl = 0; pl < NP; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
             }
 #pragma unroll
             for (int i = 0; i < TM16; i++)
 #pragma unroll
-                for (int j = 0; j < TN16; j++) {
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][2], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][2], af[i][0], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][1], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][0], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc16[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN16; j++) acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
             return;
         }
 #pragma unroll
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     __builtin_amdgcn_s_barrier();                            // all fragment reads done before the epilogue reuses the LDS
 
     if constexpr (MF == 16) {
-        s3_epilogue_m16<TM16, TN16, OUT32>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+        s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
         return;
     }
     const int col = lane & 31, rbase = 4 * fh;
@@ -684,10 +689,11 @@ __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 // heads preparation: (a) featS3 = split3(feat * scale) as three planes [3][B][5120]; (b) the keep bits of both heads'
 // first dropout for every local sample, one byte per 8 consecutive NHWC elements.  The hash is evaluated on the
 // reference's NCHW flatten index c*20 + pix (include/hnet_rng.h); stream 0 = mean head, 2 = uncertainty head.
-__global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
+static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
                                                          uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                          const uint64_t* __restrict__ seq_dev,
                                                          uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask) {
+    // (plain-bf16 mode reads plane 0 only; writing all three costs nothing measurable here)
     const size_t nfeat = (size_t)batch * 5120;
     const size_t nmask = (size_t)batch * n_local * 2 * 640;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -712,9 +718,9 @@ __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict
 }
 
 // S3 variant of splitk_reduce_kernel: out planes <- split3(LeakyReLU(bias + sum_z partial[z]))
-__global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const float* __restrict__ partial, int k_split, int M, int N,
+static __global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const float* __restrict__ partial, int k_split, int M, int N,
                                                                const float* __restrict__ bias, uint16_t* __restrict__ out16,
-                                                               size_t o_plane) {
+                                                               size_t o_plane) {   // three planes also in the plain-bf16 mode (plane 0 = bf16(v) is the one read)
     const size_t total = (size_t)M * N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const float* __re
 }
 
 // layout / format conversion helpers (operator-level entry points and debug read-back)
-__global__ void nchw_f32_to_nhwc_s3_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t o_plane,
+[[maybe_unused]] static __global__ void nchw_f32_to_nhwc_s3_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t o_plane,
                                            int batch, int c, int hw) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)batch * c * hw) return;
@@ -739,15 +745,16 @@ __global__ void nchw_f32_to_nhwc_s3_kernel(const float* __restrict__ in, uint16_
     split3(in[((size_t)b * c + ch) * hw + px], x, y, z);
     out[idx] = x; out[o_plane + idx] = y; out[2 * o_plane + idx] = z;
 }
-__global__ void nhwc_s3_to_nchw_f32_kernel(const uint16_t* __restrict__ in, size_t i_plane, float* __restrict__ out,
-                                           int batch, int c, int hw) {
+[[maybe_unused]] static __global__ void nhwc_s3_to_nchw_f32_kernel(const uint16_t* __restrict__ in, size_t i_plane, float* __restrict__ out,
+                                           int batch, int c, int hw, int n_planes) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)batch * c * hw) return;
     const int px = (int)(idx % hw);
     const long t = idx / hw;
     const int ch = (int)(t % c), b = (int)(t / c);
     const size_t src = ((size_t)b * hw + px) * c + ch;
-    out[idx] = (bf16_to_f32(in[src]) + bf16_to_f32(in[i_plane + src])) + bf16_to_f32(in[2 * i_plane + src]);
+    out[idx] = n_planes == 3 ? (bf16_to_f32(in[src]) + bf16_to_f32(in[i_plane + src])) + bf16_to_f32(in[2 * i_plane + src])
+                             : bf16_to_f32(in[src]);      // plain-bf16 mode: planes 1, 2 are never written by the NP = 1 kernels
 }
 
 }  // namespace hnet

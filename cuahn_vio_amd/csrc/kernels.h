@@ -23,27 +23,29 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
                        const float* bias, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0,
                        uint16_t* out16 = nullptr, size_t o_plane = 0);
 
+// n_planes (all bf16-matrix-core launchers): 3 = split-bf16 (fp32-grade), 1 = plain bf16 operands (only plane 0 is read / written)
 // split-bf16 (S3) convolution of the layers with Cin >= 8: in / out16 are [3][B][H][W][C] bf16 planes
 // (plane stride in elements), wplanes [3][Cout][Kp]; out32 != nullptr selects an fp32 [B][Ho][Wo][Cout] output
 bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr);
+                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
-                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s);
+                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes = 3);
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
-                                int h, int w, hipStream_t s);
+                                int h, int w, hipStream_t s, int n_planes = 3);
 hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */,
+                               int cfg = 1 /* 0: 8x32 tiles x 512 threads, 1: 7x32 tiles x 256 threads, two workgroups per CU */, int n_planes = 3);
 // dynamic-LDS limits of the kernels that use more than 64 KB; once per device (hnet_create)
 hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
-                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr);
+                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3);
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s);
-hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s);
+hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 
 // first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]
 hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,

@@ -1,0 +1,263 @@
+// s3_dispatch.h — tile / kernel-variant selection of the bf16-matrix-core layers, templated on the number of bf16 planes
+// NP (3 = split-bf16, the fp32-grade default; 1 = plain bf16 operands, HNET_PREC_BF16).  Included by kernels_conv.hip
+// (instantiates NP = 3) and kernels_conv_bf16.hip (NP = 1) so that the two sets of kernels compile in parallel.
+#pragma once
+#include "igemm.h"
+#include "conv_first.h"
+#include "igemm_s3.h"
+#include "conv_b4_fused.h"
+#include "conv_patch_s2.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace hnet {
+
+int splitk_min_iters(long tiles);        // kernels_conv.hip
+int splitk_target_blocks(long tiles);
+
+template <bool OUT32>
+static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hipStream_t s) {
+    if (split > 1) {
+        if (OUT32) {
+            const size_t total4 = (size_t)p.M * p.N / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out32);
+        } else {
+            const size_t total = (size_t)p.M * p.N;
+            hipLaunchKernelGGL(splitk_reduce_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out16, p.o_plane);
+        }
+    }
+    return hipGetLastError();
+}
+#define finish_split(p, split, ws, s) finish_split_impl<OUT32>(p, split, ws, s)
+
+template <class L, int BM, int BN, int WGM, bool OUT32, int NP>
+static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
+    const long tiles = (long)grid.x * grid.y;
+    const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
+    int split = 1;
+    if (ws && tiles < 192 && n_iter >= 8) {
+        split = (int)std::min<long>(std::min<long>(n_iter / splitk_min_iters(tiles), (splitk_target_blocks(tiles) + tiles - 1) / tiles), 64);
+        const size_t per = (size_t)p.M * p.N;
+        if ((size_t)split * per > ws_floats) split = (int)(ws_floats / per);
+        if (split < 2) split = 1;
+    }
+    p.k_split = split;
+    p.partial = ws;
+    grid.z = split;
+    // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel LDS-DMA layers -> wide taps only
+    static const int xcd = std::getenv("HNET_XCD_REMAP") ? std::atoi(std::getenv("HNET_XCD_REMAP")) : -1;
+    p.xcd_remap = xcd >= 0 ? xcd : (L::WIDE_TAPS ? 1 : 0);
+    // LDS-DMA ring (3 stages) by default: 2-8 % faster than register staging on the 64x64 tiles (HNET_S3_DMA=0 disables)
+    static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : 3;
+
+    if constexpr (NP == 1) {
+        // plain bf16 operands: the measured winners of the split-bf16 dispatch below, in their 16x16x32 form (the only form
+        // the NP = 1 kernels exist in), no experiment switches
+        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
+            if (dma && split == 1 && p.zeros) {
+                hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, 1>), grid, dim3(256), 0, s, p);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96)
+            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16, 1>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, 1>), grid, dim3(256), 0, s, p);
+        return finish_split(p, split, ws, s);
+    } else {
+        static const int nbuf = std::getenv("HNET_S3_NBUF") ? std::atoi(std::getenv("HNET_S3_NBUF")) : 1;   // experiments
+        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
+            if (dma && split == 1 && p.zeros) {
+                if constexpr (BM * BN <= 128 * 64) {
+                    if (dma == 4) { hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
+                }
+                // the 16x16x32 shape gains nothing on these short-K (288) 32-channel layers (0.110 vs 0.109 ms): 32x32x16 unless HNET_S3_MF16=2
+                static const int mf16d = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 0;
+                if (mf16d == 2) hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3>), grid, dim3(256), 0, s, p);
+                return hipGetLastError();
+            }
+        }
+        // MFMA shape 16x16x32 (transposed tiles) by default: -4..-9 % per layer against 32x32x16 at the same LDS traffic (HNET_S3_MF16=0: 32x32x16)
+        static const int mf16 = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 1;
+        // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
+        // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
+        static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
+        static const int t96 = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
+        const bool bk64_ok = BM != 96 || t96 == 6;               // 96-row tiles: 32-wide K tiles keep three workgroups per CU (61 KB of LDS at BK 64)
+        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
+            if (bk64 && mf16 && bk64_ok) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+            if constexpr (BM != 96) {
+                if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+            }
+        }
+        if constexpr (BM == 96) {     // 96-row tiles exist only in the 16x16x32 form (wave tile 48 x 32)
+            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
+        } else {
+            if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
+            else if (mf16) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
+        }
+        return finish_split(p, split, ws, s);
+    }
+}
+
+template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
+static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
+    typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
+    static const int tile = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;   // experiments
+    if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
+    else {
+        // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
+        const bool big_m = p.M >= 4096;
+        if constexpr (NP == 3) {
+            if (tile == 1) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn);
+            if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+            if constexpr (CIN == 128 && KS == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
+        }
+        if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
+        if constexpr (CIN == 128 && KS == 5) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+        return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
+    }
+}
+
+// block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
+// cfg 0: 8 x 32 tiles, one 512-thread workgroup per CU;  cfg 1: 7 x 32 tiles, two 256-thread workgroups per CU
+template <int TH1, int THREADS, int NP>
+static hipError_t run_b4(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
+                         size_t o_plane, int batch, hipStream_t s, int flags) {
+    typedef B4Cfg<TH1, THREADS, NP> C;
+    const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
+    const int per_cu = std::max(1, std::min(2, std::min(2048 / THREADS, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
+    const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
+    hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, (const u32x4*)w0frag,
+                       bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_block4_fused_np(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+                                  uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg) {
+#ifdef HNET_B4_ABLATE   // profiling build only (make FLAGS+=-DHNET_B4_ABLATE): HNET_B4_DBG drops phases of the kernel, results are wrong
+    static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
+    flags = (flags & 1) | ((dbg_env & 7) << 1);
+#else
+    flags &= 1;
+#endif
+    if (cfg == 0) return run_b4<8, 512, NP>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    return run_b4<7, 256, NP>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+}
+
+// block_3_0 on the bf16 matrix cores (conv_first.h): x_in fp32 [B][h][w][2] -> out16 S3 planes [3][B][h][w][16]
+template <int NP>
+hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
+                                   int h, int w, hipStream_t s) {
+    const int tx = (w + 31) / 32, ty = (h + 15) / 16;
+    hipLaunchKernelGGL(conv7_c2_s1_s3_kernel<NP>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, x_in, (const u32x4*)wfrag, bias, out16,
+                       o_plane, h, w, tx, ty);
+    return hipGetLastError();
+}
+
+// block_3_1 (5x5) / block_4_2 (3x3): 16 -> 32 channels, stride 2, from an LDS-resident patch (conv_patch_s2.h)
+template <int KS, int NP>
+static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfrag, const float* bias, uint16_t* out16,
+                            size_t o_plane, int batch, int h, int w, hipStream_t s) {
+    typedef PatchS2Cfg<KS, NP> C;
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
+    const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent, 2 workgroups per CU
+    // bit 0: reverse the 5x5 kernel (block_3_1), bit 1: reverse the 3x3 kernel (block_4_2)
+    static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
+    hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
+                       out16, o_plane, h, w, n_tiles, KS == 5 ? (rev & 1) : ((rev >> 1) & 1));
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
+                                const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s) {
+    if (layer == 8) return run_patch<5, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
+    if (layer == 15) return run_patch<3, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
+    return hipErrorInvalidValue;
+}
+
+// first FC of both heads on the bf16 matrix cores.  feat fp32 [B][5120]; w1planes [3][512][5120] bf16;
+// scratch: feat16 [3][B][5120] bf16 and mask [B][n_local][2][640] bytes (context-owned)
+template <int NP>
+hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
+                                  uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
+                                  uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
+                                  const uint64_t* seq_dev) {
+    const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
+    hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
+                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask);
+    S3Params p = {};
+    p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
+    p.out32 = hidden;
+    p.M = batch * n_local; p.N = 512; p.Kp = 5120;
+    p.mask = mask; p.n_local = n_local;
+    // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
+    if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn);
+    return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, ws, wsn);
+}
+
+template <int NP>
+hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
+                             size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
+                             float* ws, size_t wsn, const uint16_t* zeros) {
+    if (layer < 0 || layer >= 20 || !conv_is_s3_layer(layer)) return hipErrorInvalidValue;
+    const ConvDesc& d = kConvs[layer];
+    S3Params p = {};
+    p.A = in; p.a_plane = in_plane; p.Wp = wplanes; p.w_plane = w_plane; p.bias = bias;
+    p.out16 = out16; p.o_plane = o_plane; p.out32 = out32;
+    p.zeros = zeros;
+    p.H = h; p.W = w;
+    p.Ho = conv_out_dim(h, d.ks, d.stride);
+    p.Wo = conv_out_dim(w, d.ks, d.stride);
+    p.M = batch * p.Ho * p.Wo;
+    p.N = d.cout;
+    p.Kp = conv_padded_k(layer);
+    const bool o32 = out32 != nullptr;
+    switch (layer) {
+        case 1:  return run_conv_s3<128, 5, 2, 32, 128, false, NP>(p, s, ws, wsn);
+        case 2: case 5: case 11: case 18:
+            return o32 ? run_conv_s3<128, 3, 2, 32, 256, true, NP>(p, s, ws, wsn) : run_conv_s3<128, 3, 2, 32, 256, false, NP>(p, s, ws, wsn);
+        case 4:  return run_conv_s3<64, 5, 2, 32, 128, false, NP>(p, s, ws, wsn);
+        case 6: case 12: case 19:
+            return o32 ? run_conv_s3<256, 3, 2, 32, 256, true, NP>(p, s, ws, wsn) : run_conv_s3<256, 3, 2, 32, 256, false, NP>(p, s, ws, wsn);
+        case 8:  return run_conv_s3<16, 5, 2, 16, 32, false, NP>(p, s, ws, wsn);
+        case 9: case 16: return run_conv_s3<32, 3, 2, 32, 64, false, NP>(p, s, ws, wsn);
+        case 10: case 17: return run_conv_s3<64, 3, 2, 32, 128, false, NP>(p, s, ws, wsn);
+        case 14: return run_conv_s3<8, 5, 2, 8, 16, false, NP>(p, s, ws, wsn);
+        case 15: return run_conv_s3<16, 3, 2, 16, 32, false, NP>(p, s, ws, wsn);
+    }
+    return hipErrorInvalidValue;
+}
+
+// dynamic-LDS limits of the kernels that use more than 64 KB, for this NP; once per device
+template <int NP>
+hipError_t conv_kernels_init_device_np() {
+    hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
+    return e;
+}
+
+// the explicit instantiations live in kernels_conv.hip (NP = 3) and kernels_conv_bf16.hip (NP = 1)
+#define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
+    KW template hipError_t launch_block4_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*,     \
+                                                      size_t, int, hipStream_t, int, int);                                               \
+    KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
+    KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
+                                                    size_t, hipStream_t);                                                                \
+    KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \
+                                                      const float*, float*, uint16_t*, size_t, uint8_t*, hipStream_t, float*, size_t,    \
+                                                      const uint64_t*);                                                                  \
+    KW template hipError_t launch_conv_s3_np<NP>(int, const uint16_t*, size_t, int, int, int, const uint16_t*, size_t, const float*,     \
+                                                 uint16_t*, size_t, float*, hipStream_t, float*, size_t, const uint16_t*);               \
+    KW template hipError_t conv_kernels_init_device_np<NP>();
+
+}  // namespace hnet

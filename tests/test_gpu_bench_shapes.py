@@ -76,15 +76,25 @@ def _conv2(state, x):
     return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
 
 
+@pytest.mark.parametrize("cfg", [0, 1])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 5])
-def test_block4_fused_kernel_elementwise(blob, state, batch, reverse):
+def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg):
     """block4_fused_kernel (block_4_0 + block_4_1 in one launch, the 8-channel map never leaves LDS) against
     conv_lrelu(conv_lrelu(.)) of the oracle, every element of every pair, random inputs that are non-zero up to the image
     border (so the zero padding of BOTH layers matters), forward and reverse tile walk, batches that give every persistent
-    workgroup 1 tile (70, 210 tiles) and more than one (350 tiles over 256 workgroups)"""
+    workgroup 1 tile (70, 210 tiles) and more than one (350 tiles over 256 workgroups); both geometries of the kernel
+    (cfg 0: 8x32 tiles, 512 threads, one workgroup per CU; cfg 1: 7x32 tiles, 256 threads, two per CU: 80 / 240 / 400 tiles)"""
     from cuahn_vio_amd.homography_net import HnetEngine
-    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    old = os.environ.get("HNET_B4_CFG")
+    os.environ["HNET_B4_CFG"] = str(cfg)          # read by hnet_create
+    try:
+        eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    finally:
+        if old is None:
+            del os.environ["HNET_B4_CFG"]
+        else:
+            os.environ["HNET_B4_CFG"] = old
     rng = np.random.default_rng(100 + batch)
     x = rng.standard_normal((batch, 2, 224, 320)).astype(np.float32)
     x[:, :, :3, :] += 2.0          # make the borders stand out: a wrong border / padding rule cannot hide

@@ -1,0 +1,102 @@
+"""HNET_PREC_BF16 — plain bf16 operands on the matrix cores (BASELINE.json config 2 names "bf16").  A REPORTED mode
+(bf16 lands around 1e-2 px, outside the 1e-4 px parity gate): these tests pin what it is — the same
+kernels reading one bf16 plane, one MFMA per product, fp32 accumulation — and record its error; the loose bounds only
+catch a broken kernel, they are not a parity claim.  Reference arithmetic it approximates: fp32 conv (model_to_trace.py:7-15)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+PREC_BF16 = 1
+
+
+@pytest.fixture(scope="module")
+def eng_bf16(blob):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    e = HnetEngine(blob, variant="full", mc_samples=16, dropout_p=0.0, max_batch=4, precision=PREC_BF16)
+    yield e
+    e.close()
+
+
+def _bf16(x):
+    """round-to-nearest-even bf16 of a float32 array, as float32"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("layer", [1, 4, 6, 7, 8, 9, 10, 12, 14, 15, 19])
+def test_bf16_conv_is_the_conv_of_bf16_rounded_operands(eng_bf16, state, layer):
+    """every kernel family in its one-plane form: the result must be conv(bf16(x), bf16(w)) accumulated in fp32 — i.e. equal
+    to the ORACLE conv fed with bf16-rounded inputs and weights up to fp32 summation order, then rounded to bf16 on output"""
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    from oracle import pyoracle
+    name, cin, cout, k, s = CONV_LAYERS[layer]
+    blk = int(name[6])
+    h, w = {1: (28, 40), 2: (56, 80), 3: (112, 160), 4: (224, 320)}[blk]
+    for n2, _ci, _co, k2, s2 in CONV_LAYERS:
+        if n2 == name:
+            break
+        if n2[6] == name[6]:
+            p2 = (k2 - 1) // 2
+            h, w = (h + 2 * p2 - k2) // s2 + 1, (w + 2 * p2 - k2) // s2 + 1
+    rng = np.random.default_rng(300 + layer)
+    x = rng.standard_normal((2, cin, h, w)).astype(np.float32)
+    prefix = "model_last_block_list.0." if blk == 4 else "model_part1."
+    wgt, bias = state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"]
+    got = eng_bf16.op_conv(layer, x)
+    last_of_block = layer in (2, 6, 12, 19)            # fp32 output (feeds an FC), not rounded to bf16
+    for b in range(2):
+        ref = pyoracle.conv_lrelu(_bf16(x[b]), _bf16(wgt), bias, s)
+        if not last_of_block:
+            ref = _bf16(ref)
+        scale = max(1.0, float(np.abs(ref).max()))
+        # one bf16 ulp (2^-8 relative) where fp32 summation order moves a value across a rounding boundary
+        assert np.abs(got[b] - ref).max() < 2.0 ** -7 * scale, name
+        assert np.mean(np.abs(got[b] - ref) > 1e-5 * scale) < 0.02, name     # and that happens rarely
+
+
+def test_bf16_fused_block4_kernel(blob, state):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from oracle import pyoracle
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=PREC_BF16)
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 2, 224, 320)).astype(np.float32)
+    got = eng.op_block4_fused(x)
+    eng.close()
+    pre = "model_last_block_list.0."
+    for b in range(3):
+        y = _bf16(pyoracle.conv_lrelu(_bf16(x[b]), _bf16(state[pre + "block_4_0.0.weight"]), state[pre + "block_4_0.0.bias"], 1))
+        ref = _bf16(pyoracle.conv_lrelu(y, _bf16(state[pre + "block_4_1.0.weight"]), state[pre + "block_4_1.0.bias"], 2))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got[b] - ref).max() < 2.0 ** -6 * scale     # a flipped rounding of the intermediate propagates
+        assert np.mean(np.abs(got[b] - ref) > 1e-5 * scale) < 0.05
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_bf16_forward_error_is_reported(blob, oracle, name):
+    """the whole forward in plain bf16 against the reference goldens: REPORTED (printed and appended to the parity table),
+    bounded only loosely (a broken kernel gives O(10) px)"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    g, i1, i2, prior, btr = load_case(name)
+    eng = HnetEngine(blob, variant=str(g["variant"]), mc_samples=int(g["n_mc"]), dropout_p=float(g["p"]),
+                     mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0, max_batch=1, precision=PREC_BF16)
+    seq = int(g["pair_seq"]) if "pair_seq" in g else 0
+    mean, cov = eng.infer_batch(i1[None], i2[None], None if prior is None else prior[None], pair_seq0=seq)
+    eng.close()
+    d32 = float(np.abs(mean[0] - g["mean"]).max())
+    d64 = float(np.abs(mean[0] - g["mean64"]).max())
+    dc = float(np.abs(cov[0] - g["cov64"]).max() / np.abs(g["cov64"]).max())
+    print(f"{name} [plain bf16]: |hip-ref32|={d32:.2e} |hip-ref64|={d64:.2e} px, cov rel {dc:.2e}")
+    table = os.environ.get("HNET_PARITY_TABLE")
+    if table:
+        new = not os.path.exists(table)
+        with open(table, "a") as f:
+            if new:
+                f.write("case,precision,abs_err_vs_ref_fp32_px,abs_err_vs_ref_fp64_px,abs_err_vs_oracle_px,cov_rel_err_vs_ref_fp64\n")
+            f.write(f"{name},bf16,{d32:.3e},{d64:.3e},,{dc:.3e}\n")
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    assert d64 < 1.0          # px; expected ~1e-2..1e-1 (reported), a wrong kernel is off by many pixels

@@ -370,7 +370,7 @@ def test_error_behaviour(blob):
         HnetEngine(b"not a blob at all", variant="full")
     assert ei.value.status == 2
     with pytest.raises(HnetError) as ei:
-        HnetEngine(blob, variant="full", precision=1)       # plain bf16 is not a supported arithmetic
+        HnetEngine(blob, variant="full", precision=7)       # not an arithmetic mode
     assert ei.value.status == 6
 
 
