@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libhnet_hip.so")
+# HNET_LIB_PATH: another build of the SAME library (the -DHNET_B4_ABLATE profiling build of tools/b4_ablate.sh); never a fallback
+LIB_PATH = os.environ.get("HNET_LIB_PATH") or os.path.join(_PKG, "libhnet_hip.so")
 
 HNET_OK = 0
 PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2

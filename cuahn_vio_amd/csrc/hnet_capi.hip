@@ -140,12 +140,6 @@ struct hnet_ctx {
         return prev == o.prev && curr == o.curr && prior == o.prior && mean == o.mean && cov == o.cov && batch == o.batch && fmt == o.fmt; } };
     GraphKey g_key = {};
     hipGraphExec_t g_batch = nullptr;                     // hnet_time_batch_device on resident buffers (last signature)
-    // intra-batch concurrency: the batch is cut into n_streams chunks of independent pairs that run on separate HIP
-    // streams, so the tail of one chunk's layer overlaps the next layer of another chunk (frame pairs are independent)
-    int n_streams = 1;
-    std::vector<hipStream_t> aux;       // n_streams - 1 extra streams
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipEvent_t> ev_join;
 };
 
 namespace {
@@ -369,50 +363,17 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     return HNET_OK;
 }
 
-// Validates, then runs the batch as n_streams chunks of independent pairs on separate streams (fork / join with
-// events around the caller's stream `s`).  Results do not depend on the chunking (tests: slot invariance).
+// Validates and enqueues the forward of the whole batch on stream `s`.
+// (Round 1 had an HNET_STREAMS switch that cut the batch into chunks on separate HIP streams.  It never gave a speed-up and
+// the round-2 determinism test showed run-to-run differences of ~1e-3 px between concurrent chunks on the split-bf16 path
+// (tools/dbg_streams.py; single-stream runs are bit-reproducible), so the chunked mode was removed rather than shipped.)
 int forward(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     const hnet_config& g = c->cfg;
-    const int B = a.batch;
-    if (B < 1) return fail(c, HNET_ERR_INVALID_ARG, "batch < 1");
-    if (B > g.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
+    if (a.batch < 1) return fail(c, HNET_ERR_INVALID_ARG, "batch < 1");
+    if (a.batch > g.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
     if (g.use_prior && !a.prior) return fail(c, HNET_ERR_INVALID_ARG, "context uses a prior but none was given");
-    c->last_batch = B;
-    int ns = c->n_streams;
-    if (!c->prof_ev.empty() || B < 2 * 16) ns = 1;            // per-stage profiling and small batches: one stream
-    ns = std::min(ns, B / 16);
-    if (ns <= 1) return forward_chunk(c, a, s);
-    const size_t px = a.pix_fmt == HNET_PIX_U8 ? 1 : 4;
-    if (hipEventRecord(c->ev_fork, s) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipEventRecord(fork)");
-    const int per = (B + ns - 1) / ns;
-    for (int i = 0; i < ns; i++) {
-        const int b0 = i * per, nb = std::min(per, B - b0);
-        if (nb <= 0) break;
-        hipStream_t si = i == 0 ? s : c->aux[i - 1];
-        if (i > 0 && hipStreamWaitEvent(si, c->ev_fork, 0) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipStreamWaitEvent(fork)");
-        FwdArgs ch = a;
-        ch.use_ws = false;
-        ch.pair0 = a.pair0 + b0;
-        ch.batch = nb;
-        ch.seq0 = a.seq0 + (uint64_t)b0;
-        ch.prev = (const uint8_t*)a.prev + (size_t)b0 * NPIX * px;
-        ch.curr = (const uint8_t*)a.curr + (size_t)b0 * NPIX * px;
-        if (a.prior) ch.prior = a.prior + (size_t)b0 * 8;
-        if (a.mean) ch.mean = a.mean + (size_t)b0 * 8;
-        if (a.cov) ch.cov = a.cov + (size_t)b0 * 64;
-        if (a.err) ch.err = a.err + (size_t)b0 * NPIX;
-        if (a.err_u8) ch.err_u8 = a.err_u8 + (size_t)b0 * NPIX;
-        if (a.mean_s) ch.mean_s = a.mean_s + (size_t)b0 * c->n_local * 8;
-        if (a.logvar_s) ch.logvar_s = a.logvar_s + (size_t)b0 * c->n_local * 8;
-        if (a.h_part1) ch.h_part1 = a.h_part1 + (size_t)b0 * 9;
-        const int rc = forward_chunk(c, ch, si);
-        if (rc != HNET_OK) return rc;
-        if (i > 0) {
-            if (hipEventRecord(c->ev_join[i - 1], si) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipEventRecord(join)");
-            if (hipStreamWaitEvent(s, c->ev_join[i - 1], 0) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "hipStreamWaitEvent(join)");
-        }
-    }
-    return HNET_OK;
+    c->last_batch = a.batch;
+    return forward_chunk(c, a, s);
 }
 
 // Captures `body` (work enqueued on c->stream) into an executable graph.  Returns nullptr when capture is not possible;
@@ -472,19 +433,6 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
-    {
-        const char* e = getenv("HNET_STREAMS");
-        c->n_streams = e ? std::max(1, std::min(8, atoi(e))) : 1;
-        CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        for (int i = 1; i < c->n_streams; i++) {
-            hipStream_t st; hipEvent_t ev;
-            CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            c->aux.push_back(st);
-            c->ev_join.push_back(ev);
-        }
-    }
-
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
     for (int l = 0; l < 20; l++) {
         const ConvDesc& d = kConvs[l];
@@ -750,9 +698,6 @@ void hnet_destroy(hnet_ctx* c) {
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
-    for (auto st : c->aux) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (auto e : c->ev_join) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -134,32 +134,6 @@ def eng_s3(blob):
     e.close()
 
 
-def test_multi_stream_chunks_equal_single_stream(blob):
-    """HNET_STREAMS=2: the batch is cut into two chunks of independent pairs on two HIP streams (fork / join with events).
-    Concurrent chunks cannot share the split-K workspace, so the small-M layers sum in one pass instead of in K slices:
-    same math, other summation order (like batch 1 vs batch 5 in test_gpu_parity.py) - equal to 3e-5 px, and the
-    two-stream run itself is deterministic"""
-    from cuahn_vio_amd.homography_net import HnetEngine
-    prev, curr, prior = _batch(4500, 8, 48)
-    one = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=48)
-    m1, c1 = one.infer_batch(prev, curr, prior, pair_seq0=11)
-    one.close()
-    old = os.environ.get("HNET_STREAMS")
-    os.environ["HNET_STREAMS"] = "2"
-    try:
-        two = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=MC_SEED, max_batch=48)
-    finally:
-        if old is None:
-            del os.environ["HNET_STREAMS"]
-        else:
-            os.environ["HNET_STREAMS"] = old
-    m2, c2 = two.infer_batch(prev, curr, prior, pair_seq0=11)
-    m3, c3 = two.infer_batch(prev, curr, prior, pair_seq0=11)
-    two.close()
-    assert np.array_equal(m2, m3) and np.array_equal(c2, c3)
-    assert np.abs(m1 - m2).max() < 3e-5 and np.abs(c1 - c2).max() / np.abs(c1).max() < 1e-6
-
-
 def test_iekf_reruns_do_not_enter_the_timing_average(blob):
     """HomographyNet.cpp:189,245-251: `inference_counting` and the running average only see calls with num_of_inference == 0;
     IEKF re-runs (iteration > 0) advance the mask sequence number but not those statistics"""
