@@ -30,6 +30,7 @@
 //  * NP = number of bf16 planes: 3 = split-bf16 (fp32-grade), 1 = plain bf16 operands (HNET_PREC_BF16, reported mode).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "igemm_s3.h"
 
 namespace hnet {
@@ -89,7 +90,7 @@ __device__ __forceinline__ void b4_pack4(const f32x4_t& acc, const float (&bv)[4
 // flags bit 0: walk the tiles from the end of the batch.  Bits 1-3 exist only in a -DHNET_B4_ABLATE profiling build
 // (2 = drop phase-1 stores, 4 = drop phase-2 MFMAs, 8 = drop phase-1 MFMAs; wrong results).
 template <int TH1, int THREADS, int NP>
-__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
+__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel_v2(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
                                                                const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
                                                                const float* __restrict__ bias1, uint16_t* __restrict__ out16,
                                                                size_t o_plane, int n_tiles, int flags) {
@@ -294,6 +295,330 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
         }
+    }   // persistent tile loop
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (round 2): the same algorithm with the VECTOR-ISSUE cost taken out.
+//
+// rocprofv3 --pmc on v2 (profiles/r02_*): SQ_INSTS_VALU / SQ_INSTS_MFMA = 5.1, VALU busy 49 % of the SIMD cycles next to
+// 39 % MFMA busy.  On CDNA4 the two share the SIMD's vector issue (a 16x16x32 MFMA holds it for 8 of its 16 cycles, a VALU
+// instruction of one wave for 4: MI355X_MICROARCH.md, per-instruction cycle constants): 1476 MFMAs x 8 + 7470 VALU x 4 cycles
+// per tile and SIMD is the measured kernel time to within 25 %.  The kernel was issue-bound on address arithmetic, register
+// moves and epilogue math, not on the matrix pipe, the LDS or HBM (ablation, tools/b4_ablate.py: every component additive).
+//
+// So: * every M-tile a wave will ever process is known at compile time (tile = wave + WAVES * j), the j loops are fully
+//       unrolled and EVERY LDS address is one lane-invariant VGPR (set up once per workgroup) plus an instruction immediate
+//       (ds_read_b64 / ds_write_b64 offset:N) - zero address VALU in the MFMA loops.  The reads are inline asm because hipcc
+//       otherwise fuses pairs into ds_read2_b64 (8-bit offsets) and pays a v_add per plane and a v_mov per fragment half;
+//     * waits are counted by hand (lgkmcnt, two read groups in flight) with the fragment registers as "+v" operands of the
+//       wait statement so that no consumer can be scheduled above it (cdna_hip_programming.md §5.7 form (ii), rule 18);
+//     * bias = initial accumulator; LeakyReLU = max(v, 0.1 v); the three planes of a value pair come out of
+//       v_cvt_pk_bf16_f32 already packed (no shifts / ors to assemble the 8-byte pieces);
+//     * wave-uniform quantities (wave id, tile origin, output row base) live in SGPRs (readfirstlane), global stores use the
+//       SGPR-base + VGPR-offset form.
+namespace b4v3 {
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int IMM>
+__device__ __forceinline__ bf16x4 rd64(uint32_t addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset is 16 bits");
+    bf16x4 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int IMM>
+__device__ __forceinline__ void wr64(uint32_t addr, uint2 v) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset is 16 bits");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ u32x4 rd128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// wait until at most N LDS operations of this wave are outstanding; the six (a) / twelve (a, b) fragment halves named here
+// cannot be consumed above this statement
+template <int N>
+__device__ __forceinline__ void wait6(bf16x4 (&a)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "n"(N));
+}
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// two fp32 values -> their NP bf16 planes, each plane as one packed dword (lo = v0, hi = v1)
+template <int NP>
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
+    pl[0] = cvt_pk(v0, v1);
+    if constexpr (NP == 3) {
+        const float r0 = v0 - __builtin_bit_cast(float, pl[0] << 16), r1 = v1 - __builtin_bit_cast(float, pl[0] & 0xffff0000u);
+        pl[1] = cvt_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, pl[1] << 16), s1 = r1 - __builtin_bit_cast(float, pl[1] & 0xffff0000u);
+        pl[2] = cvt_pk(s0, s1);
+    }
+}
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
+
+}  // namespace b4v3
+
+template <int TH1, int THREADS, int NP>
+__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
+                                                                  const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
+                                                                  const float* __restrict__ bias1, uint16_t* __restrict__ out16,
+                                                                  size_t o_plane, int n_tiles, int flags) {
+    using namespace b4v3;
+    typedef B4Cfg<TH1, THREADS, NP> C;
+    constexpr int WAVES = C::WAVES, TW1 = C::TW1, RH = C::RH, RW = C::RW, PH0 = C::PH0, PW0 = C::PW0, PROW0 = C::PROW0;
+    constexpr int PPLANE = C::PPLANE, XH = C::XH, PLANE = C::PLANE, N_MT0 = C::N_MT0, N_MT1 = C::N_MT1;
+    constexpr int H0 = 224, W0 = 320, H1 = 112, W1 = 160;
+    constexpr int HW = WAVES / 2;                                     // region rows / output rows a wave advances per j
+    constexpr int N_REG = 2 * RH;                                     // regular phase-1 M-tiles (row, half)
+    constexpr int J1 = (N_REG + WAVES - 1) / WAVES, J2 = (N_MT1 + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint16_t* patch = reinterpret_cast<uint16_t*>(lds_raw);                    // [NP][PH0][PROW0] bf16
+    uint16_t* img = patch + NP * PPLANE;                                        // S3 image of the block_4_0 region
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+    const uint32_t img0 = lds0 + NP * PPLANE * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // SGPR: everything derived from it is wave-uniform
+    const int m = lane & 15, g = lane >> 4;
+    const int wrow = wave >> 1, whalf = wave & 1;
+
+    // ---- weights -> registers, once per (persistent) workgroup
+    bf16x8 w0[4][3], w1[7][3];
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) w0[st][pl] = __builtin_bit_cast(bf16x8, w0frag[(st * 3 + pl) * 64 + lane]);
+#pragma unroll
+    for (int st = 0; st < 7; st++)
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) w1[st][pl] = __builtin_bit_cast(bf16x8, w1frag[(st * 3 + pl) * 64 + lane]);
+    const int dx = g >> 1, co0 = 4 * (g & 1);            // phase 1: D row 4g + r = (dx, co0 + r)
+    f32x4_t bv, bv1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { bv[r] = bias0[co0 + r]; bv1[r] = bias1[4 * g + r]; }
+
+    // ---- lane-invariant LDS byte addresses (the per-tile part is an instruction immediate)
+    // phase 1, regular M-tile j of this wave: region row wrow + HW*j, half whalf, pixel pair 16*whalf + m;
+    // step st reads kernel row min(2st + (g>>1), 6) (row 7 has zero weights), taps 4(g&1)..+3
+    uint32_t p1a[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+        p1a[st] = lds0 + 2 * ((wrow + min(2 * st + (g >> 1), 6)) * PROW0 + (16 * whalf + m) * 4 + 8 * (g & 1));
+    // phase-1 store: pixel column 2m + dx of the half, channels co0..co0+3, region row wrow (+ HW*j as immediate)
+    const uint32_t st1a = img0 + 2 * (((wrow * 2 + dx) * XH + 16 * whalf + m) * 8 + co0);
+    // phase 2, M-tile j: output row wrow + HW*j, half whalf, column 16*whalf + m; tap t = 4*step + g; even groups read the
+    // low 8 bytes of the chunk first, odd groups the high 8 bytes (bank-conflict free, see the header); p2b = the other half
+    uint32_t p2a[7], p2b[7];
+#pragma unroll
+    for (int st = 0; st < 7; st++) {
+        const int t = 4 * st + g;
+        const int kh = t / 5, kw = t - kh * 5;
+        const int tap = t < 25 ? ((kh * 2 + (kw & 1)) * XH + (kw >> 1)) * 8 : 0;
+        p2a[st] = img0 + 2 * (((2 * wrow) * 2 * XH + 16 * whalf + m) * 8 + tap + 4 * (g & 1));
+        p2b[st] = p2a[st] ^ 8u;
+    }
+    // phase-2 output staging (wave private, overlays the dead patch): write 4 channels of pixel m, read back 16-byte pieces
+    const uint32_t st2w = lds0 + 2 * (wave * (NP * 16 * 16) + m * 16 + 4 * g);
+    const int pc0 = lane, pc1 = 64 + lane;                            // pieces [plane][16 px][2 halves of 8 channels]
+    const uint32_t st2r0 = lds0 + 2 * (wave * (NP * 16 * 16) + ((pc0 >> 5) * 16 + ((pc0 & 31) >> 1)) * 16 + (pc0 & 1) * 8);
+    const uint32_t st2r1 = lds0 + 2 * (wave * (NP * 16 * 16) + ((pc1 >> 5) * 16 + ((pc1 & 31) >> 1)) * 16 + (pc1 & 1) * 8);
+    const uint32_t gvo0 = (uint32_t)(((size_t)(pc0 >> 5) * o_plane + ((pc0 & 31) >> 1) * 16 + (pc0 & 1) * 8) * 2);   // byte offsets
+    const uint32_t gvo1 = (uint32_t)(((size_t)(pc1 >> 5) * o_plane + ((pc1 & 31) >> 1) * 16 + (pc1 & 1) * 8) * 2);
+
+    // patch pixels of the NEXT tile are prefetched into registers while the current tile computes
+    constexpr int PPT = (PH0 * PW0 + THREADS - 1) / THREADS;     // patch pixels per thread
+    float2 pre[PPT];
+    uint32_t pre_ok = 0;            // validity bits; applied when the registers are consumed, so the loads stay in flight
+    const bool reverse = (flags & 1) != 0;
+    auto tile_origin = [&](int t, int& b, int& by, int& bx) {
+        int bid = reverse ? n_tiles - 1 - t : t;
+        bx = bid % (W1 / TW1); bid /= (W1 / TW1);
+        by = bid % (H1 / TH1);
+        b = bid / (H1 / TH1);
+    };
+    auto patch_load = [&](int t) {
+        pre_ok = 0;
+        int b, by, bx;
+        tile_origin(t, b, by, bx);
+        const int Ry0 = 2 * by * TH1 - 2, Rx0 = 2 * bx * TW1 - 2;
+        const float* inb = x_in + (size_t)b * H0 * W0 * 2;
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = min(tid + q * THREADS, PH0 * PW0 - 1);
+            const int pr = i / PW0, pc = i - pr * PW0;
+            const int iy = Ry0 - 3 + pr, ix = Rx0 - 3 + pc;
+            const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
+            pre[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W0 + ix) * 2 : 0));   // unconditional load
+            pre_ok |= ok ? (1u << q) : 0u;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int b, by, bx;
+        tile_origin(tile, b, by, bx);
+        const int ty0 = by * TH1, tx0 = bx * TW1;
+        const int Ry0 = 2 * ty0 - 2, Rx0 = 2 * tx0 - 2;      // image coordinates of region pixel (0,0)
+
+        // ---- phase 0: prefetched patch -> bf16 planes in LDS
+        __syncthreads();                                     // previous tile's phase 2 is done with the LDS
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = tid + q * THREADS;
+            if (i < PH0 * PW0) {
+                const int pr = i / PW0, pc = i - pr * PW0;
+                const bool ok = (pre_ok >> q) & 1u;
+                uint32_t pk[3];
+                split_pair<NP>(ok ? pre[q].x : 0.f, ok ? pre[q].y : 0.f, pk);
+                const int e = pr * PROW0 + pc * 2;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = pk[pl];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
+
+        // ---- phase 1: block_4_0 over the region, into the S3 image.  Regular M-tiles: fully unrolled, immediate addressing.
+        // column validity of this lane's pixel (row validity is wave-uniform per M-tile)
+        const bool col_ok = (unsigned)(Rx0 + whalf * 32 + 2 * m + dx) < (unsigned)W0;
+        static_for<J1>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (wave + WAVES * j < N_REG) {                  // wave-uniform
+                constexpr int JR = HW * j * PROW0 * 2;       // bytes: HW region rows down
+                bf16x4 f[4][6];                              // [step][plane, half]; lgkmcnt is a 4-bit counter: at most two steps
+                auto rd = [&](auto sc) {                     // (12 reads) stay in flight behind the one being waited for
+                    constexpr int st = decltype(sc)::value;
+                    static_for<NP>([&](auto pc) {
+                        constexpr int pl = decltype(pc)::value;
+                        f[st][2 * pl] = rd64<JR + pl * PPLANE * 2>(p1a[st]);
+                        f[st][2 * pl + 1] = rd64<JR + pl * PPLANE * 2 + 8>(p1a[st]);
+                    });
+                };
+                f32x4_t acc = bv;
+                auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc = b4_mfma<NP>(acc, w, a);
+                };
+                constexpr int R = 2 * NP;                    // reads per step
+                rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
+                wait6<2 * R>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w0[0]);
+                rd(std::integral_constant<int, 3>{});
+                wait6<2 * R>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
+                wait6<1 * R>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
+                wait6<0>(f[3]); __builtin_amdgcn_sched_barrier(0); mm(f[3], w0[3]);
+                // epilogue: D (transposed) row 4g + r = (dx, co0 + r), column m = pixel pair.  Outside the image = block_4_1's zero padding.
+                const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = ok ? lrelu(acc[r]) : 0.f;
+                uint32_t pa[3], pb[3];
+                split_pair<NP>(v[0], v[1], pa);
+                split_pair<NP>(v[2], v[3], pb);
+                constexpr int JW = HW * j * 2 * XH * 16;     // bytes: HW image rows down
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    wr64<JW + pl * PLANE * 2>(st1a, make_uint2(pa[pl], pb[pl]));
+                });
+            }
+        });
+        // the pixel pairs of columns 64..66 (two per region row) form N_MT0 - N_REG more M-tiles: generic addressing, one per wave
+        for (int mt = N_REG + (WAVES - 1 - wave); mt < N_MT0; mt += WAVES) {
+            const int idx = (mt - N_REG) * 16 + m;
+            const int row = min(idx >> 1, RH - 1), pair = 32 + (idx & 1);
+            const int abase = row * PROW0 + pair * 4;
+            f32x4_t acc = bv;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) {
+                    const uint16_t* src = &patch[pl * PPLANE + abase + min(2 * st + (g >> 1), 6) * PROW0 + 8 * (g & 1)];
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(src + 4);
+                    a[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                acc = b4_mfma<NP>(acc, w0[st], a);
+            }
+            const int rrow = idx >> 1, rcol = 2 * (32 + (idx & 1)) + dx;
+            if (rrow < RH && rcol < RW) {
+                const int iy = Ry0 + rrow, ix = Rx0 + rcol;
+                const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
+                uint32_t pa[3], pb[3];
+                split_pair<NP>(ok ? lrelu(acc[0]) : 0.f, ok ? lrelu(acc[1]) : 0.f, pa);
+                split_pair<NP>(ok ? lrelu(acc[2]) : 0.f, ok ? lrelu(acc[3]) : 0.f, pb);
+                const int e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&img[pl * PLANE + e]) = make_uint2(pa[pl], pb[pl]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's asm ds_writes (the barrier's own wait does not count them)
+        __syncthreads();
+
+        // ---- phase 2: block_4_1 from the S3 image; fully unrolled, immediate addressing, three steps of reads in flight
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(out16) + (((size_t)b * H1 + ty0 + wrow) * W1 + tx0 + whalf * 16) * 32;
+        static_for<J2>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (wave + WAVES * j < N_MT1) {                  // wave-uniform
+                constexpr int JR = HW * j * 2 * (2 * XH * 16);   // bytes: HW output rows = 2 HW image rows down
+                bf16x4 f[7][6];
+                auto rd = [&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    static_for<NP>([&](auto pc) {
+                        constexpr int pl = decltype(pc)::value;
+                        f[st][2 * pl] = rd64<JR + pl * PLANE * 2>(p2a[st]);
+                        f[st][2 * pl + 1] = rd64<JR + pl * PLANE * 2>(p2b[st]);
+                    });
+                };
+                f32x4_t acc = bv1;
+                auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc = b4_mfma<NP>(acc, w, a);
+                };
+                constexpr int R = 2 * NP;                    // reads per step
+                rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
+                wait6<2 * R>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w1[0]);
+                rd(std::integral_constant<int, 3>{});
+                wait6<2 * R>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w1[1]);
+                rd(std::integral_constant<int, 4>{});
+                wait6<2 * R>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w1[2]);
+                rd(std::integral_constant<int, 5>{});
+                wait6<2 * R>(f[3]); __builtin_amdgcn_sched_barrier(0); mm(f[3], w1[3]);
+                rd(std::integral_constant<int, 6>{});
+                wait6<2 * R>(f[4]); __builtin_amdgcn_sched_barrier(0); mm(f[4], w1[4]);
+                wait6<1 * R>(f[5]); __builtin_amdgcn_sched_barrier(0); mm(f[5], w1[5]);
+                wait6<0>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
+                // D (transposed): row 4g + r = cout, column m = output pixel: 8 bytes (4 channels) per lane and plane
+                uint32_t pa[3], pb[3];
+                split_pair<NP>(lrelu(acc[0]), lrelu(acc[1]), pa);
+                split_pair<NP>(lrelu(acc[2]), lrelu(acc[3]), pb);
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    wr64<pl * 512>(st2w, make_uint2(pa[pl], pb[pl]));
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u32x4 o0 = rd128(st2r0), o1;
+                if constexpr (NP == 3) o1 = rd128(st2r1);
+                unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
+                __builtin_amdgcn_sched_barrier(0);
+                if (NP == 3 || lane < 32) *reinterpret_cast<u32x4*>(orow + gvo0) = o0;
+                if (NP == 3 && lane < 32) *reinterpret_cast<u32x4*>(orow + gvo1) = o1;
+            }
+        });
     }   // persistent tile loop
 }
 

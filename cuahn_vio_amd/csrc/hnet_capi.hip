@@ -416,7 +416,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
-    c->b4_cfg = getenv("HNET_B4_CFG") ? (atoi(getenv("HNET_B4_CFG")) == 0 ? 0 : 1) : 1;
+    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(3, atoi(getenv("HNET_B4_CFG")))) : 1;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \

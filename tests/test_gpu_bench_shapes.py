@@ -76,7 +76,7 @@ def _conv2(state, x):
     return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 5])
 def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg):
@@ -84,7 +84,8 @@ def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg):
     conv_lrelu(conv_lrelu(.)) of the oracle, every element of every pair, random inputs that are non-zero up to the image
     border (so the zero padding of BOTH layers matters), forward and reverse tile walk, batches that give every persistent
     workgroup 1 tile (70, 210 tiles) and more than one (350 tiles over 256 workgroups); both geometries of the kernel
-    (cfg 0: 8x32 tiles, 512 threads, one workgroup per CU; cfg 1: 7x32 tiles, 256 threads, two per CU: 80 / 240 / 400 tiles)"""
+    (cfg 0: 8x32 tiles, 512 threads, one workgroup per CU; cfg 1: 7x32 tiles, 256 threads, two per CU: 80 / 240 / 400 tiles; cfg 2, 3: the same
+    geometries in the v2 kernel kept for A/B)"""
     from cuahn_vio_amd.homography_net import HnetEngine
     old = os.environ.get("HNET_B4_CFG")
     os.environ["HNET_B4_CFG"] = str(cfg)          # read by hnet_create
