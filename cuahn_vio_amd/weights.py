@@ -190,3 +190,32 @@ def save_blob(path: str, state) -> None:
 def load_blob(path: str):
     with open(path, "rb") as f:
         return unpack_blob(f.read())
+
+
+def load_checkpoint(path: str) -> "OrderedDict[str, np.ndarray]":
+    """The reference's checkpoint format: ``torch.load(path)['state_dict']`` (trace_pytorch_model/model_to_trace.py:340-344,
+    the ``.pth.tar`` the training code writes; the file itself is a missing blob of the reference, .MISSING_LARGE_BLOBS).
+    Returns name -> float32 numpy array with the reference's own state_dict keys; a ``module.`` prefix (DataParallel) is
+    stripped.  torch is only needed here, never on the inference path."""
+    import torch
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    out = OrderedDict()
+    for k, v in sd.items():
+        k = k[len("module."):] if k.startswith("module.") else k
+        out[k] = np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32)
+    return out
+
+
+def convert_checkpoint(pth_path: str, blob_path: str) -> None:
+    """``x.pth.tar`` -> HNETW001 blob for hnet_create (strict: every expected tensor present with the reference's shape,
+    nothing else, as ``load_state_dict(strict=True)``)"""
+    save_blob(blob_path, load_checkpoint(pth_path))
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) != 3:
+        raise SystemExit("usage: python -m cuahn_vio_amd.weights <checkpoint.pth.tar> <out.hnw>")
+    convert_checkpoint(sys.argv[1], sys.argv[2])
+    print(f"wrote {sys.argv[2]}")

@@ -107,6 +107,8 @@ public:
     Eigen::Matrix<double, 8, 1> get_pred_mean() { return _pred_mean.template cast<double>(); }
     Eigen::Matrix<double, 8, 8> get_pred_Cov() { return _pred_Cov.template cast<double>(); }
     double get_latest_inference_time() { return hnet_latest_time(ctx_); }
+    // extension: wall time of the last network_inference call (ms), for the timing CSV of VioManager.cpp:304-311
+    double last_host_ms() { hnet_timing t; hnet_last_timing(ctx_, &t); return t.host_ms; }
 
     // HomographyNet.cpp:153-252
     void network_inference(Eigen::Matrix<double, 8, 1>& prior_4pt_offset_vec, int num_of_inference) {

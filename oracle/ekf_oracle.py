@@ -93,3 +93,95 @@ def propagate_mean(state, c_R_i, i_t_i2c, dt, w_hat, a_hat, gravity_mag=9.81):
     out["v"] = state["v"] + dt * (-skew(w_hat) @ state["v"] + a_hat + R.T @ np.array([0.0, 0.0, -gravity_mag]))
     out["p"] = state["p"] + dt * (-skew(w_hat) @ state["p"] + state["v"])
     return out
+
+
+# ---- covariance propagation: the state-transition and noise Jacobians of Propagator::predict_and_compute
+# (cuahn/src/state/Propagator.cpp:222-330), StateHelper::propagate_Cov (StateHelper.cpp:28-32), the noise matrix of the
+# Propagator constructor (Propagator.h:86-96).  Error-state order p q v ba bg ul bl br ur (3 each), noise order
+# (gyro, accel, accel walk, gyro walk, 4pt) x 3.
+def jr_theta(th):
+    """quat_ops.h:573-580 (no guard at |th| = 0 in the reference; the limit I is used here)"""
+    n = np.linalg.norm(th)
+    if n < 1e-12:
+        return np.eye(3)
+    S = skew(th)
+    return np.eye(3) - (1 - np.cos(n)) / n ** 2 * S + (n - np.sin(n)) / n ** 3 * S @ S
+
+
+def rotvec_2_ham_quat(rv):
+    n = np.linalg.norm(rv)
+    if n < 1e-300:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    return np.concatenate([[np.cos(0.5 * n)], np.sin(0.5 * n) * rv / n])
+
+
+def jacobians(state, c_R_i, i_t_i2c, dt, w_hat, gravity_mag=9.81):
+    """(F [27,27], Fw [27,15]) evaluated at the state BEFORE the mean is advanced (Propagator.cpp:211-220 then :222-330)"""
+    I3 = np.eye(3)
+    ez = np.array([[0.0, 0.0, 1.0]])
+    R = ham_quat_2_rot(state["q"])
+    p, v = state["p"], state["v"]
+    grav = np.array([0.0, 0.0, -gravity_mag])
+    muw = np.array([0.0, 0.0, -1.0])
+    wc = c_R_i @ w_hat                                           # :212
+    vc = c_R_i @ (v + skew(w_hat) @ i_t_i2c)                     # :213
+    muc = c_R_i @ R.T @ muw                                      # :214
+    dc = (R @ (p + i_t_i2c))[2]                                  # :215
+    F = np.zeros((27, 27))
+    Fw = np.zeros((27, 15))
+    P_, Q_, V_, BA, BG = 0, 3, 6, 9, 12
+    F[P_:P_ + 3, P_:P_ + 3] = I3 - dt * skew(w_hat)             # :224
+    F[P_:P_ + 3, V_:V_ + 3] = dt * I3
+    F[P_:P_ + 3, BG:BG + 3] = -dt * skew(p)
+    F[Q_:Q_ + 3, Q_:Q_ + 3] = ham_quat_2_rot(rotvec_2_ham_quat(w_hat * dt)).T    # :228
+    F[Q_:Q_ + 3, BG:BG + 3] = -dt * jr_theta(w_hat * dt)
+    F[V_:V_ + 3, Q_:Q_ + 3] = dt * skew(R.T @ grav)             # :231
+    F[V_:V_ + 3, V_:V_ + 3] = I3 - dt * skew(w_hat)
+    F[V_:V_ + 3, BA:BA + 3] = -dt * I3
+    F[V_:V_ + 3, BG:BG + 3] = -dt * skew(v)
+    F[BA:BA + 3, BA:BA + 3] = I3                                # :236-237
+    F[BG:BG + 3, BG:BG + 3] = I3
+    scalar = (ez @ vc).item() / dc                                # :240-241
+    J_f_df = -dt * I3                                           # :292
+    J_dc_p = ez @ R                                             # :293
+    J_dc_q = ez @ (-R @ skew(p + i_t_i2c))                      # :294
+    J_muc_q = c_R_i @ skew(R.T @ muw)                           # :295
+    J_vc_v, J_vc_bw, J_wc_bw = c_R_i, c_R_i @ skew(i_t_i2c), -c_R_i      # Propagator.h:192-194
+    for c in range(4):
+        pt = (CORNERS[c] + state["offset"][c]).reshape(3, 1)    # :217-220
+        mu = muc.reshape(3, 1)
+        vcv = vc.reshape(3, 1)
+        J_df_pt = (skew(wc) + vcv @ mu.T / dc - (ez @ skew(wc) @ pt).item() * I3 - pt @ ez @ skew(wc)
+                   - scalar * ((mu.T @ pt).item() * I3 + pt @ mu.T))          # :244-247
+        common = I3 - pt @ ez                                   # :248
+        J_df_dc = 1.0 / dc / dc * (mu.T @ pt).item() * (-common) @ vcv         # :249  [3,1]
+        J_df_vc = 1.0 / dc * (mu.T @ pt).item() * common          # :250
+        J_df_muc = 1.0 / dc * common @ vcv @ pt.T               # :251
+        J_df_wc = -common @ skew(pt.reshape(3))                 # :252
+        o = 15 + 3 * c
+        F[o:o + 3, P_:P_ + 3] = J_f_df @ J_df_dc @ J_dc_p       # :298-302
+        F[o:o + 3, Q_:Q_ + 3] = J_f_df @ (J_df_dc @ J_dc_q + J_df_muc @ J_muc_q)
+        F[o:o + 3, V_:V_ + 3] = J_f_df @ J_df_vc @ J_vc_v
+        F[o:o + 3, BG:BG + 3] = J_f_df @ (J_df_vc @ J_vc_bw + J_df_wc @ J_wc_bw)
+        F[o:o + 3, o:o + 3] = I3 + J_f_df @ J_df_pt
+    Fw[P_:P_ + 3, 0:3] = -F[P_:P_ + 3, BG:BG + 3]               # :322-328
+    Fw[P_:P_ + 3, 12:15] = F[P_:P_ + 3, V_:V_ + 3]
+    Fw[Q_:Q_ + 3, 0:3] = -F[Q_:Q_ + 3, BG:BG + 3]
+    Fw[V_:V_ + 3, 0:3] = -F[V_:V_ + 3, BG:BG + 3]
+    Fw[V_:V_ + 3, 3:6] = Fw[P_:P_ + 3, 12:15]
+    Fw[BA:BA + 3, 6:9] = Fw[P_:P_ + 3, 12:15]
+    Fw[BG:BG + 3, 9:12] = Fw[P_:P_ + 3, 12:15]
+    for c in range(4):                                          # :330-333
+        o = 15 + 3 * c
+        Fw[o:o + 3, 0:3] = -F[o:o + 3, BG:BG + 3]
+    return F, Fw
+
+
+def noise_q(sigma_w, sigma_a, sigma_wb, sigma_ab):
+    """Propagator.h:86-96 — order gyro, accel, accel random walk, gyro random walk, 4pt (1e-4)"""
+    return np.diag(np.repeat([sigma_w ** 2, sigma_a ** 2, sigma_ab ** 2, sigma_wb ** 2, 1.0e-4], 3))
+
+
+def propagate_cov(P, F, Fw, Q):
+    """StateHelper.cpp:28-32"""
+    return F @ P @ F.T + Fw @ Q @ Fw.T

@@ -47,8 +47,50 @@ static int prop_mode(const char* fin, const char* fout) {
     return 0;
 }
 
+// mode "jac": in: n, then per case p3 q4 v3 ba3 bg3 offset12 cov729 | c_R_i9 t3 dt w3 a3 qdiag15 ;
+//             out: F729 Fw405, then the state after hnet_ekf::propagate (p3 q4 v3 ba3 bg3 offset12 cov729)
+static int jac_mode(const char* fin, const char* fout) {
+    FILE* f = std::fopen(fin, "rb");
+    if (!f) return 2;
+    double n;
+    if (std::fread(&n, 8, 1, f) != 1) return 2;
+    std::vector<double> out;
+    for (int c = 0; c < (int)n; c++) {
+        std::vector<double> in(757 + 9 + 3 + 1 + 3 + 3 + 15);
+        if (std::fread(in.data(), 8, in.size(), f) != in.size()) return 3;
+        hnet_ekf::State s;
+        const double* d = in.data();
+        for (int i = 0; i < 3; i++) s.p[i] = *d++;
+        for (int i = 0; i < 4; i++) s.q[i] = *d++;
+        for (int i = 0; i < 3; i++) s.v[i] = *d++;
+        for (int i = 0; i < 3; i++) s.ba[i] = *d++;
+        for (int i = 0; i < 3; i++) s.bg[i] = *d++;
+        for (int i = 0; i < 12; i++) (&s.offset[0][0])[i] = *d++;
+        for (int i = 0; i < 729; i++) s.cov[i] = *d++;
+        hnet_ekf::Extrinsics e;
+        for (int i = 0; i < 9; i++) e.c_R_i[i] = *d++;
+        for (int i = 0; i < 3; i++) e.i_t_i2c[i] = *d++;
+        const double dt = *d++;
+        const double* w = d; d += 3;
+        const double* a = d; d += 3;
+        const double* q = d; d += 15;
+        std::vector<double> F(729), Fw(405);
+        hnet_ekf::propagate_jacobians(s, e, dt, w, F.data(), Fw.data());
+        out.insert(out.end(), F.begin(), F.end());
+        out.insert(out.end(), Fw.begin(), Fw.end());
+        hnet_ekf::propagate(s, e, dt, w, a, q);
+        put(out, s);
+    }
+    std::fclose(f);
+    FILE* g = std::fopen(fout, "wb");
+    std::fwrite(out.data(), 8, out.size(), g);
+    std::fclose(g);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 4 && std::string(argv[3]) == "prop") return prop_mode(argv[1], argv[2]);
+    if (argc >= 4 && std::string(argv[3]) == "jac") return jac_mode(argv[1], argv[2]);
     if (argc < 3) return 2;
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;

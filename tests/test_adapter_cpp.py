@@ -80,39 +80,52 @@ def test_adapter_feeds_the_iterated_ekf_update(blob, tmp_path):
     _build("iekf_demo.cpp", IEKF_BIN)
     wpath = tmp_path / "traced_model_3_blocks_using_prior.hnw"
     wpath.write_bytes(blob)
-    frames = np.stack([synth.make_pair(60 + i)[0] for i in range(4)])
+    n_frames = 14                                   # the filter only uses the network from the 11th image on (VioManager.cpp:257)
+    frames = np.stack([synth.make_pair(60 + i)[0] for i in range(n_frames)])
     fpath = tmp_path / "frames.u8"
     frames.tofile(fpath)
     env = dict(os.environ, HNET_MC_SEED="99", HNET_DROPOUT_P="0.05")
-    r = subprocess.run([IEKF_BIN, str(wpath), str(fpath), "4", "2"], capture_output=True, text=True, env=env, timeout=300)
+    csv_path = tmp_path / "traj_timing.txt"
+    r = subprocess.run([IEKF_BIN, str(wpath), str(fpath), str(n_frames), "2", str(csv_path)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
+    # the timing file in the reference's format (VioManager.cpp:98,304-311), parsed the way ov_eval does
+    from cuahn_vio_amd import timing_csv
+    names, trows = timing_csv.parse(str(csv_path))
+    assert [x.strip() for x in names] == list(timing_csv.COLUMNS) and len(trows) == n_frames - 1
+    assert all(len(t) == 6 and t[5] >= t[3] > 0.0 for t in trows)           # total >= network inference > 0 ms
     rows = [l.split() for l in r.stdout.splitlines() if l.startswith("STATE")]
-    assert [int(x[1]) for x in rows] == [1, 2, 3] and all(int(x[2]) == 2 for x in rows)
+    assert [int(x[1]) for x in rows] == list(range(1, n_frames))
+    assert [int(x[2]) for x in rows] == [2 if k + 1 > 10 else 0 for k in range(1, n_frames)]     # img_counter = k + 1 > 10
 
     eng = HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=99, max_batch=1)
-    st = dict(p=np.zeros(3), q=np.array([1.0, 0, 0, 0]), v=np.zeros(3), ba=np.zeros(3), bg=np.zeros(3), offset=np.zeros((4, 3)),
-              cov=np.diag([1e-4] * 15 + [0.0] * 12))
+    c_R_i = np.array([[-0.027256691772188965, -0.9996260641688061, 0.0021919370477445077],
+                      [-0.7139206120417471, 0.017931469899155242, -0.6999970157716363],
+                      [0.6996959571525168, -0.020644471939022302, -0.714142404092339]])
+    t_i2c = np.array([0.0070507, 0.0240435, 0.0057731])
+    w_hat, a_hat = np.array([0.02, -0.03, 0.05]), np.array([0.1, -0.05, 9.81])
+    Q = ekf_oracle.noise_q(0.00559017, 0.01118034, 8.94427e-04, 0.04472136)
+    st = dict(p=np.array([0.0, 0.0, 1.5]), q=np.array([1.0, 0, 0, 0]), v=np.array([0.4, -0.2, 0.0]), ba=np.zeros(3), bg=np.zeros(3),
+              offset=np.zeros((4, 3)), cov=np.diag([1e-4] * 15 + [0.0] * 12))
     seq = 0
     for x in rows:
         k = int(x[1])
-        for c in range(4):
-            st["offset"][c, 0] += 0.004 * (c + 1)
-            st["offset"][c, 1] -= 0.003 * (c + 1)
-            for d in range(3):
-                o = 15 + 3 * c + d
-                st["cov"][o, o] += 2.5e-3
-                st["cov"][d, o] = st["cov"][o, d] = 2e-5
-                st["cov"][6 + d, o] = st["cov"][o, 6 + d] = -1e-5
-        for it in range(2):
+        for _ in range(16):                          # Propagator::propagate_with_imu's loop: Jacobians at the old state, mean, covariance
+            F, Fw = ekf_oracle.jacobians(st, c_R_i, t_i2c, 0.002, w_hat)
+            cov = ekf_oracle.propagate_cov(st["cov"], F, Fw, Q)
+            st = ekf_oracle.propagate_mean(st, c_R_i, t_i2c, 0.002, w_hat, a_hat)
+            st["cov"] = cov
+        for it in range(2):                          # the network runs in every iteration (the mask sequence number advances), the update is gated
             prop = st["offset"][:, :2].reshape(8).copy()
             m, c = eng.infer_batch(frames[k - 1][None], frames[k][None], (prop * ekf_oracle.F_PIX).astype(np.float32)[None], pair_seq0=seq)
             seq += 1
-            st = ekf_oracle.update(st, m[0].astype(np.float64), c[0].astype(np.float64), prop, 10.0, it == 0)
+            if k + 1 > 10:
+                st = ekf_oracle.update(st, m[0].astype(np.float64), c[0].astype(np.float64), prop, 10.0, it == 0)
         st = ekf_oracle.reset_4pt_offset(st)
         got = np.array([float(v) for v in x[3:]])
-        want = np.concatenate([st["p"], st["q"], st["v"], np.diag(st["cov"])[:15]])
+        want = np.concatenate([st["p"], st["q"], st["v"], np.diag(st["cov"])[:15], [st["cov"][0, 7], st["cov"][4, 13]]])
         assert np.abs(got - want).max() < 1e-9, (k, np.abs(got - want).max())
-        assert np.abs(st["p"]).max() > 0 and (np.diag(st["cov"])[:15] > 0).all()
+    assert np.abs(st["p"]).max() > 0 and (np.diag(st["cov"])[:15] > 0).all()
+    eng.close()
 
 
 LAT_BIN = os.path.join(ROOT, "tests", "cpp", "adapter_latency.bin")

@@ -117,3 +117,32 @@ def test_product_path_never_touches_the_oracle():
                 assert "pyoracle" not in txt and "liboracle" not in txt and "hnet_oracle" not in txt, f
     for f in ("hnet.h", "hnet_rng.h"):
         assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().replace("CPU oracle", "")
+
+
+def test_pth_tar_checkpoint_round_trip(tmp_path, state, blob):
+    """the reference's checkpoint container — torch.save({'state_dict': ...}, 'x.pth.tar'), what
+    model_to_trace.py:340-344 loads — converts to exactly the blob hnet_create consumes; DataParallel's 'module.' prefix too"""
+    import subprocess
+    import sys
+
+    import torch
+    from cuahn_vio_amd import weights
+    sd = {k: torch.from_numpy(v.copy()) for k, v in state.items()}
+    p1 = tmp_path / "model_best.pth.tar"
+    torch.save({"epoch": 12, "state_dict": sd, "best_EPE": 0.5}, p1)
+    out = tmp_path / "w.hnw"
+    weights.convert_checkpoint(str(p1), str(out))
+    assert out.read_bytes() == blob
+    p2 = tmp_path / "dp.pth.tar"
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}}, p2)
+    out2 = tmp_path / "w2.hnw"
+    r = subprocess.run([sys.executable, "-m", "cuahn_vio_amd.weights", str(p2), str(out2)], capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == blob
+    # strictness: a missing or an extra tensor is an error, like load_state_dict(strict=True)
+    bad = dict(sd)
+    bad.pop("model_part1.fc_block_1.bias")
+    torch.save({"state_dict": bad}, tmp_path / "bad.pth.tar")
+    with pytest.raises(KeyError):
+        weights.convert_checkpoint(str(tmp_path / "bad.pth.tar"), str(tmp_path / "bad.hnw"))
