@@ -32,14 +32,16 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 #include "igemm_s3.h"
+#include "kernels.h"
 
 namespace hnet {
 
-template <int TH1_, int THREADS_, int NP_>
+template <int TH1_, int THREADS_, int NP_, bool DMA_ = false>
 struct B4Cfg {
     static constexpr int TH1 = TH1_, TW1 = 32, THREADS = THREADS_, WAVES = THREADS_ / 64, NP = NP_;
     static constexpr int RH = 2 * TH1 + 3, RW = 2 * TW1 + 3;   // block_4_0 region: (2 TH1 + 3) x 67
-    static constexpr int PH0 = RH + 6, PW0 = 76;             // input patch: (RH + 6) x 76 px (67 + 7 taps + pad)
+    static constexpr bool DMA = DMA_;
+    static constexpr int PH0 = RH + 6, PW0 = DMA_ ? 80 : 76;  // input patch: (RH + 6) x 76 px (67 + 7 taps + pad); 80 px = 20 chunks of 16 bytes per row for the LDS-DMA
     static constexpr int PROW0 = PW0 * 2;                    // bf16 elements per patch row (2 channels)
     static constexpr int PPLANE = PH0 * PROW0;               // elements per patch plane
     static constexpr int XH = 34;                            // chunks per (row, parity) of the S3 image (ceil(67/2) = 34)
@@ -50,6 +52,7 @@ struct B4Cfg {
     static constexpr int LDS_BYTES = (NP * PPLANE + NP * PLANE) * 2;
     static_assert(112 % TH1 == 0, "tiles cover the 112-row output exactly");
     static_assert(STAGE <= NP * PPLANE, "output staging fits in the patch area");
+    static_assert(PW0 % 4 == 0, "patch rows are whole 16-byte chunks");
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -368,13 +371,19 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
 
 }  // namespace b4v3
 
-template <int TH1, int THREADS, int NP>
-__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
+// DMA = true: x_in_v points to the padded bf16-plane input written by the prep kernel (kernels.h B4_*: [plane][B][B4_HP][B4_WP]
+// dwords, x_plane dwords per plane); the patch of a tile is copied global -> LDS by global_load_lds_dwordx4 (no registers, no
+// split, no bounds logic: the zero border is in memory), the copy of tile t+1 runs under phase 2 of tile t, and phase 2 stores
+// its 8-byte pieces straight to global memory (the patch area is busy, and 64 lanes x 8 bytes already cover whole 512-byte
+// runs).  DMA = false: fp32 NHWC input, split while staged (the round-2 first version of this kernel).
+template <int TH1, int THREADS, int NP, bool DMA = false>
+__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __restrict__ x_in_v, size_t x_plane, const u32x4* __restrict__ w0frag,
                                                                   const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
                                                                   const float* __restrict__ bias1, uint16_t* __restrict__ out16,
                                                                   size_t o_plane, int n_tiles, int flags) {
     using namespace b4v3;
-    typedef B4Cfg<TH1, THREADS, NP> C;
+    typedef B4Cfg<TH1, THREADS, NP, DMA> C;
+    const float* const x_in = reinterpret_cast<const float*>(x_in_v);
     constexpr int WAVES = C::WAVES, TW1 = C::TW1, RH = C::RH, RW = C::RW, PH0 = C::PH0, PW0 = C::PW0, PROW0 = C::PROW0;
     constexpr int PPLANE = C::PPLANE, XH = C::XH, PLANE = C::PLANE, N_MT0 = C::N_MT0, N_MT1 = C::N_MT1;
     constexpr int H0 = 224, W0 = 320, H1 = 112, W1 = 160;
@@ -435,10 +444,6 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
     const uint32_t gvo0 = (uint32_t)(((size_t)(pc0 >> 5) * o_plane + ((pc0 & 31) >> 1) * 16 + (pc0 & 1) * 8) * 2);   // byte offsets
     const uint32_t gvo1 = (uint32_t)(((size_t)(pc1 >> 5) * o_plane + ((pc1 & 31) >> 1) * 16 + (pc1 & 1) * 8) * 2);
 
-    // patch pixels of the NEXT tile are prefetched into registers while the current tile computes
-    constexpr int PPT = (PH0 * PW0 + THREADS - 1) / THREADS;     // patch pixels per thread
-    float2 pre[PPT];
-    uint32_t pre_ok = 0;            // validity bits; applied when the registers are consumed, so the loads stay in flight
     const bool reverse = (flags & 1) != 0;
     auto tile_origin = [&](int t, int& b, int& by, int& bx) {
         int bid = reverse ? n_tiles - 1 - t : t;
@@ -446,6 +451,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
         by = bid % (H1 / TH1);
         b = bid / (H1 / TH1);
     };
+    // !DMA: patch pixels of the NEXT tile are prefetched into registers while the current tile computes
+    constexpr int PPT = DMA ? 1 : (PH0 * PW0 + THREADS - 1) / THREADS;     // patch pixels per thread
+    float2 pre[PPT];
+    uint32_t pre_ok = 0;            // validity bits; applied when the registers are consumed, so the loads stay in flight
     auto patch_load = [&](int t) {
         pre_ok = 0;
         int b, by, bx;
@@ -462,7 +471,40 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
             pre_ok |= ok ? (1u << q) : 0u;
         }
     };
-    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+    // DMA: the patch [plane][PH0 rows][PW0 / 4 chunks of 16 bytes] is one linear run of NCH chunks in LDS; wave-instruction k
+    // (64 chunks) is issued by wave k % WAVES, lane l fetching chunk 64 k + l.  Its source offset from the tile's first chunk is
+    // lane invariant: set up once (IPW registers).  Patch pixel (0, 0) = image pixel (Ry0 - 3, Rx0 - 3) = padded-array dword
+    // (2 by TH1, 64 bx): a multiple of 4 dwords, so every chunk is a 16-byte aligned load.
+    constexpr int CPR = PW0 / 4, CPP = PH0 * CPR, NCH = NP * CPP, NINS = (NCH + 63) / 64, IPW = (NINS + WAVES - 1) / WAVES;
+    uint32_t dsrc[IPW];
+    uint32_t dma_ok = 0;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < IPW; i++) {
+            const int q = 64 * (wave + WAVES * i) + lane;
+            const int qq = q < NCH ? q : 0;
+            const int pl = qq / CPP, r = qq - pl * CPP, row = r / CPR, c = r - row * CPR;
+            dsrc[i] = (uint32_t)((size_t)pl * x_plane * 4 + ((size_t)row * B4_WP + 4 * c) * 4);
+            dma_ok |= q < NCH ? (1u << i) : 0u;
+        }
+    }
+    auto dma_issue = [&](int t) {
+        int b, by, bx;
+        tile_origin(t, b, by, bx);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(x_in_v) + (((size_t)b * B4_HP + 2 * by * TH1) * B4_WP + 64 * bx) * 4;
+#pragma unroll
+        for (int i = 0; i < IPW; i++) {
+            const int k = wave + WAVES * i;                  // wave-uniform
+            if (k < NINS && ((dma_ok >> i) & 1u))
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + dsrc[i]),
+                                                 (void __attribute__((address_space(3)))*)(lds_raw + k * 1024), 16, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        if constexpr (DMA) dma_issue(blockIdx.x);
+        else patch_load(blockIdx.x);
+    }
+    const uint32_t gv = (uint32_t)(m * 32 + g * 8);          // DMA: byte offset of this lane's 8-byte piece in a 16-pixel output run
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int b, by, bx;
@@ -470,23 +512,30 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
         const int ty0 = by * TH1, tx0 = bx * TW1;
         const int Ry0 = 2 * ty0 - 2, Rx0 = 2 * tx0 - 2;      // image coordinates of region pixel (0,0)
 
-        // ---- phase 0: prefetched patch -> bf16 planes in LDS
-        __syncthreads();                                     // previous tile's phase 2 is done with the LDS
+        if constexpr (DMA) {
+            // ---- phase 0: this wave's share of the patch copy has landed (it ran under phase 2 of the previous tile) ...
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // ... and everybody else's; the previous tile's phase 2 is done with the image
+            asm volatile("" ::: "memory");
+        } else {
+            // ---- phase 0: prefetched patch -> bf16 planes in LDS
+            __syncthreads();                                     // previous tile's phase 2 is done with the LDS
 #pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const int i = tid + q * THREADS;
-            if (i < PH0 * PW0) {
-                const int pr = i / PW0, pc = i - pr * PW0;
-                const bool ok = (pre_ok >> q) & 1u;
-                uint32_t pk[3];
-                split_pair<NP>(ok ? pre[q].x : 0.f, ok ? pre[q].y : 0.f, pk);
-                const int e = pr * PROW0 + pc * 2;
+            for (int q = 0; q < PPT; q++) {
+                const int i = tid + q * THREADS;
+                if (i < PH0 * PW0) {
+                    const int pr = i / PW0, pc = i - pr * PW0;
+                    const bool ok = (pre_ok >> q) & 1u;
+                    uint32_t pk[3];
+                    split_pair<NP>(ok ? pre[q].x : 0.f, ok ? pre[q].y : 0.f, pk);
+                    const int e = pr * PROW0 + pc * 2;
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = pk[pl];
+                    for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = pk[pl];
+                }
             }
+            __syncthreads();
+            if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
         }
-        __syncthreads();
-        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
 
         // ---- phase 1: block_4_0 over the region, into the S3 image.  Regular M-tiles: fully unrolled, immediate addressing.
         // column validity of this lane's pixel (row validity is wave-uniform per M-tile)
@@ -564,7 +613,13 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's asm ds_writes (the barrier's own wait does not count them)
-        __syncthreads();
+        if constexpr (DMA) {
+            __builtin_amdgcn_s_barrier();                    // raw barrier: a __syncthreads() would also drain the stores of phase 2
+            asm volatile("" ::: "memory");
+            if (tile + (int)gridDim.x < n_tiles) dma_issue(tile + gridDim.x);    // the patch is dead: the next tile's copy runs under phase 2
+        } else {
+            __syncthreads();
+        }
 
         // ---- phase 2: block_4_1 from the S3 image; fully unrolled, immediate addressing, three steps of reads in flight
         unsigned char* const obase = reinterpret_cast<unsigned char*>(out16) + (((size_t)b * H1 + ty0 + wrow) * W1 + tx0 + whalf * 16) * 32;
@@ -605,18 +660,23 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const float* _
                 uint32_t pa[3], pb[3];
                 split_pair<NP>(lrelu(acc[0]), lrelu(acc[1]), pa);
                 split_pair<NP>(lrelu(acc[2]), lrelu(acc[3]), pb);
-                static_for<NP>([&](auto pc) {
-                    constexpr int pl = decltype(pc)::value;
-                    wr64<pl * 512>(st2w, make_uint2(pa[pl], pb[pl]));
-                });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4 o0 = rd128(st2r0), o1;
-                if constexpr (NP == 3) o1 = rd128(st2r1);
                 unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
-                __builtin_amdgcn_sched_barrier(0);
-                if (NP == 3 || lane < 32) *reinterpret_cast<u32x4*>(orow + gvo0) = o0;
-                if (NP == 3 && lane < 32) *reinterpret_cast<u32x4*>(orow + gvo1) = o1;
+                if constexpr (DMA) {
+#pragma unroll
+                    for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(orow + (size_t)pl * o_plane * 2 + gv) = make_uint2(pa[pl], pb[pl]);
+                } else {
+                    static_for<NP>([&](auto pc) {
+                        constexpr int pl = decltype(pc)::value;
+                        wr64<pl * 512>(st2w, make_uint2(pa[pl], pb[pl]));
+                    });
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    u32x4 o0 = rd128(st2r0), o1;
+                    if constexpr (NP == 3) o1 = rd128(st2r1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (NP == 3 || lane < 32) *reinterpret_cast<u32x4*>(orow + gvo0) = o0;
+                    if (NP == 3 && lane < 32) *reinterpret_cast<u32x4*>(orow + gvo1) = o1;
+                }
             }
         });
     }   // persistent tile loop

@@ -88,7 +88,9 @@ struct hnet_ctx {
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
     int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments)
-    int b4_cfg = 1;                    // fused-kernel geometry (s3_dispatch.h run_b4): 0 = 8x32 tiles / 512 threads, 1 = 7x32 / 256, two workgroups per CU (HNET_B4_CFG)
+    int b4_cfg = 5;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging
+    uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
+    size_t x16_plane = 0;              // dwords per plane
     int n_planes = 3;                  // bf16 planes the matrix-core layers read and write: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
@@ -301,7 +303,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
         int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
         float* x = c->x_in[blk] + P0 * h * w * 2;
-        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hm : nullptr, 8 >> blk, x, B, s));
+        const bool b4_dma = blk == 3 && c->x16_b4 != nullptr;      // block 4 always warps (:261): the prep kernel writes the padded planes
+        uint32_t* x16 = b4_dma ? c->x16_b4 + P0 * B4_HP * B4_WP : nullptr;
+        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hm : nullptr, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes));
         const float* in = x;
         const uint16_t* in16 = nullptr;
         size_t in_plane = 0;
@@ -310,7 +314,8 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
                 const size_t cnt1 = c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
-                STAGE(launch_block4_fused(in, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16, MB * cnt1, B, s, c->b4_flags, c->b4_cfg, c->n_planes));
+                STAGE(launch_block4_fused(b4_dma ? (const void*)x16 : (const void*)in, c->x16_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16,
+                                          MB * cnt1, B, s, c->b4_flags, c->b4_cfg, c->n_planes));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -416,7 +421,9 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
-    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(3, atoi(getenv("HNET_B4_CFG")))) : 1;
+    // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
+    // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
+    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(5, atoi(getenv("HNET_B4_CFG")))) : 5;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -590,6 +597,11 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipHostMalloc((void**)&c->pinned_img[i], NPIX, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&c->ev_img[i], hipEventDisableTiming));
     }
+    if (c->fuse_b4 && b4_cfg_is_dma(c->b4_cfg)) {            // zeroed once: the border is block_4_0's zero padding and is never written again
+        c->x16_plane = MB * B4_HP * B4_WP;
+        CK(hipMalloc((void**)&c->x16_b4, 3 * c->x16_plane * 4));
+        CK(hipMemset(c->x16_b4, 0, 3 * c->x16_plane * 4));
+    }
     CK(hipMalloc((void**)&c->zero_page, 256));
     CK(hipMemset(c->zero_page, 0, 256));
     c->ws_floats = (size_t)16 << 20;
@@ -693,7 +705,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1125,7 +1137,18 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
     HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
     HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, IMG_H, IMG_W, c->stream));
-    HIPCHK(c, launch_block4_fused(d_b, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0, c->b4_cfg, c->n_planes));
+    const void* x_in = d_b;
+    size_t x_plane = 0;
+    if (b4_cfg_is_dma(c->b4_cfg)) {      // the DMA-staged kernel reads padded bf16 planes with a zero border
+        uint32_t* d_p = nullptr;
+        x_plane = (size_t)batch * B4_HP * B4_WP;
+        HIPCHK(c, t.alloc(&d_p, 3 * x_plane));
+        HIPCHK(c, hipMemsetAsync(d_p, 0, 3 * x_plane * 4, c->stream));
+        HIPCHK(c, launch_f32_nhwc_to_s3pad(d_b, d_p, x_plane, batch, c->n_planes, c->stream));
+        x_in = d_p;
+    }
+    HIPCHK(c, launch_block4_fused(x_in, x_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0,
+                                  c->b4_cfg, c->n_planes));
     HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
@@ -1172,7 +1195,14 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     if (c->fuse_b4 && layer == 13) {   // the fused kernel keeps block_4_0's output in LDS: recompute it unfused for inspection
         uint16_t* tmp = nullptr;
         HIPCHK(c, t.alloc(&tmp, 3 * n));
-        HIPCHK(c, launch_conv(13, c->x_in[3] + (size_t)pair * NPIX * 2, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
+        const float* xin = c->x_in[3] + (size_t)pair * NPIX * 2;
+        if (c->x16_b4) {                 // the block-4 input only exists as padded bf16 planes: their sum is the exact fp32 value
+            float* xf = nullptr;
+            HIPCHK(c, t.alloc(&xf, (size_t)NPIX * 2));
+            HIPCHK(c, launch_s3pad_to_f32_nhwc(c->x16_b4 + (size_t)pair * B4_HP * B4_WP, c->x16_plane, xf, 1, c->n_planes, c->stream));
+            xin = xf;
+        }
+        HIPCHK(c, launch_conv(13, xin, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
                               nullptr, 0, tmp, n));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));   // three planes: written by the fp32-MFMA kernel
     } else if (c->act16[layer])

@@ -35,9 +35,12 @@ hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int 
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes = 3);
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 int h, int w, hipStream_t s, int n_planes = 3);
-hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+// cfg (s3_dispatch.h): 0 / 1 fp32 NHWC input (8x32 tiles x 512 threads / 7x32 x 256, two workgroups per CU), 2 / 3 the older v2 kernel,
+// 4 / 5 the same geometries fed from the padded bf16 planes (B4_* above, x_plane dwords per plane) by LDS-DMA
+inline bool b4_cfg_is_dma(int cfg) { return cfg == 4 || cfg == 5; }
+hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */,
-                               int cfg = 1 /* 0: 8x32 tiles x 512 threads, 1: 7x32 tiles x 256 threads, two workgroups per CU */, int n_planes = 3);
+                               int cfg = 1, int n_planes = 3);
 // dynamic-LDS limits of the kernels that use more than 64 KB; once per device (hnet_create)
 hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
@@ -52,9 +55,18 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
                             uint64_t pair_seq0, const float* w1packed, const float* b1, float* hidden, hipStream_t s,
                             float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr);
 
+// Input of the fused block-4 kernel (conv_b4_fused.h, DMA staging): cat(img1, warp(img2, H)) as bf16 planes with a zero border,
+// [plane][B][B4_HP][B4_WP] dwords (lo half = channel 0, hi half = channel 1), pixel (u, v) at row v + B4_PADY, column u + B4_PADX.
+// The border (never written after the allocation was zeroed) IS the zero padding of block_4_0, and the patch of every tile
+// starts at a column that is a multiple of 4 dwords (16-byte chunks for the LDS-DMA) while staying an odd pixel column.
+constexpr int B4_PADX = 5, B4_PADY = 5, B4_WP = 336, B4_HP = 235;
+
 // cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
+// out_s3 != nullptr (k = 1 only): write the padded bf16 planes above instead (s3_plane = dwords per plane)
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
-                       int batch, hipStream_t s);
+                       int batch, hipStream_t s, uint32_t* out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3);
+hipError_t launch_f32_nhwc_to_s3pad(const float* x, uint32_t* out, size_t s3_plane, int batch, int n_planes, hipStream_t s);
+hipError_t launch_s3pad_to_f32_nhwc(const uint32_t* in, size_t s3_plane, float* x, int batch, int n_planes, hipStream_t s);
 
 // |warp(img2,H) - img1| * 255 -> float [B][224][320]  (and optional u8 clamp copy)
 hipError_t launch_undistort(const uint8_t* raw, int rows, int cols, int stride, const float* map_x, const float* map_y, uint8_t* out,

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include "kernels.h"
 #include "geom.h"
+#include "s3_format.h"
 #include "../../include/hnet.h"
 #include "../../include/hnet_rng.h"
 
@@ -177,9 +178,12 @@ __device__ __forceinline__ float warp_sample_box(const float* h, int u, int v, c
 // Lane = column of the tile, wave w = rows 8w .. 8w+7, eight pixels of one column per thread: the taps of a wave are
 // (nearly) consecutive LDS words, the K = 1 stores are 512 contiguous bytes per wave and row.  Pooling: the rows of a
 // window are summed in the thread, its columns across lanes (xor 1, 2, 4); lane % K == 0 stores.
-template <typename PIX, int K>
+// OUTS3 (K = 1 only): the block-4 input is written as bf16 planes with a zero border, [plane][B][B4_HP][B4_WP] dwords
+// (lo = img1, hi = warped img2 of one pixel), the layout the fused block-4 kernel stages by LDS-DMA (kernels.h B4_*)
+template <typename PIX, int K, bool OUTS3 = false>
 __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
-                                                              const float* __restrict__ H, float* __restrict__ out) {
+                                                              const float* __restrict__ H, float* __restrict__ out,
+                                                              uint32_t* __restrict__ out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3) {
     __shared__ float lut[256];                                          // only the per-pixel fallback path reads it
     __shared__ __attribute__((aligned(16))) float reg[WT_CAP];
     __shared__ __attribute__((aligned(16))) float a1[WT_H][WT_W];
@@ -218,7 +222,20 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
         for (int i = 0; i < 8; i++)
             if (fb & (1u << i)) w[i] = warp_taps_global<PIX>(i2, fx[i], fy[i], lut);
     }
-    if constexpr (K == 1) {
+    if constexpr (K == 1 && OUTS3) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint16_t a0, a1, a2, w0, w1, w2;
+            split3(a[i], a0, a1, a2);
+            split3(w[i], w0, w1, w2);
+            const size_t idx = ((size_t)b * B4_HP + (v0 + r0 + i + B4_PADY)) * B4_WP + u + B4_PADX;
+            out_s3[idx] = (uint32_t)a0 | ((uint32_t)w0 << 16);
+            if (n_planes == 3) {
+                out_s3[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
+                out_s3[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
+            }
+        }
+    } else if constexpr (K == 1) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
             *reinterpret_cast<float2*>(out + ((size_t)b * NPIX + (size_t)(v0 + r0 + i) * IMG_W + u) * 2) = make_float2(a[i], w[i]);
@@ -324,8 +341,62 @@ __global__ __launch_bounds__(256) void prep_k1_kernel(const PIX* __restrict__ im
     o[1] = make_float4(a[2], w[2], a[3], w[3]);
 }
 
+// fp32 NHWC [B][224][320][2] <-> the padded bf16-plane layout of the block-4 input (operator entry points, debug read-back and the
+// fallback when the images are not 16-byte aligned)
+__global__ void f32_nhwc_to_s3pad_kernel(const float* __restrict__ x, uint32_t* __restrict__ out, size_t s3_plane, int batch, int n_planes) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * NPIX) return;
+    const int b = (int)(i / NPIX), pix = (int)(i - (long)b * NPIX), v = pix / IMG_W, u = pix - v * IMG_W;
+    const float2 f = *reinterpret_cast<const float2*>(x + (size_t)i * 2);
+    uint16_t a0, a1, a2, w0, w1, w2;
+    split3(f.x, a0, a1, a2);
+    split3(f.y, w0, w1, w2);
+    const size_t idx = ((size_t)b * B4_HP + v + B4_PADY) * B4_WP + u + B4_PADX;
+    out[idx] = (uint32_t)a0 | ((uint32_t)w0 << 16);
+    if (n_planes == 3) {
+        out[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
+        out[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
+    }
+}
+__global__ void s3pad_to_f32_nhwc_kernel(const uint32_t* __restrict__ in, size_t s3_plane, float* __restrict__ x, int batch, int n_planes) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)batch * NPIX) return;
+    const int b = (int)(i / NPIX), pix = (int)(i - (long)b * NPIX), v = pix / IMG_W, u = pix - v * IMG_W;
+    const size_t idx = ((size_t)b * B4_HP + v + B4_PADY) * B4_WP + u + B4_PADX;
+    float lo = 0.f, hi = 0.f;
+    for (int pl = n_planes - 1; pl >= 0; pl--) {         // smallest plane first: the sum of the three planes is the exact fp32 value
+        const uint32_t d = in[pl * s3_plane + idx];
+        lo += bf16_to_f32((uint16_t)(d & 0xffffu));
+        hi += bf16_to_f32((uint16_t)(d >> 16));
+    }
+    *reinterpret_cast<float2*>(x + (size_t)i * 2) = make_float2(lo, hi);
+}
+hipError_t launch_f32_nhwc_to_s3pad(const float* x, uint32_t* out, size_t s3_plane, int batch, int n_planes, hipStream_t s) {
+    const long n = (long)batch * NPIX;
+    hipLaunchKernelGGL(f32_nhwc_to_s3pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, s3_plane, batch, n_planes);
+    return hipGetLastError();
+}
+hipError_t launch_s3pad_to_f32_nhwc(const uint32_t* in, size_t s3_plane, float* x, int batch, int n_planes, hipStream_t s) {
+    const long n = (long)batch * NPIX;
+    hipLaunchKernelGGL(s3pad_to_f32_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, s3_plane, x, batch, n_planes);
+    return hipGetLastError();
+}
+
 template <typename PIX>
-static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s) {
+static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s,
+                                uint32_t* out_s3, size_t s3_plane, int n_planes) {
+    if (out_s3) {     // block-4 input as padded bf16 planes (k = 1, with warp): the tiled kernel writes them directly
+        if (k != 1 || !H) return hipErrorInvalidValue;
+        if ((((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {
+            const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
+            hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, out_s3, s3_plane, n_planes);
+            return hipGetLastError();
+        }
+        // unaligned images: direct-gather kernel into the fp32 buffer, then convert
+        const long groups = (long)batch * (NPIX / 4);
+        hipLaunchKernelGGL(prep_k1_kernel<PIX>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, i1, i2, H, out, batch);
+        return launch_f32_nhwc_to_s3pad(out, out_s3, s3_plane, batch, n_planes, s);
+    }
     static const bool tiled = !(std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 0);   // 0: direct-gather kernels
     // measured at batch 256 (ms, tiled vs direct): K=1 0.085 / 0.094, K=2 0.076 / 0.080, K=4 0.068 / 0.062 -> tiled for K <= 2
     // (HNET_PREP_TILED=2 forces it for every K: the parity tests run both)
@@ -363,9 +434,9 @@ static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, in
 }
 
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
-                       int batch, hipStream_t s) {
-    if (pix_fmt == HNET_PIX_U8) return prep_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, H, k, out, batch, s);
-    return prep_dispatch<float>((const float*)img1, (const float*)img2, H, k, out, batch, s);
+                       int batch, hipStream_t s, uint32_t* out_s3, size_t s3_plane, int n_planes) {
+    if (pix_fmt == HNET_PIX_U8) return prep_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes);
+    return prep_dispatch<float>((const float*)img1, (const float*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes);
 }
 
 // ---------------------------------------------------------------------------------------------

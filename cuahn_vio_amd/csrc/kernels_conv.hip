@@ -141,10 +141,10 @@ hipError_t conv_kernels_init_device() {
     return e != hipSuccess ? e : conv_kernels_init_device_np<1>();
 }
 
-hipError_t launch_block4_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg, int n_planes) {
-    return n_planes == 1 ? launch_block4_fused_np<1>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg)
-                         : launch_block4_fused_np<3>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
+    return n_planes == 1 ? launch_block4_fused_np<1>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg)
+                         : launch_block4_fused_np<3>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
 }
 
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,

@@ -125,24 +125,25 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
 
 // block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
 // cfg 0: 8 x 32 tiles, one 512-thread workgroup per CU;  cfg 1: 7 x 32 tiles, two 256-thread workgroups per CU
-template <int TH1, int THREADS, int NP, bool V2 = false>
-static hipError_t run_b4(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
-                         size_t o_plane, int batch, hipStream_t s, int flags) {
-    typedef B4Cfg<TH1, THREADS, NP> C;
+template <int TH1, int THREADS, int NP, bool V2 = false, bool DMA = false>
+static hipError_t run_b4(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+                         uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
+    typedef B4Cfg<TH1, THREADS, NP, DMA> C;
     const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
     const int per_cu = std::max(1, std::min(2, std::min(2048 / THREADS, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
     const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
     if constexpr (V2)
-        hipLaunchKernelGGL((block4_fused_kernel_v2<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, (const u32x4*)w0frag,
-                           bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+        hipLaunchKernelGGL((block4_fused_kernel_v2<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, (const float*)x_in,
+                           (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
     else
-        hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, (const u32x4*)w0frag,
-                           bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+        hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP, DMA>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, x_plane,
+                           (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
     return hipGetLastError();
 }
 
+// x_in: fp32 NHWC [B][224][320][2] for cfg 0-3; the padded bf16 planes of kernels.h B4_* (x_plane dwords per plane) for cfg 4, 5
 template <int NP>
-hipError_t launch_block4_fused_np(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg) {
 #ifdef HNET_B4_ABLATE   // profiling build only (make FLAGS+=-DHNET_B4_ABLATE): HNET_B4_DBG drops phases of the kernel, results are wrong
     static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
@@ -152,10 +153,13 @@ hipError_t launch_block4_fused_np(const float* x_in, const void* w0frag, const f
 #endif
     // cfg 0 / 1: the v3 kernel (immediate addressing, hand-counted waits) in the two geometries; 2 / 3: the round-2 v2 kernel kept
     // for in-process A/B (tools/ab_bench.py) and as the reference implementation of the same arithmetic
-    if (cfg == 0) return run_b4<8, 512, NP>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 2) return run_b4<8, 512, NP, true>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 3) return run_b4<7, 256, NP, true>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    return run_b4<7, 256, NP>(x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    // 4 / 5: v3 with LDS-DMA staging from the padded bf16-plane input
+    if (cfg == 0) return run_b4<8, 512, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if (cfg == 2) return run_b4<8, 512, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if (cfg == 3) return run_b4<7, 256, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if (cfg == 4) return run_b4<8, 512, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if (cfg == 5) return run_b4<7, 256, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    return run_b4<7, 256, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
 // block_3_0 on the bf16 matrix cores (conv_first.h): x_in fp32 [B][h][w][2] -> out16 S3 planes [3][B][h][w][16]
@@ -249,6 +253,8 @@ template <int NP>
 hipError_t conv_kernels_init_device_np() {
     hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP, true>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
@@ -258,8 +264,8 @@ hipError_t conv_kernels_init_device_np() {
 
 // the explicit instantiations live in kernels_conv.hip (NP = 3) and kernels_conv_bf16.hip (NP = 1)
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
-    KW template hipError_t launch_block4_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*,     \
-                                                      size_t, int, hipStream_t, int, int);                                               \
+    KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
+                                                      uint16_t*, size_t, int, hipStream_t, int, int);                                    \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
     KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
                                                     size_t, hipStream_t);                                                                \
