@@ -78,6 +78,7 @@ struct ConvLoaderS3 {
     static constexpr int KP = TOTAL_SEGS * SEG;
     static constexpr int SEGMENT = SEG;
     static constexpr bool WIDE_TAPS = CIN >= 64;        // a 64-wide K tile stays inside one tap: 128 contiguous bytes per row and plane
+    template <int BK> static constexpr bool lean_ok() { return CIN % BK == 0 && (KS * CIN) % SEG == 0; }   // igemm_s3_lean_kernel: one tap per K-tile
     static_assert(IG_BK % SEG == 0 && SEG % 8 == 0 && CIN % 8 == 0, "16-byte chunks must stay inside one pixel");
     static_assert(RL % SEG == 0, "no padded segments for Cin >= 8 layers");
 
@@ -120,6 +121,7 @@ struct HeadLoaderS3 {
     static constexpr int SEGMENT = 32;
     static constexpr bool WIDE_TAPS = true;
     static constexpr bool HAS_MASK = true;
+    template <int BK> static constexpr bool lean_ok() { return true; }
     struct Row { int b; size_t mrow; bool valid; };
     __device__ static inline Row make_row(const S3Params& p, int m, int n0) {
         Row r;
@@ -497,6 +499,207 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
         igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
                                n0 + wn * WN, lane);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lean-staging variant of igemm_s3_kernel (round 2).  rocprofv3 --pmc on the round-1 kernels (profiles/r02_*): 3.3-3.8 VALU
+// instructions per MFMA — per K-tile and wave 110 (64x64 conv tiles) to 366 (heads) VALU for 48 / 96 MFMAs — and VALU busy +
+// MFMA busy = 87-98 % of the SIMD cycles with almost no overlap: on CDNA4 a VALU instruction and an MFMA share the SIMD's
+// vector issue (MI355X_MICROARCH.md, per-instruction cycle constants), so the GEMMs were bound by the ADDRESS ARITHMETIC of
+// their operand staging (im2col offsets, 64-bit pointer adds, zero selects on 16-byte registers, mask expansion), not by
+// the matrix pipe.  Here
+//   * operands are fetched with buffer loads: address = descriptor base (SGPRs) + per-row byte offset (one VGPR, set up
+//     once per workgroup) + a SCALAR offset that carries everything that changes with the K-tile and the plane (tap, channel
+//     block, plane stride).  A K-tile of these layers lies inside one filter tap (BK divides Cin), so the tap is wave-uniform;
+//   * padding taps and rows beyond M / N are an out-of-range offset: the buffer load returns zeros by itself (no selects);
+//   * the registers go to LDS with ds_write_b128 at lane-invariant addresses;
+//   * the heads' dropout mask of a chunk (one byte) becomes its 16-byte AND mask through a 4 KB table in LDS.
+// Same tiles, same K order and same MFMA sequence as igemm_s3_kernel<..., MF = 16>: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t S3_OOB = 0x80000000u;        // voffset >= num_records of every descriptor built here (all < 2 GB): reads as zero
+
+template <class L> struct LeanRow;              // per staged row: byte offset of its window origin (may be negative), origin, validity
+template <int CIN, int KS, int STRIDE, int SEG>
+struct LeanRow<ConvLoaderS3<CIN, KS, STRIDE, SEG>> {
+    typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
+    int off, iy0, ix0;
+    bool valid;
+    __device__ static inline LeanRow make(const S3Params& p, int m, int /*n0*/, int schunk) {
+        const typename L::Row r = L::make_row(p, m, 0);
+        LeanRow o;
+        o.valid = r.valid;
+        o.iy0 = r.iy0; o.ix0 = r.ix0;
+        o.off = (r.pix0 * CIN + schunk * 8) * 2;
+        return o;
+    }
+    // K-tile `it` of width BK: the filter tap it lies in (wave-uniform), the byte offset it adds to every row, validity of a row
+    struct Tap { int kh, kw, delta; };
+    template <int BK>
+    __device__ static inline Tap tap(const S3Params& p, int it) {
+        static_assert(CIN % BK == 0 && L::RL % SEG == 0, "a K-tile lies inside one tap");
+        const int kp = it * BK, t = kp / CIN, ci0 = kp - t * CIN;
+        Tap x;
+        x.kh = t / KS; x.kw = t - x.kh * KS;
+        x.delta = ((x.kh * p.W + x.kw) * CIN + ci0) * 2;
+        return x;
+    }
+    __device__ inline uint32_t voffset(const S3Params& p, const Tap& t) const {
+        const bool ok = valid && (unsigned)(iy0 + t.kh) < (unsigned)p.H && (unsigned)(ix0 + t.kw) < (unsigned)p.W;
+        return ok ? (uint32_t)(off + t.delta) : S3_OOB;
+    }
+};
+template <>
+struct LeanRow<HeadLoaderS3> {
+    int off;
+    uint32_t moff;          // byte offset of this row's mask bytes (plus the chunk) in p.mask
+    bool valid;
+    __device__ static inline LeanRow make(const S3Params& p, int m, int n0, int schunk) {
+        const HeadLoaderS3::Row r = HeadLoaderS3::make_row(p, m, n0);
+        LeanRow o;
+        o.valid = r.valid;
+        o.off = (r.b * 5120 + schunk * 8) * 2;
+        o.moff = (uint32_t)(r.mrow + schunk);       // rows beyond M alias row 0 (make_row): the byte is loaded unconditionally, their data is zero anyway
+        return o;
+    }
+    struct Tap { int delta; };
+    template <int BK>
+    __device__ static inline Tap tap(const S3Params&, int it) { return Tap{it * BK * 2}; }
+    __device__ inline uint32_t voffset(const S3Params&, const Tap& t) const { return valid ? (uint32_t)(off + t.delta) : S3_OOB; }
+};
+
+template <class L, int BM, int BN, int WGM, bool OUT32, int BKT = 64, int NP = 3>
+__global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
+    constexpr int BK = BKT;
+    constexpr int CH = BK / 8, RPP = 256 / CH;
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM16 = WM / 16, TN16 = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 32 == 0 && BK % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile shape");
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
+    constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
+    constexpr int LUT_ELEMS = L::HAS_MASK ? 256 * 8 : 0;          // 256 entries x 16 bytes
+    constexpr int TILES = NP * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NP * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[TILES + LUT_ELEMS];
+    uint16_t* As = smem;
+    uint16_t* Bs = smem + NP * TILE_A;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    int m0, n0;
+    s3_tile_origin(p, BM, BN, m0, n0);
+    const int srow = tid / CH, schunk = tid % CH;
+
+    if constexpr (L::HAS_MASK) {     // entry x of the table: 8 keep bits -> 8 x 16-bit lane masks
+        u32x4 e;
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = ((tid >> (2 * j)) & 1u) * 0xFFFFu | ((tid >> (2 * j + 1)) & 1u) * 0xFFFF0000u;
+        *reinterpret_cast<u32x4*>(&smem[TILES + tid * 8]) = e;
+    }
+
+    // descriptors: num_records only has to cover what is addressed; offsets >= S3_OOB read as zero
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7FFFFFF0, 0x00020000);
+
+    LeanRow<L> rows[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) rows[i] = LeanRow<L>::make(p, m0 + srow + i * RPP, n0, schunk);
+    uint32_t wvoff[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) {
+        const int n = n0 + srow + i * RPP;
+        wvoff[i] = n < p.N ? (uint32_t)((n * p.Kp + schunk * 8) * 2) : S3_OOB;
+    }
+    // lane-invariant LDS element offsets of the staged chunks
+    int a_lds[A_ROWS], b_lds[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) a_lds[i] = (srow + i * RPP) * BK + s3_swz<CH>(srow + i * RPP, schunk);
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) b_lds[i] = (srow + i * RPP) * BK + s3_swz<CH>(srow + i * RPP, schunk);
+
+    f32x4_m16 acc16[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; i++)
+#pragma unroll
+        for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
+    uint32_t amask[A_ROWS];
+    const int n_iter_total = (p.Kp + BK - 1) / BK;
+    const int it0 = (int)(((long)blockIdx.z * n_iter_total) / p.k_split);
+    const int n_iter = (int)(((long)(blockIdx.z + 1) * n_iter_total) / p.k_split) - it0;
+    const int a_pl = (int)(p.a_plane * 2), w_pl = (int)(p.w_plane * 2);     // plane strides in bytes (< 2 GB)
+
+    auto g_load = [&](int it) {          // `it` is wave-uniform: the tap and every scalar offset live in SGPRs
+        const typename LeanRow<L>::Tap t = LeanRow<L>::template tap<BK>(p, it);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            const uint32_t vo = rows[i].voffset(p, t);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                areg[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, vo, pl * a_pl, 0));
+            if constexpr (L::HAS_MASK) amask[i] = p.mask[rows[i].moff + (size_t)it * (BK / 8)];
+        }
+        const int ws = it * BK * 2;
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                breg[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, wvoff[i], ws + pl * w_pl, 0));
+    };
+    auto s_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            u32x4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if constexpr (L::HAS_MASK) mk = *reinterpret_cast<const u32x4*>(&smem[TILES + amask[i] * 8]);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                u32x4 v = areg[i][pl];
+                if constexpr (L::HAS_MASK) { v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3]; }
+                *reinterpret_cast<u32x4*>(&As[pl * TILE_A + a_lds[i]]) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<u32x4*>(&Bs[pl * TILE_B + b_lds[i]]) = breg[i][pl];
+    };
+
+    if constexpr (L::HAS_MASK) __syncthreads();      // the table is read by s_store
+    g_load(it0);
+    s_store();
+    __syncthreads();
+
+    const int r16 = lane & 15, g16 = lane >> 4;
+    for (int it = 0; it < n_iter; it++) {
+        if (it + 1 < n_iter) g_load(it0 + it + 1);
+#pragma unroll
+        for (int step = 0; step < BK / 32; step++) {
+            bf16x8 af[TM16][3], bf[TN16][3];
+#pragma unroll
+            for (int i = 0; i < TM16; i++) {
+                const int r = wm * WM + i * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN16; j++) {
+                const int r = wn * WN + j * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM16; i++)
+#pragma unroll
+                for (int j = 0; j < TN16; j++) acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the consumers of the prefetched registers behind the MFMAs (see igemm.h)
+        __syncthreads();                     // every wave has read tile `it`
+        if (it + 1 < n_iter) s_store();
+        __syncthreads();
+    }
+    s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

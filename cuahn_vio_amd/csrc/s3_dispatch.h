@@ -87,6 +87,20 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
         static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
         static const int t96 = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
         const bool bk64_ok = BM != 96 || t96 == 6;               // 96-row tiles: 32-wide K tiles keep three workgroups per CU (61 KB of LDS at BK 64)
+        // lean operand staging (igemm_s3.h: buffer loads with scalar tap offsets, no selects): same tiles, bit-identical results,
+        // a fraction of the VALU instructions per MFMA (HNET_S3_LEAN=0: the round-1 staging)
+        static const int lean = std::getenv("HNET_S3_LEAN") ? std::atoi(std::getenv("HNET_S3_LEAN")) : 1;
+        if (lean && mf16) {
+            if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
+                if constexpr (L::template lean_ok<64>()) {
+                    if (bk64) { hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
+                }
+            }
+            if constexpr (L::template lean_ok<32>() && BM != 96) {
+                hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
+                return finish_split(p, split, ws, s);
+            }
+        }
         if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
             if (bk64 && mf16 && bk64_ok) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
             if constexpr (BM != 96) {
