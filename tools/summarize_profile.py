@@ -58,15 +58,19 @@ if len(sys.argv) > 2:
         if k not in best or g > best[k][0]:
             best[k] = (g, {n: sum(v) / len(v) for n, v in cs.items()}, len(next(iter(cs.values()))))
     with open(os.path.join(dst, tag + "_pmc_mfma_lds.csv"), "w") as out:
-        out.write("# rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE (tools/pmc_pass.sh), batch 256, averages over the full-batch launches.\n")
+        out.write("# rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (tools/profile_round.sh), batch 256, averages over the full-batch launches.\n")
         out.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); lds_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES; conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n")
         cw = csv.writer(out)
-        cw.writerow(["kernel", "grid_threads", "launches", "mfma_busy", "lds_busy", "lds_conflict_share", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"])
+        out.write("# valu_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (4 SIMDs x SQ_BUSY_CU_CYCLES); valu_per_mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA (wave instructions).\n")
+        cw.writerow(["kernel", "grid_threads", "launches", "mfma_busy", "lds_busy", "lds_conflict_share", "valu_busy", "valu_per_mfma", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"])
         for k, (g, c, n) in sorted(best.items(), key=lambda kv: -kv[1][1].get("SQ_BUSY_CU_CYCLES", 0)):
             busy = c.get("SQ_BUSY_CU_CYCLES", 0)
             if busy <= 0 or "rocclr" in k:
                 continue
             lds = c.get("SQ_LDS_IDX_ACTIVE", 0)
             cw.writerow([k, g, n, round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * busy), 4), round(lds / busy, 4),
-                         round(c.get("SQ_LDS_BANK_CONFLICT", 0) / lds, 4) if lds else 0, int(busy), int(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))])
+                         round(c.get("SQ_LDS_BANK_CONFLICT", 0) / lds, 4) if lds else 0,
+                         round(c.get("SQ_ACTIVE_INST_VALU", 0) / busy, 4) if "SQ_ACTIVE_INST_VALU" in c else "",
+                         round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"], 2) if c.get("SQ_INSTS_MFMA") else "",
+                         int(busy), int(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))])
 print("profiles/ updated for", tag)
