@@ -321,4 +321,117 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// block_1_1 (2 -> 128 @28x40 -> 14x20) and block_2_1 (2 -> 64 @56x80 -> 28x40): 7x7, stride 2, Cin 2, on the bf16 matrix
+// cores (round 2).  In round 1 these two layers were the last ones on the fp32 MFMA (1/16 of the bf16 rate): 0.9 % of the
+// network's MACs took 4.8 % of the step (block_1_1 0.046 ms, block_2_1 0.082 ms, 14.9 VALU instructions per MFMA in the
+// generic im2col GEMM).  Here a workgroup stages the input band of TH output rows (all columns) ONCE into LDS as bf16 planes
+// and every wave multiplies all the band's pixels with ITS slice of output channels, whose weights stay in registers:
+//   M-tile = 16 consecutive output pixels of the band (row major), lane column m = pixel;
+//   K = (kh, kw' 0..7, ci): a kernel row is 8 taps x 2 channels = 16 values (tap 7 has zero weights), two rows per
+//   32-deep step, four steps (row 7 zero): lane group g reads row 2 st + (g>>1), taps 4 (g&1) .. + 3 = 16 contiguous bytes
+//   of the patch (8-byte aligned: the first tap of output column ox is input column 2 ox);
+//   N = 16 output channels per MFMA, weights as A operand (transposed tile: a lane holds 4 channels of one pixel).
+// wfrag: [COUT / 16 n-tiles][4 steps][3 planes][64 lanes] x 16 B (pack in hnet_capi.hip).  out16: S3 planes [B][HO][WO][COUT].
+// ---------------------------------------------------------------------------------------------
+template <int COUT, int HO, int WO, int TH, int NP>
+__global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __restrict__ in, const u32x4* __restrict__ wfrag,
+                                                             const float* __restrict__ bias, uint16_t* __restrict__ out16, size_t o_plane) {
+    constexpr int H = 2 * HO, W = 2 * WO;
+    constexpr int PH = 2 * TH + 5, PW = 2 * WO + 6, PPLANE = PH * PW * 2;      // patch rows x columns (x 2 channels, bf16 elements)
+    constexpr int BANDS = HO / TH, NPIX_T = TH * WO, M_TILES = (NPIX_T + 15) / 16;
+    constexpr int NT = COUT / 16, NTW = NT / 4;                                 // n-tiles per wave
+    static_assert(HO % TH == 0 && NT % 4 == 0, "band / channel split");
+    __shared__ __attribute__((aligned(16))) uint16_t patch[NP * PPLANE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int band = blockIdx.x % BANDS, b = blockIdx.x / BANDS;
+    const int oy0 = band * TH;
+
+    bf16x8 wv[NTW][4][3];
+    float bv[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int nt = wave + 4 * t;
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) wv[t][st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * 4 + st) * 3 + pl) * 64 + lane]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[t][r] = bias[nt * 16 + 4 * g + r];
+    }
+
+    // ---- stage the band: input rows 2 oy0 - 3 .. + PH, columns -3 .. + PW, zero outside the image, split into planes
+    const float* inb = in + (size_t)b * H * W * 2;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int pr = i / PW, pc = i - pr * PW;
+        const int iy = 2 * oy0 - 3 + pr, ix = pc - 3;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float2 f = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
+        uint16_t a[3], c[3];
+        if constexpr (NP == 3) {
+            split3(ok ? f.x : 0.f, a[0], a[1], a[2]);
+            split3(ok ? f.y : 0.f, c[0], c[1], c[2]);
+        } else {
+            a[0] = f32_to_bf16_rn(ok ? f.x : 0.f);
+            c[0] = f32_to_bf16_rn(ok ? f.y : 0.f);
+        }
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + i * 2]) = (uint32_t)a[pl] | ((uint32_t)c[pl] << 16);
+    }
+    __syncthreads();
+
+    typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+    for (int mt = 0; mt < M_TILES; mt++) {
+        const int p = min(mt * 16 + m, NPIX_T - 1);                            // pixels beyond the band are computed on a clamped address, not stored
+        const int oy = p / WO, ox = p - oy * WO;
+        const int abase = ((2 * oy + (g >> 1)) * PW + 2 * ox + 4 * (g & 1)) * 2;
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                const uint16_t* src = &patch[pl * PPLANE + abase + min(2 * st, 6 - (g >> 1)) * PW * 2];     // kernel row 7 has zero weights
+                const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(src);
+                const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(src + 4);
+                a[st][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        const bool store = mt * 16 + m < NPIX_T;
+        const size_t opix = ((size_t)b * HO + oy0 + oy) * WO + ox;
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            f32x4 acc = {bv[t][0], bv[t][1], bv[t][2], bv[t][3]};
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                if constexpr (NP == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][2], a[st][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][1], a[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][1], a[st][0], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][0], acc, 0, 0, 0);
+            }
+            // D (transposed): row 4g + r = channel 4g + r of n-tile wave + 4t, column m = pixel: 8 bytes per lane and plane
+            uint16_t sp[3][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = fmaxf(acc[r], acc[r] * 0.1f);
+                if constexpr (NP == 3) split3(v, sp[0][r], sp[1][r], sp[2][r]);
+                else sp[0][r] = f32_to_bf16_rn(v);
+            }
+            if (store) {
+                uint16_t* o = out16 + opix * COUT + (wave + 4 * t) * 16 + 4 * g;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    *reinterpret_cast<uint2*>(o + pl * o_plane) =
+                        make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
+            }
+        }
+    }
+}
+
 }  // namespace hnet

@@ -97,6 +97,8 @@ struct hnet_ctx {
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
     bool b30_s3 = true;
+    uint16_t* s2_frag[4] = {};         // block_1_1 / block_2_1 (layers 0, 3) weights as 16x16x32 A-fragments [Cout/16][4][3][64] x 16 B (conv7_c2_s2_s3_kernel)
+    bool first_s2 = true;              // HNET_FIRST_S2=0: the round-1 fp32-MFMA implicit GEMM for these two layers
     uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
@@ -326,6 +328,8 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
             if (c->s3 && l == 7 && c->b30_s3 && c->b30_frag && o16)
                 STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s, c->n_planes));
+            else if (c->s3 && conv_is_first_s2(l) && c->first_s2 && c->s2_frag[l] && o16)
+                STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
             else if (c->use_patch && conv_is_patch_layer(l))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->s3 && conv_is_s3_layer(l))
@@ -482,6 +486,27 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             CK(hipMemcpy(c->b30_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
             const char* e30 = getenv("HNET_B30_S3");
             c->b30_s3 = !(e30 && atoi(e30) == 0);
+        }
+        if (c->s3 && conv_is_first_s2(l)) {   // lane (i = channel of the n-tile, g): kernel row 2 st + (g>>1), taps 4 (g&1) + (j>>1), ci = j&1
+            const int nt_n = d.cout / 16;
+            std::vector<uint16_t> fr((size_t)nt_n * 4 * 3 * 64 * 8, 0);
+            for (int nt = 0; nt < nt_n; nt++)
+                for (int st = 0; st < 4; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int co = nt * 16 + (ln & 15), gg = ln >> 4, kh = 2 * st + (gg >> 1);
+                        if (kh >= 7) continue;
+                        for (int j = 0; j < 8; j++) {
+                            const int kw = 4 * (gg & 1) + (j >> 1), ci = j & 1;
+                            if (kw >= 7) continue;
+                            uint16_t sp[3];
+                            split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                            for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * 4 + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
+                        }
+                    }
+            CK(hipMalloc((void**)&c->s2_frag[l], fr.size() * 2));
+            CK(hipMemcpy(c->s2_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            const char* e = getenv("HNET_FIRST_S2");
+            c->first_s2 = !(e && atoi(e) == 0);
         }
         if (c->s3 && conv_is_patch_layer(l)) {   // 16 -> 32, KSxKS: step st = taps 2st, 2st+1; lane group g -> tap 2st + (g>>1), ci 8(g&1)+j
             const int ks = d.ks, nstep = (ks * ks + 1) / 2;
@@ -705,7 +730,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1114,7 +1139,9 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
                                      c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes));
         } else {
             HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
-            if (layer == 7 && c->b30_s3 && c->b30_frag)     // the kernel the forward uses for block_3_0
+            if (conv_is_first_s2(layer) && c->first_s2 && c->s2_frag[layer] && h == (layer == 0 ? 28 : 56) && w == (layer == 0 ? 40 : 80))
+                HIPCHK(c, launch_conv_first_s2(layer, d_b, c->s2_frag[layer], c->conv_b[layer], p_out, n_out, batch, c->stream, c->n_planes));
+            else if (layer == 7 && c->b30_s3 && c->b30_frag)     // the kernel the forward uses for block_3_0
                 HIPCHK(c, launch_conv_first_s3(d_b, c->b30_frag, c->conv_b[layer], p_out, n_out, batch, h, w, c->stream, c->n_planes));
             else
                 HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
@@ -1207,7 +1234,8 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));   // three planes: written by the fp32-MFMA kernel
     } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
-                                             c->act_h[layer], c->act_w[layer], c->stream, (layer == 0 || layer == 3) ? 3 : c->n_planes));   // block_1_1 / block_2_1 come from the fp32-MFMA kernel: three planes
+                                             c->act_h[layer], c->act_w[layer], c->stream,
+                                             (conv_is_first_s2(layer) && !c->first_s2) ? 3 : c->n_planes));   // HNET_FIRST_S2=0: block_1_1 / block_2_1 from the fp32-MFMA kernel, three planes
     else
         HIPCHK(c, launch_nhwc_to_nchw(c->act[layer] + (size_t)pair * n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

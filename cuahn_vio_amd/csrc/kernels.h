@@ -35,6 +35,10 @@ hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int 
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes = 3);
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 int h, int w, hipStream_t s, int n_planes = 3);
+// block_1_1 (layer 0) / block_2_1 (layer 3): 7x7 stride 2, Cin 2, fp32 [B][h][w][2] in -> S3 planes out (conv_first.h)
+inline bool conv_is_first_s2(int layer) { return layer == 0 || layer == 3; }
+hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
+                                hipStream_t s, int n_planes = 3);
 // cfg (s3_dispatch.h): 0 / 1 fp32 NHWC input (8x32 tiles x 512 threads / 7x32 x 256, two workgroups per CU), 2 / 3 the older v2 kernel,
 // 4 / 5 the same geometries fed from the padded bf16 planes (B4_* above, x_plane dwords per plane) by LDS-DMA
 inline bool b4_cfg_is_dma(int cfg) { return cfg == 4 || cfg == 5; }

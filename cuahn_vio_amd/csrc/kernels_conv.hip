@@ -153,6 +153,12 @@ hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const floa
                          : launch_conv_first_s3_np<3>(x_in, wfrag, bias, out16, o_plane, batch, h, w, s);
 }
 
+hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
+                                hipStream_t s, int n_planes) {
+    return n_planes == 1 ? launch_conv_first_s2_np<1>(layer, x_in, wfrag, bias, out16, o_plane, batch, s)
+                         : launch_conv_first_s2_np<3>(layer, x_in, wfrag, bias, out16, o_plane, batch, s);
+}
+
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes) {
     return n_planes == 1 ? launch_conv_patch_np<1>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s)

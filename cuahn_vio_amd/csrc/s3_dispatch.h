@@ -49,8 +49,9 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel LDS-DMA layers -> wide taps only
     static const int xcd = std::getenv("HNET_XCD_REMAP") ? std::atoi(std::getenv("HNET_XCD_REMAP")) : -1;
     p.xcd_remap = xcd >= 0 ? xcd : (L::WIDE_TAPS ? 1 : 0);
-    // LDS-DMA ring (3 stages) by default: 2-8 % faster than register staging on the 64x64 tiles (HNET_S3_DMA=0 disables)
-    static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : 3;
+    // LDS-DMA ring (HNET_S3_DMA=3 stages) for the Cin-32 layers: 2-8 % faster than the round-1 register staging, but 1-3 % slower than
+    // the lean staging of round 2 (0.1116 vs 0.1086 ms on block_3_2, profiles/r02_ab_s3_dma.log) -> off in split-bf16 mode, on in plain bf16
+    static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : (NP == 3 ? 0 : 3);
 
     if constexpr (NP == 1) {
         // plain bf16 operands: the measured winners of the split-bf16 dispatch below, in their 16x16x32 form (the only form
@@ -186,6 +187,21 @@ hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const f
     return hipGetLastError();
 }
 
+// block_1_1 (layer 0: 2 -> 128 @28x40) / block_2_1 (layer 3: 2 -> 64 @56x80), 7x7 stride 2 (conv_first.h conv7_c2_s2_s3_kernel)
+template <int NP>
+hipError_t launch_conv_first_s2_np(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane,
+                                   int batch, hipStream_t s) {
+    if (layer == 0)
+        hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<128, 14, 20, 7, NP>), dim3((unsigned)(batch * 2)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                           bias, out16, o_plane);
+    else if (layer == 3)
+        hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<64, 28, 40, 7, NP>), dim3((unsigned)(batch * 4)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                           bias, out16, o_plane);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // block_3_1 (5x5) / block_4_2 (3x3): 16 -> 32 channels, stride 2, from an LDS-resident patch (conv_patch_s2.h)
 template <int KS, int NP>
 static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfrag, const float* bias, uint16_t* out16,
@@ -281,6 +297,7 @@ hipError_t conv_kernels_init_device_np() {
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
                                                       uint16_t*, size_t, int, hipStream_t, int, int);                                    \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
+    KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
                                                     size_t, hipStream_t);                                                                \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \
