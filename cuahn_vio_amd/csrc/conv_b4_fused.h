@@ -351,23 +351,9 @@ template <int N>
 __device__ __forceinline__ void wait6(bf16x4 (&a)[6]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "n"(N));
 }
-__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// two fp32 values -> their NP bf16 planes, each plane as one packed dword (lo = v0, hi = v1)
-template <int NP>
-__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
-    pl[0] = cvt_pk(v0, v1);
-    if constexpr (NP == 3) {
-        const float r0 = v0 - __builtin_bit_cast(float, pl[0] << 16), r1 = v1 - __builtin_bit_cast(float, pl[0] & 0xffff0000u);
-        pl[1] = cvt_pk(r0, r1);
-        const float s0 = r0 - __builtin_bit_cast(float, pl[1] << 16), s1 = r1 - __builtin_bit_cast(float, pl[1] & 0xffff0000u);
-        pl[2] = cvt_pk(s0, s1);
-    }
-}
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
+using s3p::cvt_pk;
+using s3p::split_pair;
+using s3p::lrelu;
 
 }  // namespace b4v3
 

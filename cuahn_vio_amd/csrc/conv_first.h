@@ -199,59 +199,43 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_kernel(const float* __restric
 template <int NP>
 __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __restrict__ in, const u32x4* __restrict__ wfrag,
                                                              const float* __restrict__ bias, uint16_t* __restrict__ out16, size_t o_plane,
-                                                             int H, int W, int tiles_x, int tiles_y) {
+                                                             int H, int W, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int TH = 16, TW = 32, PH = TH + 6, PW = TW + 8, PROW = PW * 2, PPLANE = PH * PROW;
     __shared__ __attribute__((aligned(16))) uint16_t patch[NP * PPLANE];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4 * NP * 64 * 16];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4 * NP * 256 * 4];      // per wave and plane: 256 units of 8 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
 
+    // persistent workgroups (round 2): the 84 weight registers are loaded once, not once per 16 x 32 tile (86 KB per tile from L2), and
+    // the next tile's patch is in flight while the current one is computed
     bf16x8 wv[7][3];
 #pragma unroll
     for (int kh = 0; kh < 7; kh++)
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) wv[kh][pl] = __builtin_bit_cast(bf16x8, wfrag[(kh * 3 + pl) * 64 + lane]);
 
-    // ---- stage the patch: unconditional float2 loads from a clamped address, zero selected afterwards, split into planes
-    const float* inb = in + (size_t)b * H * W * 2;
     constexpr int PPT = (PH * PW + 255) / 256;
     float2 px[PPT];
     uint32_t okbits = 0;
+    // unconditional float2 loads from a clamped address; zero is selected when the registers are consumed
+    auto patch_load = [&](int t) {
+        int bid = t;
+        const int tx = bid % tiles_x; bid /= tiles_x;
+        const int ty = bid % tiles_y;
+        const int b = bid / tiles_y;
+        const float* inb = in + (size_t)b * H * W * 2;
+        okbits = 0;
 #pragma unroll
-    for (int q = 0; q < PPT; q++) {
-        const int i = min(tid + q * 256, PH * PW - 1);
-        const int pr = i / PW, pc = i - pr * PW;
-        const int iy = y0 - 3 + pr, ix = x0 - 3 + pc;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        px[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
-        okbits |= ok ? (1u << q) : 0u;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < PPT; q++) {
-        const int i = tid + q * 256;
-        if (i < PH * PW) {
-            const bool ok = (okbits >> q) & 1u;
-            uint16_t pa[3], pb[3];
-            if constexpr (NP == 3) {
-                split3(ok ? px[q].x : 0.f, pa[0], pa[1], pa[2]);
-                split3(ok ? px[q].y : 0.f, pb[0], pb[1], pb[2]);
-            } else {
-                pa[0] = f32_to_bf16_rn(ok ? px[q].x : 0.f);
-                pb[0] = f32_to_bf16_rn(ok ? px[q].y : 0.f);
-            }
-            const int e = i * 2;                                // [row][column][2 ch], rows of PROW elements: i = pr*PW + pc
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = (uint32_t)pa[pl] | ((uint32_t)pb[pl] << 16);
+        for (int q = 0; q < PPT; q++) {
+            const int i = min(tid + q * 256, PH * PW - 1);
+            const int pr = i / PW, pc = i - pr * PW;
+            const int iy = ty * TH - 3 + pr, ix = tx * TW - 3 + pc;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            px[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
+            okbits |= ok ? (1u << q) : 0u;
         }
-    }
-    __syncthreads();
+    };
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
 
-    // M-tile = 2 output rows x 16 pixel pairs; lane column = (row-of-pair, pixel pair), lane half hh = taps 4hh..4hh+3
     const int pcol = lane & 31, hh = lane >> 5;
     const int prow = pcol >> 4, pair = pcol & 15;
     int hi4 = 4;                                                // opaque: two ds_read_b64 (2 + 2 LDS cycles) instead of one ds_read2_b64 (8)
@@ -261,12 +245,38 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int i = 0; i < 4; i++) bv[q][i] = bias[(8 * q + 4 * hh + i) & 15];
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- the prefetched patch -> bf16 planes in LDS
+    __syncthreads();                                            // the previous tile's MFMA phase is done with the patch
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+        const int i = tid + q * 256;
+        if (i < PH * PW) {
+            const bool ok = (okbits >> q) & 1u;
+            uint32_t pk[3];
+            s3p::split_pair<NP>(ok ? px[q].x : 0.f, ok ? px[q].y : 0.f, pk);
+            const int e = i * 2;                                // [row][column][2 ch], rows of PROW elements: i = pr*PW + pc
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = pk[pl];
+        }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);
+
+    // M-tile = 2 output rows x 16 pixel pairs; lane column = (row-of-pair, pixel pair), lane half hh = taps 4hh..4hh+3
 #pragma unroll 1
     for (int j = 0; j < (TH / 2) / 4; j++) {
         const int mt = wave + 4 * j;
-        f32x16 acc;
+        f32x16 acc;                                            // bias = initial accumulator
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[r] = bv[r >> 2][r & 3];
         const int abase = (mt * 2 + prow) * PROW + pair * 4 + 8 * hh;
 #pragma unroll
         for (int kh = 0; kh < 7; kh++) {
@@ -288,37 +298,43 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[0], acc, 0, 0, 0);
         }
-        // stage the wave's 64 pixels x 16 channels per plane in LDS ([plane][row-of-pair][x 0..31][16 ch]) as 8-byte pieces,
-        // then write 16 bytes per lane: one plane of one output row of the tile is 1 KiB of contiguous global memory
-        uint16_t* st = stage + wave * (NP * 64 * 16);
+        // D row 4 (2 q' + hh) + i of group q = (dx, co half c): a lane holds channels 8 c + 4 hh .. + 3 of pixel 2 pair + dx.  The wave's
+        // 2 rows x 32 pixels x 16 channels are staged per plane in LDS as 8-byte units and read back so that a lane stores 16 bytes and
+        // one store instruction covers 1 KiB of contiguous global memory (direct 8-byte stores at 64-byte stride were measured 35 %
+        // slower: 4x the cache lines per instruction).  Unit index U = ((c 2 + hh) 2 + prow) 32 + 16 (prow ^ dx) + pair: the 32 lanes of a
+        // write (fixed dx, c, hh; all prow, pair) and of a read (fixed prow, hh, c; all pair, dx) each fall on 32 different units mod 32
+        // = all 64 banks once.  (Round 1 used the plain [row][x][16 ch] order: pairs 0, 4, 8, 12 on the same bank, 58 % of the LDS cycles.)
+        uint16_t* st = stage + wave * (NP * 256 * 4);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int dx = q >> 1, co0 = 8 * (q & 1) + 4 * hh;
-            uint16_t sp[3][4];
+            const int dx = q >> 1, c = q & 1;
+            uint32_t pa[3], pb[3];
+            s3p::split_pair<NP>(s3p::lrelu(acc[4 * q]), s3p::lrelu(acc[4 * q + 1]), pa);
+            s3p::split_pair<NP>(s3p::lrelu(acc[4 * q + 2]), s3p::lrelu(acc[4 * q + 3]), pb);
+            const int u = ((c * 2 + hh) * 2 + prow) * 32 + 16 * (prow ^ dx) + pair;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float v = acc[4 * q + i] + bv[q][i];
-                v = v > 0.f ? v : v * 0.1f;
-                if constexpr (NP == 3) split3(v, sp[0][i], sp[1][i], sp[2][i]);
-                else sp[0][i] = f32_to_bf16_rn(v);
-            }
-            const int e = (prow * 32 + 2 * pair + dx) * 16 + co0;
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++)
-                *reinterpret_cast<uint2*>(&st[pl * 64 * 16 + e]) =
-                    make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&st[(pl * 256 + u) * 4]) = make_uint2(pa[pl], pb[pl]);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS writes have landed
+        {
+            const int rp = lane & 15, rdx = (lane >> 4) & 1, rc = lane >> 5;      // this lane's piece of a row: pixel 2 rp + rdx, channel half rc
+            const int x = x0 + 2 * rp + rdx;
 #pragma unroll
-        for (int q = 0; q < 2 * NP; q++) {
-            const int piece = q * 64 + lane;                    // NP x 128 pieces of 16 B: [plane][row-of-pair][x][half]
-            const int pl = piece >> 7, rem = piece & 127, pr = rem >> 6, xx = (rem >> 1) & 31, hf = rem & 1;
-            const int y = y0 + mt * 2 + pr, x = x0 + xx;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(&st[(pl * 64 + pr * 32 + xx) * 16 + hf * 8]);
-            if (y < H && x < W) *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * H + y) * W + x) * 16 + hf * 8) = v;
+            for (int pr = 0; pr < 2; pr++) {
+                const int y = y0 + mt * 2 + pr;
+                const int u0 = ((rc * 2) * 2 + pr) * 32 + 16 * (pr ^ rdx) + rp;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(&st[(pl * 256 + u0) * 4]);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(&st[(pl * 256 + u0 + 64) * 4]);
+                    if (y < H && x < W)
+                        *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * H + y) * W + x) * 16 + rc * 8) = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
+    }   // persistent tile loop
 }
 
 

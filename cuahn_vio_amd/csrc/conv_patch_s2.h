@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "igemm_s3.h"
+#include "conv_b4_fused.h"      // s3p::split_pair / lrelu
 
 namespace hnet {
 
@@ -30,8 +31,7 @@ template <int KS, int NP = 3> struct PatchS2Cfg {
     static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, half)
     static constexpr int PLANE = RH * 2 * 2 * XH * 8;           // bf16 elements per plane
     static constexpr int NSTEP = (KS * KS + 1) / 2;             // two taps per 32-deep MFMA step
-    static constexpr int STAGE = 4 * NP * 16 * 16;              // epilogue staging, elements
-    static constexpr int LDS_BYTES = (NP * PLANE + STAGE) * 2;
+    static constexpr int LDS_BYTES = NP * PLANE * 2;
 };
 
 typedef float f32x4_p __attribute__((ext_vector_type(4)));
@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
     constexpr int TH = C::TH, TW = C::TW, RH = C::RH, RW = C::RW, XH = C::XH, PLANE = C::PLANE, NSTEP = C::NSTEP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint16_t* img = reinterpret_cast<uint16_t*>(lds_raw);
-    uint16_t* stage = img + NP * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -74,7 +73,6 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
     };
     const int lane_off = (g & 1) * (XH * 8 + 4);                 // channel half of the group; odd groups: high 8 bytes first
     const int second = 4 - 8 * (g & 1);                         // element offset from the first to the second 8-byte read
-    uint16_t* st_lds = stage + wave * (NP * 16 * 16);
     // staging items of one region row: (plane, column, channel half), NP*RW*2 of them, ITEMS per lane
     constexpr int ROW_ITEMS = NP * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
     constexpr int RB = KS == 5 ? 1 : 5;                         // region rows loaded per batch (register budget)
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
             int gv = g;                                           // opaque per M-tile: the 13 tap addresses are formed next to their
             asm volatile("" : "+v"(gv));                          // reads instead of being hoisted into 13 registers
             const bool odd_tap = (gv >> 1) != 0;                  // lane groups 2, 3 take the odd tap of a step
-            f32x4_p acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4_p acc = {bv[0], bv[1], bv[2], bv[3]};          // bias = initial accumulator
 #pragma unroll
             for (int st = 0; st < NSTEP; st++) {
                 bf16x8 a[3];
@@ -179,35 +177,21 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
                 }
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[0], acc, 0, 0, 0);
             }
-            // D (transposed): row 4g + r = cout within the half, column m = output column
+            // D (transposed): row 4g + r = cout within the half, column m = output column: a lane holds four consecutive channels of one
+            // pixel, 8 bytes per plane, and stores them straight to global memory (the 16 lanes of a group x 4 groups cover 32 of the 64
+            // bytes of 16 consecutive pixels; the partner wave of the other channel half writes the rest of each line).  Round 1 staged
+            // the tile through LDS to form 16-byte stores: one more LDS round trip and two waits per M-tile for nothing measurable.
             {
-                uint16_t sp[3][4];
+                const int Y = ty0 + oy, X = tx0 + m;
+                uint32_t pa[3], pb[3];
+                s3p::split_pair<NP>(s3p::lrelu(acc[0]), s3p::lrelu(acc[1]), pa);
+                s3p::split_pair<NP>(s3p::lrelu(acc[2]), s3p::lrelu(acc[3]), pb);
+                if (Y < Ho && X < Wo) {
+                    uint16_t* o = out16 + (((size_t)b * Ho + Y) * Wo + X) * 32 + nt * 16 + 4 * g;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = acc[r] + bv[r];
-                    v = v > 0.f ? v : v * 0.1f;
-                    if constexpr (NP == 3) split3(v, sp[0][r], sp[1][r], sp[2][r]);
-                    else sp[0][r] = f32_to_bf16_rn(v);
-                }
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    *reinterpret_cast<uint2*>(&st_lds[(pl * 16 + m) * 16 + 4 * g]) =
-                        make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            const int Y = ty0 + oy;
-#pragma unroll
-            for (int q = 0; q < (NP * 32 + 63) / 64; q++) {
-                const int piece = q * 64 + lane;                 // NP x 32 pieces of 16 B: [plane][16 px][2 x 8 channels]
-                if (piece < NP * 32) {
-                    const int pl = piece >> 5, rem = piece & 31, px = rem >> 1, hh = rem & 1;
-                    const int X = tx0 + px;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st_lds[(pl * 16 + px) * 16 + hh * 8]);
-                    if (Y < Ho && X < Wo)
-                        *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (((size_t)b * Ho + Y) * Wo + X) * 32 + nt * 16 + hh * 8) = v;
+                    for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
         }
     }
 }

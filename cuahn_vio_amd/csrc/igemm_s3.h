@@ -112,6 +112,28 @@ struct ConvLoaderS3 {
     }
 };
 
+// packed epilogue helpers shared by the direct-convolution kernels (conv_first.h, conv_patch_s2.h, conv_b4_fused.h)
+namespace s3p {
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// two fp32 values -> their NP bf16 planes, each plane as one packed dword (lo = v0, hi = v1)
+template <int NP>
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
+    pl[0] = cvt_pk(v0, v1);
+    if constexpr (NP == 3) {
+        const float r0 = v0 - __builtin_bit_cast(float, pl[0] << 16), r1 = v1 - __builtin_bit_cast(float, pl[0] & 0xffff0000u);
+        pl[1] = cvt_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, pl[1] << 16), s1 = r1 - __builtin_bit_cast(float, pl[1] & 0xffff0000u);
+        pl[2] = cvt_pk(s0, s1);
+    }
+}
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
+
+}  // namespace s3p
+
 // MC-dropout input of the heads in S3 form: A[(b, s)][k] = keep(s, k) ? featS3[b][k] : 0, where featS3 are the three
 // bf16 planes of feat * 1/(1-p) (heads_prep_kernel) and the keep bits come from a precomputed bit array (one byte per
 // 8-element chunk) so that the staging path does no hashing (reference: Dropout -> Linear(5120,256),

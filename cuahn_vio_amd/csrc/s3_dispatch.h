@@ -182,8 +182,10 @@ template <int NP>
 hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                    int h, int w, hipStream_t s) {
     const int tx = (w + 31) / 32, ty = (h + 15) / 16;
-    hipLaunchKernelGGL(conv7_c2_s1_s3_kernel<NP>, dim3((unsigned)(batch * tx * ty)), dim3(256), 0, s, x_in, (const u32x4*)wfrag, bias, out16,
-                       o_plane, h, w, tx, ty);
+    const int n_tiles = batch * tx * ty;
+    static const int per_cu = std::getenv("HNET_B30_WGS") ? std::atoi(std::getenv("HNET_B30_WGS")) : 2;    // measured 0.113 (2) / 0.119 (3) / 0.114 (4) ms at batch 256
+    hipLaunchKernelGGL(conv7_c2_s1_s3_kernel<NP>, dim3((unsigned)std::min(n_tiles, 256 * per_cu)), dim3(256), 0, s, x_in, (const u32x4*)wfrag, bias,
+                       out16, o_plane, h, w, tx, ty, n_tiles);
     return hipGetLastError();
 }
 
