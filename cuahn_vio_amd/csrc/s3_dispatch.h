@@ -193,12 +193,24 @@ hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const f
 template <int NP>
 hipError_t launch_conv_first_s2_np(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane,
                                    int batch, hipStream_t s) {
-    if (layer == 0)
-        hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<128, 14, 20, 7, NP>), dim3((unsigned)(batch * 2)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
-                           bias, out16, o_plane);
-    else if (layer == 3)
-        hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<64, 28, 40, 7, NP>), dim3((unsigned)(batch * 4)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
-                           bias, out16, o_plane);
+    // bands of 7 output rows amortise the weight loads at large batches; at small ones (the batch-1 latency path) 2-row bands give
+    // 7 / 14 workgroups per pair instead of 2 / 4
+    const bool small = batch <= 16;
+    if (layer == 0) {
+        if (small)
+            hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<128, 14, 20, 2, NP>), dim3((unsigned)(batch * 7)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                               bias, out16, o_plane);
+        else
+            hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<128, 14, 20, 7, NP>), dim3((unsigned)(batch * 2)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                               bias, out16, o_plane);
+    } else if (layer == 3) {
+        if (small)
+            hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<64, 28, 40, 2, NP>), dim3((unsigned)(batch * 14)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                               bias, out16, o_plane);
+        else
+            hipLaunchKernelGGL((conv7_c2_s2_s3_kernel<64, 28, 40, 7, NP>), dim3((unsigned)(batch * 4)), dim3(256), 0, s, x_in, (const u32x4*)wfrag,
+                               bias, out16, o_plane);
+    }
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
