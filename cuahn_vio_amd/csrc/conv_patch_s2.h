@@ -196,4 +196,156 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// block_3_2 / block_4_3: 3x3 stride 2, 32 -> 64 channels, 56x80 -> 28x40, in the same patch-resident form (round 2).
+// In the implicit-GEMM kernel these two layers ran at 0.257 MFMA busy (profiles/r02_v2): K is only 288 (nine 32-deep
+// K-tiles), so prologue, barriers and the 24 KB epilogue of every 64 x 64 tile weigh as much as its MFMAs, and the A tile is
+// staged 2.25 times.  Here: a workgroup owns 4 rows x 20 columns of output pixels = five M-tiles of 16 pixels (row-major over
+// the tile, so the 40-column image splits into two tiles without a ragged one), stages the 9 x 41 x 32-channel input region
+// once (16-byte chunks of 8 channels, [plane][row][column parity][channel quarter][column / 2]), and wave w computes output
+// channels 16 w .. 16 w + 15 of all five M-tiles with its 9 x 3 weight fragments (one tap x 32 channels per MFMA step) in
+// registers for the lifetime of the (persistent) workgroup.  Lane group g reads channel quarter g of the step's tap; the
+// 16 bytes as two ds_read_b64 with the halves swapped for odd groups (see above), weights packed to match.
+template <int NP = 3> struct Patch32Cfg {
+    static constexpr int CIN = 32, COUT = 64, KS = 3, PAD = 1;
+    static constexpr int TH = 4, TW = 20, MT = TH * TW / 16;     // 80 pixels = 5 M-tiles
+    static constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1;
+    static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, quarter)
+    static constexpr int ROW = 2 * 4 * XH * 8;                  // bf16 elements per region row and plane
+    static constexpr int PLANE = RH * ROW;
+    static constexpr int NSTEP = 9;
+    static constexpr int LDS_BYTES = NP * PLANE * 2;
+};
+
+// in: S3 planes [3][B][56][80][32];  wfrag: [4 n-tiles][9 steps][3][64 lanes] x 16 B;  out16: [3][B][28][40][64]
+template <int NP>
+__global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
+                                                                  const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                  uint16_t* __restrict__ out16, size_t o_plane, int n_tiles, int reverse) {
+    typedef Patch32Cfg<NP> C;
+    constexpr int TH = C::TH, TW = C::TW, MT = C::MT, RH = C::RH, RW = C::RW, XH = C::XH, ROW = C::ROW, PLANE = C::PLANE, NSTEP = C::NSTEP;
+    constexpr int H = 56, W = 80, Ho = 28, Wo = 40, tiles_x = Wo / TW, tiles_y = Ho / TH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint16_t* img = reinterpret_cast<uint16_t*>(lds_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int nt = wave;
+
+    bf16x8 wv[NSTEP][3];
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++)
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
+    f32x4_p bv;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
+
+    // element offset of tap t inside a plane (quarter 0, column 0)
+    auto tap_elem = [](int t) constexpr {
+        const int kh = t / 3, kw = t - kh * 3;
+        return kh * ROW + ((kw & 1) * 4 * XH + (kw >> 1)) * 8;
+    };
+    const int goff = g * XH * 8 + 4 * (g & 1);                    // this group's channel quarter; odd groups: high 8 bytes first
+    const int second = 4 - 8 * (g & 1);
+    // staging items of one region row: (plane, column, channel quarter)
+    constexpr int ROW_ITEMS = NP * RW * 4, ITEMS = (ROW_ITEMS + 63) / 64;
+    constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int bid = reverse ? n_tiles - 1 - tile : tile;
+        const int bx = bid % tiles_x; bid /= tiles_x;
+        const int by = bid % tiles_y;
+        const int b = bid / tiles_y;
+        const int ty0 = by * TH, tx0 = bx * TW;
+        const int Ry0 = 2 * ty0 - 1, Rx0 = 2 * tx0 - 1;
+
+        // ---- stage the input region: 16-byte copies, zero outside the image; a wave takes whole region rows.  Buffer loads: the
+        // per-lane part of an address is one 32-bit byte offset, out-of-image chunks get an offset beyond the descriptor's range (= 0),
+        // and all of the wave's rows (3 x 7 loads per lane) are in flight before the first LDS write
+        __syncthreads();
+        {
+            int it_pc[ITEMS], it_loff[ITEMS];
+            uint32_t it_goff[ITEMS];
+            uint32_t it_valid = 0;
+            int lv = lane;
+            asm volatile("" : "+v"(lv));                         // formed per tile: not live across the MFMA phase
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const int item = lv + 64 * q;
+                const int it = item < ROW_ITEMS ? item : 0;
+                const int pl = it / (RW * 4), rem = it - pl * (RW * 4), pc = rem >> 2, cq = rem & 3;
+                it_pc[q] = pc;
+                it_goff[q] = (uint32_t)((pl * i_plane + cq * 8 + (size_t)pc * 32) * 2);
+                it_loff[q] = pl * PLANE + (((pc & 1) * 4 + cq) * XH + (pc >> 1)) * 8;
+                if (item < ROW_ITEMS) it_valid |= 1u << q;
+            }
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)b * H * W * 32), 0, 0x7FFFFFF0, 0x00020000);
+            u32x4 buf[ROWS_PER_WAVE][ITEMS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
+                const int pr = wave + 4 * rr;
+                const int iy = Ry0 + pr;
+                const bool row_ok = pr < RH && iy >= 0 && iy < H;
+                const int soff = row_ok ? (iy * W + Rx0) * 64 : 0;      // bytes; Rx0 = -1 for the left tile: the column test below covers it
+#pragma unroll
+                for (int q = 0; q < ITEMS; q++) {
+                    const int ix = Rx0 + it_pc[q];
+                    const bool ok = row_ok && ix >= 0 && ix < W;
+                    buf[rr][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? it_goff[q] + (uint32_t)soff : S3_OOB, 0, 0));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
+                const int pr = wave + 4 * rr;
+#pragma unroll
+                for (int q = 0; q < ITEMS; q++)
+                    if (pr < RH && (it_valid & (1u << q))) *reinterpret_cast<u32x4*>(&img[pr * ROW + it_loff[q]]) = buf[rr][q];
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMAs: all five M-tiles for this wave's 16 output channels
+        uint16_t* const ob = out16 + ((size_t)b * Ho * Wo + (size_t)ty0 * Wo + tx0) * 64 + nt * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            // this lane's pixel of M-tile j: p = 16 j + m, row p / 20, column p % 20; input row 2 oy, column 2 ox (parity 0, chunk ox)
+            const int pp = 16 * j + m, oy = pp / TW, ox = pp - oy * TW;
+            const int base = 2 * oy * ROW + ox * 8 + goff;
+            f32x4_p acc = bv;                                     // bias = initial accumulator
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) {
+                    const uint16_t* src = &img[pl * PLANE + base + tap_elem(st)];
+                    const bf16x4_p first = *reinterpret_cast<const bf16x4_p*>(src);
+                    const bf16x4_p other = *reinterpret_cast<const bf16x4_p*>(src + second);
+                    a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if constexpr (NP == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][2], a[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[0], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[0], acc, 0, 0, 0);
+            }
+            // D (transposed): row 4g + r = cout 16 nt + 4g + r, column m = pixel: 8 bytes per lane and plane straight to global memory
+            // (forming whole 128-byte lines through LDS first, the four waves' quarters together, measured 0.1028 vs 0.1004 ms: not worth
+            // the two extra barriers per tile)
+            uint32_t pa[3], pb[3];
+            s3p::split_pair<NP>(s3p::lrelu(acc[0]), s3p::lrelu(acc[1]), pa);
+            s3p::split_pair<NP>(s3p::lrelu(acc[2]), s3p::lrelu(acc[3]), pb);
+            uint16_t* o = ob + (size_t)(oy * Wo + ox) * 64;
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
+        }
+    }
+}
+
 }  // namespace hnet

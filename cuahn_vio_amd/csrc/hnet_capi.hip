@@ -94,6 +94,7 @@ struct hnet_ctx {
     int n_planes = 3;                  // bf16 planes the matrix-core layers read and write: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
+    bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
     bool b30_s3 = true;
@@ -330,7 +331,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s, c->n_planes));
             else if (c->s3 && conv_is_first_s2(l) && c->first_s2 && c->s2_frag[l] && o16)
                 STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
-            else if (c->use_patch && conv_is_patch_layer(l))
+            else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
@@ -424,6 +425,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : 3;
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
+    c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
     // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
     // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
@@ -507,6 +509,22 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             CK(hipMemcpy(c->s2_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
             const char* e = getenv("HNET_FIRST_S2");
             c->first_s2 = !(e && atoi(e) == 0);
+        }
+        if (c->s3 && conv_is_patch32_layer(l)) {   // 32 -> 64, 3x3: step st = tap st; lane group g -> channels 8g .. 8g+7 (odd groups rotated by 4)
+            std::vector<uint16_t> fr((size_t)4 * 9 * 3 * 64 * 8, 0);
+            for (int nt = 0; nt < 4; nt++)
+                for (int st = 0; st < 9; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int n = nt * 16 + (ln & 15), gg = ln >> 4, kh = st / 3, kw = st % 3;
+                        for (int j = 0; j < 8; j++) {
+                            const int ci = 8 * gg + ((gg & 1) ? (j + 4) % 8 : j);
+                            uint16_t sp[3];
+                            split3(w->data[(((size_t)n * 32 + ci) * 3 + kh) * 3 + kw], sp[0], sp[1], sp[2]);
+                            for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * 9 + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
+                        }
+                    }
+            CK(hipMalloc((void**)&c->patch_frag[l], fr.size() * 2));
+            CK(hipMemcpy(c->patch_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
         }
         if (c->s3 && conv_is_patch_layer(l)) {   // 16 -> 32, KSxKS: step st = taps 2st, 2st+1; lane group g -> tap 2st + (g>>1), ci 8(g&1)+j
             const int ks = d.ks, nstep = (ks * ks + 1) / 2;
@@ -1130,7 +1148,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         uint16_t *p_in = nullptr, *p_out = nullptr;
         HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32));
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
-        if (c->use_patch && conv_is_patch_layer(layer)) {
+        if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
         } else if (conv_is_s3_layer(layer)) {

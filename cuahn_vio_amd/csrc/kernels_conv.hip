@@ -135,6 +135,7 @@ HNET_S3_DISPATCH_INSTANCES(extern, 1)
 
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
 bool conv_is_patch_layer(int layer) { return layer == 8 || layer == 15; }   // block_3_1 (5x5), block_4_2 (3x3)
+bool conv_is_patch32_layer(int layer) { return layer == 9 || layer == 16; }   // block_3_2, block_4_3 (3x3, 32 -> 64)
 
 hipError_t conv_kernels_init_device() {
     const hipError_t e = conv_kernels_init_device_np<3>();

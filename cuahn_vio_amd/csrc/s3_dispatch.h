@@ -236,6 +236,14 @@ hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, i
                                 const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s) {
     if (layer == 8) return run_patch<5, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
     if (layer == 15) return run_patch<3, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s);
+    if ((layer == 9 || layer == 16) && h == 56 && w == 80) {     // block_3_2 / block_4_3
+        typedef Patch32Cfg<NP> C;
+        const int n_tiles = batch * (28 / C::TH) * (40 / C::TW);
+        static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
+        hipLaunchKernelGGL((conv_patch32_s2_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
+                           (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
+        return hipGetLastError();
+    }
     return hipErrorInvalidValue;
 }
 
@@ -303,6 +311,7 @@ hipError_t conv_kernels_init_device_np() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
     return e;
 }
 
