@@ -212,7 +212,9 @@ template <int NP = 3> struct Patch32Cfg {
     static constexpr int TH = 4, TW = 20, MT = TH * TW / 16;     // 80 pixels = 5 M-tiles
     static constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1;
     static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, quarter)
-    static constexpr int ROW = 2 * 4 * XH * 8;                  // bf16 elements per region row and plane
+    // bf16 elements per region row and plane, + 32 bytes: an M-tile of 16 pixels wraps from output row oy (columns 16..19) to row oy + 1
+    // (columns 0..11); two region rows further down must not be a multiple of 256 bytes or those lanes read the same banks
+    static constexpr int ROW = 2 * 4 * XH * 8 + 16;
     static constexpr int PLANE = RH * ROW;
     static constexpr int NSTEP = 9;
     static constexpr int LDS_BYTES = NP * PLANE * 2;
@@ -248,8 +250,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
         const int kh = t / 3, kw = t - kh * 3;
         return kh * ROW + ((kw & 1) * 4 * XH + (kw >> 1)) * 8;
     };
-    const int goff = g * XH * 8 + 4 * (g & 1);                    // this group's channel quarter; odd groups: high 8 bytes first
-    const int second = 4 - 8 * (g & 1);
+    // this group's channel quarter; groups 1 and 2 read the high 8 bytes of their chunk first.  A group's 16 lanes cover all banks
+    // = 0,1 (low half) or = 2,3 (high half) mod 4 whatever its chunk offset, so two groups served in the same LDS cycle must differ in that
+    // choice: hsw = (g & 1) ^ (g >> 1) makes that true for the pairs (0,1)(2,3) and for (0,2)(1,3).  (The PMC still shows a conflict share
+    // of 0.48 for this kernel, LDS busy 0.62 - profiles/r02_v6_pmc_mfma_lds.csv; padding the chunk rows did not change it.  Open.)
+    const int hsw = (g & 1) ^ (g >> 1);
+    const int goff = g * XH * 8 + 4 * hsw;
+    const int second = 4 - 8 * hsw;
     // staging items of one region row: (plane, column, channel quarter)
     constexpr int ROW_ITEMS = NP * RW * 4, ITEMS = (ROW_ITEMS + 63) / 64;
     constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
