@@ -212,9 +212,9 @@ template <int NP = 3> struct Patch32Cfg {
     static constexpr int TH = 4, TW = 20, MT = TH * TW / 16;     // 80 pixels = 5 M-tiles
     static constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1;
     static constexpr int XH = (RW + 1) / 2;                     // chunks per (row, parity, quarter)
-    // bf16 elements per region row and plane, + 32 bytes: an M-tile of 16 pixels wraps from output row oy (columns 16..19) to row oy + 1
-    // (columns 0..11); two region rows further down must not be a multiple of 256 bytes or those lanes read the same banks
-    static constexpr int ROW = 2 * 4 * XH * 8 + 16;
+    // bf16 elements per region row and plane, + 64 bytes: an M-tile of 16 pixels wraps from output row oy to row oy + 1; with two region
+    // rows = 128 bytes mod 256 the wrapped lanes continue the 32-byte-stride bank pattern of the first ones (see the kernel)
+    static constexpr int ROW = 2 * 4 * XH * 8 + 32;
     static constexpr int PLANE = RH * ROW;
     static constexpr int NSTEP = 9;
     static constexpr int LDS_BYTES = NP * PLANE * 2;
@@ -248,15 +248,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
     // element offset of tap t inside a plane (quarter 0, column 0)
     auto tap_elem = [](int t) constexpr {
         const int kh = t / 3, kw = t - kh * 3;
-        return kh * ROW + ((kw & 1) * 4 * XH + (kw >> 1)) * 8;
+        return kh * ROW + ((kw & 1) * 4 * XH + (kw >> 1) * 2) * 8;
     };
-    // this group's channel quarter; groups 1 and 2 read the high 8 bytes of their chunk first.  A group's 16 lanes cover all banks
-    // = 0,1 (low half) or = 2,3 (high half) mod 4 whatever its chunk offset, so two groups served in the same LDS cycle must differ in that
-    // choice: hsw = (g & 1) ^ (g >> 1) makes that true for the pairs (0,1)(2,3) and for (0,2)(1,3).  (The PMC still shows a conflict share
-    // of 0.48 for this kernel, LDS busy 0.62 - profiles/r02_v6_pmc_mfma_lds.csv; padding the chunk rows did not change it.  Open.)
-    const int hsw = (g & 1) ^ (g >> 1);
-    const int goff = g * XH * 8 + 4 * hsw;
-    const int second = 4 - 8 * hsw;
+    // LDS layout of a region row: [column parity][quarter pair][column / 2][quarter & 1] chunks of 16 bytes: a lane (pixel m, group g) reads
+    // chunk ((g >> 1) XH + x0 + m) 2 + (g & 1), i.e. 32 bytes between the lanes of a group and 16 bytes between groups g and g + 1.
+    // tools/lds_probe.hip (MI355X, LDS cycles per wave-instruction): ds_read_b128 5.4 in this pattern (and for lane groups a multiple of
+    // 256 bytes apart), 8.1 when the groups are 128 / 272 / 336 bytes apart (the quarter-major layout used first); ds_read_b64 5.3 whatever
+    // the pattern - so the two-ds_read_b64 form (conflict free by construction) paid 10.6 cycles per fragment plane for the same 1 KiB.
+    const int goff = ((g >> 1) * XH * 2 + (g & 1)) * 8;
     // staging items of one region row: (plane, column, channel quarter)
     constexpr int ROW_ITEMS = NP * RW * 4, ITEMS = (ROW_ITEMS + 63) / 64;
     constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
                 const int pl = it / (RW * 4), rem = it - pl * (RW * 4), pc = rem >> 2, cq = rem & 3;
                 it_pc[q] = pc;
                 it_goff[q] = (uint32_t)((pl * i_plane + cq * 8 + (size_t)pc * 32) * 2);
-                it_loff[q] = pl * PLANE + (((pc & 1) * 4 + cq) * XH + (pc >> 1)) * 8;
+                it_loff[q] = pl * PLANE + ((pc & 1) * 4 * XH + ((cq >> 1) * XH + (pc >> 1)) * 2 + (cq & 1)) * 8;
                 if (item < ROW_ITEMS) it_valid |= 1u << q;
             }
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)b * H * W * 32), 0, 0x7FFFFFF0, 0x00020000);
@@ -321,17 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
         for (int j = 0; j < MT; j++) {
             // this lane's pixel of M-tile j: p = 16 j + m, row p / 20, column p % 20; input row 2 oy, column 2 ox (parity 0, chunk ox)
             const int pp = 16 * j + m, oy = pp / TW, ox = pp - oy * TW;
-            const int base = 2 * oy * ROW + ox * 8 + goff;
+            const int base = 2 * oy * ROW + ox * 16 + goff;
             f32x4_p acc = bv;                                     // bias = initial accumulator
 #pragma unroll
             for (int st = 0; st < NSTEP; st++) {
                 bf16x8 a[3];
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) {
-                    const uint16_t* src = &img[pl * PLANE + base + tap_elem(st)];
-                    const bf16x4_p first = *reinterpret_cast<const bf16x4_p*>(src);
-                    const bf16x4_p other = *reinterpret_cast<const bf16x4_p*>(src + second);
-                    a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
+                    a[pl] = *reinterpret_cast<const bf16x8*>(&img[pl * PLANE + base + tap_elem(st)]);
                 }
                 if constexpr (NP == 3) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);

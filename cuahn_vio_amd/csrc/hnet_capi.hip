@@ -517,7 +517,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                     for (int ln = 0; ln < 64; ln++) {
                         const int n = nt * 16 + (ln & 15), gg = ln >> 4, kh = st / 3, kw = st % 3;
                         for (int j = 0; j < 8; j++) {
-                            const int ci = 8 * gg + ((((gg & 1) ^ (gg >> 1)) != 0) ? (j + 4) % 8 : j);     // groups 1, 2 read the high half first
+                            const int ci = 8 * gg + j;
                             uint16_t sp[3];
                             split3(w->data[(((size_t)n * 32 + ci) * 3 + kh) * 3 + kw], sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * 9 + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
