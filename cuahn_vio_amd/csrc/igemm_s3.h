@@ -589,6 +589,17 @@ struct LeanRow<HeadLoaderS3> {
     __device__ inline uint32_t voffset(const S3Params&, const Tap& t) const { return valid ? (uint32_t)(off + t.delta) : S3_OOB; }
 };
 
+// chunk swizzle of the lean kernel's tiles (fragments are read in the 16x16x32 shape only: lane (row r16, chunk group g16)).
+// A ds_read_b128 is served in four passes of 16 lanes: rows {0-3, 12-15} of lane group g with rows {4-11} of group g + 1, then the
+// complement (tools/lds_probe.hip); a pass is conflict free when its 16 lanes hit 16 different 16-byte slots of the 256-byte bank row.
+//   128-byte rows: chunk ^ ((row >> 1) & 7), as s3_swz (5.3 LDS cycles per wave-instruction);
+//   64-byte rows:  chunk ^ (3 * ((row >> 3) & 1)) - 5.4 cycles, where s3_swz<4>'s chunk ^ ((row >> 2) & 3) costs 8.1: rows r and r + 4k of
+//   the two groups of a pass met in the same slot (conflict share 0.33 of block_1_2's LDS cycles, profiles/r02_v3).
+template <int CH>
+__device__ __forceinline__ int s3_swz_m16(int row, int chunk) {
+    return CH == 4 ? (chunk ^ (((row >> 3) & 1) * 3)) * 8 : (chunk ^ ((row >> 1) & 7)) * 8;   // bf16 elements
+}
+
 template <class L, int BM, int BN, int WGM, bool OUT32, int BKT = 64, int NP = 3>
 __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
     constexpr int BK = BKT;
@@ -634,9 +645,9 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
     // lane-invariant LDS element offsets of the staged chunks
     int a_lds[A_ROWS], b_lds[B_ROWS];
 #pragma unroll
-    for (int i = 0; i < A_ROWS; i++) a_lds[i] = (srow + i * RPP) * BK + s3_swz<CH>(srow + i * RPP, schunk);
+    for (int i = 0; i < A_ROWS; i++) a_lds[i] = (srow + i * RPP) * BK + s3_swz_m16<CH>(srow + i * RPP, schunk);
 #pragma unroll
-    for (int i = 0; i < B_ROWS; i++) b_lds[i] = (srow + i * RPP) * BK + s3_swz<CH>(srow + i * RPP, schunk);
+    for (int i = 0; i < B_ROWS; i++) b_lds[i] = (srow + i * RPP) * BK + s3_swz_m16<CH>(srow + i * RPP, schunk);
 
     f32x4_m16 acc16[TM16][TN16];
 #pragma unroll
@@ -702,14 +713,14 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
                 const int r = wm * WM + i * 16 + r16;
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
             }
 #pragma unroll
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
             }
 #pragma unroll
             for (int i = 0; i < TM16; i++)

@@ -91,6 +91,9 @@ int main() {
     mk("b128 32B stride (m*32 + g*16): 8-channel pixels, tap pairs", 16, false, [&](int m, int g, int) { return m * 32 + (g & 1) * 16 + (g >> 1) * 2048; });
     mk("b128 GEMM-style 128B rows swizzled (row m, chunk g^((m>>1)&7))", 16, false, [&](int m, int g, int) { return m * 128 + ((g ^ ((m >> 1) & 7)) * 16); });
     mk("b128 64B rows swizzled (row m, chunk g^((m>>2)&3))", 16, false, [&](int m, int g, int) { return m * 64 + ((g ^ ((m >> 2) & 3)) * 16); });
+    mk("b128 64B rows, chunk g^(3*((m>>3)&1))", 16, false, [&](int m, int g, int) { return m * 64 + ((g ^ (((m >> 3) & 1) * 3)) * 16); });
+    mk("b128 64B rows, chunk g^((m>>2)&1)*2^((m>>3)&1)", 16, false, [&](int m, int g, int) { return m * 64 + ((g ^ (((m >> 2) & 1) * 2) ^ ((m >> 3) & 1)) * 16); });
+    mk("b128 64B rows unswizzled", 16, false, [&](int m, int g, int) { return m * 64 + g * 16; });
     mk("read2_b64 contiguous 16B per lane (lane*16)", 82, false, [](int, int, int l) { return l * 16; });
     mk("read2_b64 16B per lane at +8 (8-byte aligned only)", 82, false, [](int, int, int l) { return l * 16 + 8; });
     mk("read2_b64 patch: m*8 + g&1 *16, rows for g>>1 (conv_first)", 82, false, [&](int m, int g, int) { return m * 8 + (g & 1) * 16 + (g >> 1) * 344; });
