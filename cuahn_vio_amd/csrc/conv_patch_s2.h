@@ -10,12 +10,15 @@
 // Split-bf16 x3 arithmetic as igemm_s3.h (six MFMAs per step).  Each wave owns one 16-channel half of the outputs
 // and keeps its weight fragments in VGPRs for the lifetime of the workgroup.
 //
-// Round 2: the operand chunk of a lane is read as two ds_read_b64 — even lane groups low half first, odd groups (the
-// other channel half, XH chunks further) high half first — instead of one ds_read_b128.  A ds_read_b128 serves lanes
-// {0-3,12-15,20-27} in one LDS cycle, i.e. parts of two 16-chunk windows that would have to start on the same bank to
-// not collide: every fragment read was 2-way bank-conflicted (profiles/r01_v7: conflict share 0.49-0.53 of the LDS
-// cycles).  With the halves swapped the 32 lanes of a b64 access cover all 64 banks exactly once.  Odd groups so hold
-// their channels in the order (4..7, 0..3); their weight fragments are packed to match (hnet_capi.hip).
+// Operand reads (round 2, two steps).  Round 1 kept the region as [plane][row][column parity][channel half][column / 2] chunks and read
+// a fragment with one ds_read_b128: 2-way bank conflicts on every read (conflict share 0.49-0.53 of the LDS cycles, profiles/r01_v7) -
+// a ds_read_b128 is served in passes of 16 lanes that mix two lane groups (rows {0-3, 12-15} of group g with {4-11} of g + 1,
+// tools/lds_probe.hip), and the two groups' 16-chunk windows were XH chunks apart.  Step 1 (B128 = false, kept as the A/B switch
+// HNET_PATCH_B128=0): two ds_read_b64 per fragment, odd groups high half first, weights packed in the matching channel order -
+// conflict free by construction, but the probe shows a ds_read_b64 costs as many LDS cycles (5.3) as a conflict-free ds_read_b128
+// (5.4), i.e. twice per byte.  Step 2 (B128 = true, default): [plane][row][column parity][column / 2][channel half] - 32 bytes
+// between the lanes of a group, 16 between the groups g, g + 1 of a tap - read with one ds_read_b128, conflict free in that pass
+// structure: block_3_1 0.199 -> 0.192 ms, block_4_2 0.150 -> 0.140 ms in process (profiles/r02_ab_patch_b128.log).
 // NP = number of bf16 planes (3 = split-bf16, 1 = plain bf16 operands).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,7 +41,7 @@ typedef float f32x4_p __attribute__((ext_vector_type(4)));
 typedef short bf16x4_p __attribute__((ext_vector_type(4)));
 
 // in: S3 planes [3][B][H][W][16];  wfrag: [2 halves of cout][NSTEP][3][64 lanes] x 16 B;  out16: [3][B][H/2][W/2][32]
-template <int KS, int NP>
+template <int KS, int NP, bool B128 = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
                                                             const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             uint16_t* __restrict__ out16, size_t o_plane, int H, int W,
@@ -69,9 +72,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
     auto tap_elem = [](int t) constexpr {
         const int tt = t < KS * KS ? t : KS * KS - 1;            // the padding tap of the last step has zero weights
         const int kh = tt / KS, kw = tt - kh * KS;
-        return (((kh * 2 + (kw & 1)) * 2) * XH + (kw >> 1)) * 8;
+        return B128 ? ((kh * 2 + (kw & 1)) * XH + (kw >> 1)) * 16 : (((kh * 2 + (kw & 1)) * 2) * XH + (kw >> 1)) * 8;
     };
-    const int lane_off = (g & 1) * (XH * 8 + 4);                 // channel half of the group; odd groups: high 8 bytes first
+    // B128 (A/B switch HNET_PATCH_B128): region rows as [column parity][column / 2][channel half] chunks (32 bytes per pixel) and ONE
+    // ds_read_b128 per fragment plane - 32 bytes between the lanes of a group, 16 between the groups g, g + 1 of a tap: 5.4 LDS cycles per
+    // wave-instruction in tools/lds_probe.hip, against 2 x 5.3 for the two ds_read_b64 of the half-major layout
+    const int lane_off = B128 ? (g & 1) * 8 : (g & 1) * (XH * 8 + 4);   // channel half of the group; (b64 form) odd groups: high 8 bytes first
     const int second = 4 - 8 * (g & 1);                         // element offset from the first to the second 8-byte read
     // staging items of one region row: (plane, column, channel half), NP*RW*2 of them, ITEMS per lane
     constexpr int ROW_ITEMS = NP * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
                 const int pl = it / (RW * 2), rem = it - pl * (RW * 2), pc = rem >> 1, hf = rem & 1;
                 it_pc[q] = pc;
                 it_goff[q] = pl * i_plane + hf * 8;
-                it_loff[q] = pl * PLANE + (((pc & 1) * 2 + hf) * XH + (pc >> 1)) * 8;
+                it_loff[q] = pl * PLANE + (B128 ? ((pc & 1) * XH + (pc >> 1)) * 2 + hf : ((pc & 1) * 2 + hf) * XH + (pc >> 1)) * 8;
                 if (item < ROW_ITEMS) it_valid |= 1u << q;
             }
         }
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
 #pragma unroll 1
         for (int j = 0; j < TH / 2; j++) {
             const int oy = (wave >> 1) + 2 * j;
-            const int base = ((2 * oy) * 2 * 2 * XH + m) * 8 + lane_off;   // row 2*oy, parity 0, this group's half, column m
+            const int base = (B128 ? ((2 * oy) * 2 * XH + m) * 16 : ((2 * oy) * 2 * 2 * XH + m) * 8) + lane_off;   // row 2*oy, parity 0, column m, this group's half
             int gv = g;                                           // opaque per M-tile: the 13 tap addresses are formed next to their
             asm volatile("" : "+v"(gv));                          // reads instead of being hoisted into 13 registers
             const bool odd_tap = (gv >> 1) != 0;                  // lane groups 2, 3 take the odd tap of a step
@@ -164,9 +170,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) {
                     const uint16_t* src = &img[pl * PLANE + base + (odd_tap ? tap_elem(2 * st + 1) : tap_elem(2 * st))];
-                    const bf16x4_p first = *reinterpret_cast<const bf16x4_p*>(src);
-                    const bf16x4_p other = *reinterpret_cast<const bf16x4_p*>(src + second);
-                    a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (B128) {
+                        a[pl] = *reinterpret_cast<const bf16x8*>(src);
+                    } else {
+                        const bf16x4_p first = *reinterpret_cast<const bf16x4_p*>(src);
+                        const bf16x4_p other = *reinterpret_cast<const bf16x4_p*>(src + second);
+                        a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
                 }
                 if constexpr (NP == 3) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);

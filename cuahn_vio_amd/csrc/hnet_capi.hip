@@ -94,6 +94,7 @@ struct hnet_ctx {
     int n_planes = 3;                  // bf16 planes the matrix-core layers read and write: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
+    bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
@@ -332,7 +333,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             else if (c->s3 && conv_is_first_s2(l) && c->first_s2 && c->s2_frag[l] && o16)
                 STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
-                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
+                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
                                      c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes));
@@ -426,6 +427,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
+    c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
     // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
     // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
@@ -537,7 +539,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                         const int kh = t / ks, kw = t % ks;
                         for (int j = 0; j < 8; j++) {
                             // odd lane groups read their 16-byte chunk high half first (conv_patch_s2.h): element j = channel (j + 4) % 8 of the half
-                            const int ci = 8 * (gg & 1) + ((gg & 1) ? (j + 4) % 8 : j);
+                            const int ci = 8 * (gg & 1) + (((gg & 1) && !c->patch_b128) ? (j + 4) % 8 : j);
                             uint16_t sp[3];
                             split3(w->data[(((size_t)n * 16 + ci) * ks + kh) * ks + kw], sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * nstep + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
@@ -1150,7 +1152,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
         if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
-            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
+            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128));
         } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),

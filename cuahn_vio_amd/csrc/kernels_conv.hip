@@ -161,9 +161,9 @@ hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag,
 }
 
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
-                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes) {
-    return n_planes == 1 ? launch_conv_patch_np<1>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s)
-                         : launch_conv_patch_np<3>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s);
+                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes, bool b128) {
+    return n_planes == 1 ? launch_conv_patch_np<1>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128)
+                         : launch_conv_patch_np<3>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128);
 }
 
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
