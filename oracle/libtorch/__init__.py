@@ -27,9 +27,10 @@ def build(force: bool = False) -> str:
     return HARNESS
 
 
-def model_path(state, variant: str, n_mc: int, tag: str = "synth0") -> str:
-    """TorchScript file of the restatement with `state`'s weights; `tag` names the weight set in the file name"""
-    path = os.path.join(BUILD, f"restatement_{variant}_n{n_mc}_{tag}.pt")
+def model_path(state, variant: str, n_mc: int, tag: str = "synth0", out_dir: str = BUILD) -> str:
+    """TorchScript file of the restatement with `state`'s weights; `tag` names the weight set in the file name.  Only the
+    benchmark's default model is kept under oracle/_build (27 MB, it travels with the snapshot); tests pass a temporary directory"""
+    path = os.path.join(out_dir, f"restatement_{variant}_n{n_mc}_{tag}.pt")
     if not os.path.exists(path):
         from . import trace_restatement
         trace_restatement.trace(state, variant, n_mc, path)

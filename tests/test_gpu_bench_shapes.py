@@ -127,6 +127,32 @@ def test_patch_kernels_real_geometry_multi_pair(eng_s3, state, layer):
         assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
 
 
+@pytest.mark.parametrize("layer,batch", [(9, 80), (16, 80), (0, 3), (0, 40), (3, 3), (3, 40)])
+def test_round2_kernels_real_geometry_multi_pair(eng_s3, state, layer, batch):
+    """the kernels added late in round 2 at their network geometry, every element vs the oracle conv:
+    conv_patch32_s2_kernel (block_3_2 / block_4_3, 56x80x32 -> 28x40x64) with 80 pairs = 1120 tiles on 512 persistent workgroups
+    (more than two tiles per workgroup, reverse tile walk, both border tiles of every image);
+    conv7_c2_s2_s3_kernel (block_1_1 28x40 / block_2_1 56x80, Cin 2) in its small-batch form (2-row bands, batch 3) and its
+    large-batch form (7-row bands, batch 40)"""
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    from oracle import pyoracle
+    name, cin, cout, k, s = CONV_LAYERS[layer]
+    prefix = "model_last_block_list.0." if name[6] == "4" else "model_part1."
+    h, w = {9: (56, 80), 16: (56, 80), 0: (28, 40), 3: (56, 80)}[layer]
+    rng = np.random.default_rng(100 + layer)
+    x = rng.standard_normal((batch, cin, h, w)).astype(np.float32)
+    got = eng_s3.op_conv(layer, x)
+    for b in sorted(set([0, 1, 2, batch // 2, batch - 2, batch - 1])):
+        ref = pyoracle.conv_lrelu(x[b], state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"], s)
+        assert got[b].shape == ref.shape
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
+    # pairs are independent: every pair of the batch equals the same pair run alone (bitwise)
+    for b in (1, batch - 1):
+        alone = eng_s3.op_conv(layer, x[b:b + 1])
+        assert np.array_equal(alone[0], got[b]), (name, b)
+
+
 @pytest.fixture(scope="module")
 def eng_s3(blob):
     from cuahn_vio_amd.homography_net import HnetEngine

@@ -17,11 +17,11 @@ def state():
 
 
 @pytest.mark.parametrize("name", ["prior1_p0_s6", "full_mask16_s8"])
-def test_cpp_torchscript_forward_matches_reference_golden(state, name):
+def test_cpp_torchscript_forward_matches_reference_golden(state, name, tmp_path):
     from oracle import libtorch as lt
     g, i1, i2, prior, _btr = load_case(name)
     variant, n_mc, p = str(g["variant"]), int(g["n_mc"]), float(g["p"])
-    model = lt.model_path(state, variant, n_mc)
+    model = lt.model_path(state, variant, n_mc, out_dir=str(tmp_path))
     masks = lt.keep_masks(n_mc, p, int(g["mc_seed"]) if "mc_seed" in g else 0, int(g["pair_seq"]) if "pair_seq" in g else 0)
     r = lt.run(model, i1, i2, prior, masks, threads=4, seconds=0.0)
     assert r["forwards"] >= 2 and r["ms_per_forward"] > 0
