@@ -166,7 +166,9 @@ def test_op_conv_small_ragged_shapes(eng_full, state):
     """odd spatial sizes (7x10 -> 4x5 is the reference's own odd case) and tiny inputs"""
     from oracle import pyoracle
     rng = np.random.default_rng(99)
-    for layer, (h, w) in ((19, (7, 10)), (19, (1, 1)), (14, (5, 3)), (13, (9, 11)), (8, (6, 7))):
+    # (layers 0, 3, 9, 16 have kernels specialised to the network's geometry: any other size takes the generic implicit-GEMM route)
+    for layer, (h, w) in ((19, (7, 10)), (19, (1, 1)), (14, (5, 3)), (13, (9, 11)), (8, (6, 7)), (0, (20, 24)), (3, (9, 13)), (9, (30, 44)),
+                          (16, (7, 9)), (15, (11, 6))):
         from cuahn_vio_amd.weights import CONV_LAYERS
         name, cin, cout, k, s = CONV_LAYERS[layer]
         x = rng.standard_normal((3, cin, h, w)).astype(np.float32)

@@ -98,6 +98,7 @@ int main() {
     mk("read2_b64 16B per lane at +8 (8-byte aligned only)", 82, false, [](int, int, int l) { return l * 16 + 8; });
     mk("read2_b64 patch: m*8 + g&1 *16, rows for g>>1 (conv_first)", 82, false, [&](int m, int g, int) { return m * 8 + (g & 1) * 16 + (g >> 1) * 344; });
     mk("b64 patch: m*8 + g&1 *16, rows for g>>1 (conv_first)", 8, false, [&](int m, int g, int) { return m * 8 + (g & 1) * 16 + (g >> 1) * 344; });
+    mk("b128 UNALIGNED (8-byte) conv_first pattern m*8 + g&1*16 + rows", 16, false, [&](int m, int g, int) { return m * 8 + (g & 1) * 16 + (g >> 1) * 344; });
     mk("b128 write contiguous", 16, true, [](int, int, int l) { return l * 16; });
     mk("b128 write patch32 staging (cq fastest, XH=21)", 16, true, [&](int, int, int l) { const int cq = l & 3, pc = l >> 2; return (((pc & 1) * 4 + cq) * 21 + (pc >> 1)) * 16; });
     mk("b128 write patch32 staging (XH=22)", 16, true, [&](int, int, int l) { const int cq = l & 3, pc = l >> 2; return (((pc & 1) * 4 + cq) * 22 + (pc >> 1)) * 16; });
