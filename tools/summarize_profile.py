@@ -26,6 +26,25 @@ def one(pattern):
 st = one("stats/**/*kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(dst, tag + "_kernel_stats.csv"))
+# the --stats table averages over every launch of a kernel, including the batch-1 warm-up forward of hnet_create: the per-launch trace
+# of the same run, restricted to the launches with the kernel's largest grid (= the batch-256 launches), is what bench.py's per-stage
+# HIP events have to agree with
+tr = one("stats/**/*kernel_trace.csv")
+if tr:
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(tr)):
+        g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        per[r["Kernel_Name"]][g].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    rows = []
+    for k, by_grid in per.items():
+        g = max(by_grid)
+        v = by_grid[g]
+        rows.append((sum(v), k, g, len(v), sum(v) / len(v), min(v), max(v)))
+    with open(os.path.join(dst, tag + "_kernel_stats_full_batch.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace of the same run as " + tag + "_kernel_stats.csv: launches with the kernel's largest grid only (batch 256)\n")
+        f.write("kernel,grid_threads,launches,avg_us,min_us,max_us\n")
+        for _t, k, g, n, a, lo, hi in sorted(rows, reverse=True):
+            f.write('"%s",%d,%d,%.1f,%.1f,%.1f\n' % (k, g, n, a, lo, hi))
 
 
 def per_kernel_max(path, counter):
