@@ -658,29 +658,50 @@ hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_b
     return hipGetLastError();
 }
 
-// ensemble + transfer + assembly from per-sample outputs [B][n][8]: 8 lanes per pair compute the 8 component
-// statistics (two passes over the samples, model_to_trace.py:274-280), lane 0 of the group finishes (geom.h).
+// ensemble + transfer + assembly from per-sample outputs [B][n][8] (model_to_trace.py:274-280): one wave per pair.  Lane (component
+// i = lane & 7, sample chunk c = lane >> 3) sums samples c, c + 8, ... in double, the eight chunks are combined by xor-shuffles (a fixed
+// tree: the result does not depend on the batch size or the slot), then the reference's second pass over the squared deviations
+// from the fp32 mean; lane 0 finishes (geom.h).  (Round 1 ran 8 lanes per pair over all samples in sequence: 11.4 us at batch 1, most
+// of it 2 x 32 dependent double-precision exp / add chains per lane.)
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
                                                        const float* __restrict__ H1, int batch, float* __restrict__ mean,
                                                        float* __restrict__ cov, float* __restrict__ Htot) {
-    const int t = threadIdx.x, i = t & 7, grp = t >> 3;
-    const int b = blockIdx.x * 8 + grp;
-    const bool ok = b < batch;
-    const int bb = ok ? b : 0;
-    double pb, en;
-    ensemble_component(mean_s + (size_t)bb * n * 8, logvar_s + (size_t)bb * n * 8, n, i, &pb, &en);
+    const int t = threadIdx.x, i = t & 7, c = t >> 3;
+    const int b = blockIdx.x;
+    const float* ms = mean_s + (size_t)b * n * 8;
+    const float* lv = logvar_s + (size_t)b * n * 8;
+    double sm = 0, sv = 0;
+    for (int s = c; s < n; s += 8) {
+        sm += (double)ms[s * 8 + i];
+        sv += exp((double)lv[s * 8 + i]);
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) { sm += shfl_xor_f64(sm, m); sv += shfl_xor_f64(sv, m); }
+    const float mb = (float)(sm / n), vb = (float)(sv / n);
+    double se = 0;
+    for (int s = c; s < n; s += 8) { const double d = (double)mb - (double)ms[s * 8 + i]; se += d * d; }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) se += shfl_xor_f64(se, m);
+    const double en = (double)(float)((double)(float)(se / n) + (double)vb);
+    const double pb = (double)(float)(p4(i) + (double)mb);
     double pbar[8], ens[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        pbar[k] = __shfl(pb, grp * 8 + k);
-        ens[k] = __shfl(en, grp * 8 + k);
+        pbar[k] = __hiloint2double(__shfl(__double2hiint(pb), k), __shfl(__double2loint(pb), k));
+        ens[k] = __hiloint2double(__shfl(__double2hiint(en), k), __shfl(__double2loint(en), k));
     }
-    if (ok && i == 0) transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
+    if (t == 0) transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
                             float* mean, float* cov, float* Htot, hipStream_t s) {
-    hipLaunchKernelGGL(mc_finish_kernel, dim3((batch + 7) / 8), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
     return hipGetLastError();
 }
 
