@@ -189,9 +189,10 @@ def cpu_baseline_py(state, prev, curr, prior, variant, n_mc, budget_s, avail, bt
 
 
 def committed_traffic(kernel_substr, batch):
-    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    collected separately with tools/profile_round.sh at batch 256).  Not measured in this run: returned with its source so
-    that a reader can see which build it belongs to; (None, None) when no matching profile is committed."""
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE,
+    collected separately with tools/profile_round.sh at batch 256; gfx950 correction of MI355X_MICROARCH.md §HBM, re-calibrated for
+    these kernels' access shapes with tools/traffic_calib.hip: bytes = 2 x FETCH_SIZE + WRITE_SIZE).  Not measured in this run:
+    returned with its source so that a reader can see which build it belongs to; (None, None) when no matching profile is committed."""
     import csv
     import glob
     if batch != 256:
@@ -203,7 +204,7 @@ def committed_traffic(kernel_substr, batch):
         rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
     for r in rows:
         if kernel_substr in r["kernel"]:
-            return ((float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0,
+            return ((2.0 * float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0,
                     "profiles/" + os.path.basename(files[-1]))
     return None, None
 

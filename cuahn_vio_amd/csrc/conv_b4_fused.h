@@ -431,7 +431,15 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const uint32_t gvo1 = (uint32_t)(((size_t)(pc1 >> 5) * o_plane + ((pc1 & 31) >> 1) * 16 + (pc1 & 1) * 8) * 2);
 
     const bool reverse = (flags & 1) != 0;
+    // XCD-aware tile order (r02_v9).  Slot t = blockIdx.x + k gridDim.x is processed by workgroup blockIdx.x, and consecutive workgroup ids
+    // go to consecutive XCDs, each with a private L2: with tile = slot, the 23 x 80-pixel patches of neighbouring tiles - which overlap by
+    // 2.05x in total - were fetched by eight different L2s (FETCH_SIZE, corrected x2: 518 MB per launch for 242 MB of input).  Here XCD x
+    // owns the contiguous tile range [x T/8, (x + 1) T/8) and walks it in step with its 64 (x 2) workgroups, so the tiles resident on one
+    // XCD at any time are neighbours in the image.  flags bit 4 switches back (A/B).
+    const bool xcd_order = (flags & 16) == 0 && (n_tiles & 7) == 0 && (gridDim.x & 7) == 0;
+    const int t8 = n_tiles >> 3;
     auto tile_origin = [&](int t, int& b, int& by, int& bx) {
+        if (xcd_order) t = (t & 7) * t8 + (t >> 3);
         int bid = reverse ? n_tiles - 1 - t : t;
         bx = bid % (W1 / TW1); bid /= (W1 / TW1);
         by = bid % (H1 / TH1);

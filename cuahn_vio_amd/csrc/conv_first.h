@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
     uint32_t okbits = 0;
     // unconditional float2 loads from a clamped address; zero is selected when the registers are consumed
     auto patch_load = [&](int t) {
-        int bid = t;
+        int bid = s3p::xcd_tile(t, n_tiles, gridDim.x);
         const int tx = bid % tiles_x; bid /= tiles_x;
         const int ty = bid % tiles_y;
         const int b = bid / tiles_y;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
         for (int i = 0; i < 4; i++) bv[q][i] = bias[(8 * q + 4 * hh + i) & 15];
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    int bid = tile;
+    int bid = s3p::xcd_tile(tile, n_tiles, gridDim.x);
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;

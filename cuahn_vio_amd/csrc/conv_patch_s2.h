@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
         // reverse: walk the tiles from the end of the batch.  The producer wrote this 440 MB input front to back and the
         // 256 MB Infinity Cache is LRU: what it still holds is the END of the tensor, which the forward order would evict
         // before reaching it
-        int bid = reverse ? n_tiles - 1 - tile : tile;
+        int bid = s3p::xcd_tile(reverse ? n_tiles - 1 - tile : tile, n_tiles, gridDim.x);
         const int bx = bid % tiles_x; bid /= tiles_x;
         const int by = bid % tiles_y;
         const int b = bid / tiles_y;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
     constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int bid = reverse ? n_tiles - 1 - tile : tile;
+        int bid = s3p::xcd_tile(reverse ? n_tiles - 1 - tile : tile, n_tiles, gridDim.x);
         const int bx = bid % tiles_x; bid /= tiles_x;
         const int by = bid % tiles_y;
         const int b = bid / tiles_y;

@@ -87,7 +87,7 @@ struct hnet_ctx {
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
-    int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments)
+    int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments); bit 4: no XCD-aware tile order (HNET_B4_XCD=0)
     int b4_cfg = 5;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging
     uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
     size_t x16_plane = 0;              // dwords per plane
@@ -429,6 +429,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
     c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
+    if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
     // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
     // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
     c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(5, atoi(getenv("HNET_B4_CFG")))) : 5;

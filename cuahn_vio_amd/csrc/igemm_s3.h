@@ -114,6 +114,11 @@ struct ConvLoaderS3 {
 
 // packed epilogue helpers shared by the direct-convolution kernels (conv_first.h, conv_patch_s2.h, conv_b4_fused.h)
 namespace s3p {
+// XCD-aware tile order of the persistent / one-tile-per-workgroup kernels: slot t (= workgroup id + k gridDim.x; consecutive workgroup
+// ids go to consecutive XCDs, each with a private L2) -> tile id such that XCD x owns the contiguous range [x n/8, (x + 1) n/8) and the
+// tiles resident on one XCD at any time are neighbours in the image, whose halos then hit in that L2 (block4_fused_kernel: FETCH_SIZE
+// 518 -> 246 MB per launch for 242 MB of input).  Needs n and the grid to be multiples of 8; identity otherwise.
+__device__ __forceinline__ int xcd_tile(int t, int n, int grid) { return ((n | grid) & 7) == 0 ? (t & 7) * (n >> 3) + (t >> 3) : t; }
 __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

@@ -61,11 +61,14 @@ if fe and wr:
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.csv"), "w") as out:
         out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) of `python3 bench.py --steps 2 --warmup 1`, batch 256, bf16x3 path.\n")
         out.write("# Values are per launch at batch 256 (max over launches: the batch-1 warm-up launch of hnet_create is excluded). Raw counter values in KiB;\n")
-        out.write("# FETCH_SIZE under-counts wide (16 B/lane) coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md §HBM) - not corrected here.\n")
+        out.write("# gfx950 correction (MI355X_MICROARCH.md §HBM, re-calibrated for the access shapes of these kernels with tools/traffic_calib.hip on known\n")
+        out.write("# byte counts - profiles/r02_traffic_calibration.log): FETCH_SIZE reports exactly half the bytes for 16-, 8- and 4-byte-per-lane loads and for\n")
+        out.write("# LDS-DMA loads; WRITE_SIZE is exact for 16- and 8-byte-per-lane stores.  traffic_MB = (2 x FETCH_SIZE + WRITE_SIZE) / 1024: bytes that leave\n")
+        out.write("# the XCD's L2 (Infinity-Cache hits are included).\n")
         cw = csv.writer(out)
-        cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_full_batch_launch", "WRITE_SIZE_KiB_full_batch_launch"])
+        cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_full_batch_launch", "WRITE_SIZE_KiB_full_batch_launch", "traffic_MB_corrected"])
         for k in sorted(f):
-            cw.writerow([k, f[k][1], f[k][0], w.get(k, (0, 0))[0]])
+            cw.writerow([k, f[k][1], f[k][0], w.get(k, (0, 0))[0], round((2 * f[k][0] + w.get(k, (0, 0))[0]) / 1024.0, 1)])
 
 if len(sys.argv) > 2:
     pm = glob.glob(os.path.join(ROOT, "gpurun_out", sys.argv[2], "**", "*counter_collection.csv"), recursive=True)[0]
