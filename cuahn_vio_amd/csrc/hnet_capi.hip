@@ -95,6 +95,7 @@ struct hnet_ctx {
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
+    bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
     bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
@@ -332,6 +333,8 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s, c->n_planes));
             else if (c->s3 && conv_is_first_s2(l) && c->first_s2 && c->s2_frag[l] && o16)
                 STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
+            else if (c->s3 && c->use_region5 && conv_is_region5_layer(l) && h == (l == 1 ? 14 : 28) && w == (l == 1 ? 20 : 40))
+                STAGE(launch_conv5_region(l, in16, in_plane, B, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128));
             else if (c->s3 && conv_is_s3_layer(l))
@@ -427,6 +430,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
+    c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
     c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
     if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
@@ -512,6 +516,26 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             CK(hipMemcpy(c->s2_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
             const char* e = getenv("HNET_FIRST_S2");
             c->first_s2 = !(e && atoi(e) == 0);
+        }
+        if (c->s3 && c->use_region5 && conv_is_region5_layer(l)) {   // MFMA A-fragments [step = chunk * 13 + s][wave wn][tile j][plane][lane]: lane (n, g) holds row n of
+            const int nch = d.cin / 16;            // output-channel tile 2 wn + j, K = 8 g + e = tap 2 s + (g >> 1), channel 16 chunk + 8 (g & 1) + e
+            std::vector<uint16_t> wp((size_t)nch * 13 * 4 * 2 * 3 * 64 * 8, 0);
+            for (int ch = 0; ch < nch; ch++)
+                for (int st = 0; st < 13; st++)
+                    for (int wn = 0; wn < 4; wn++)
+                        for (int j = 0; j < 2; j++)
+                            for (int ln = 0; ln < 64; ln++) {
+                                const int n = (2 * wn + j) * 16 + (ln & 15), gg = ln >> 4, t = 2 * st + (gg >> 1);
+                                if (t >= 25) continue;
+                                for (int e = 0; e < 8; e++) {
+                                    uint16_t sp[3];
+                                    split3(w->data[(((size_t)n * d.cin + 16 * ch + 8 * (gg & 1) + e) * 5 + t / 5) * 5 + t % 5], sp[0], sp[1], sp[2]);
+                                    for (int pl = 0; pl < 3; pl++)
+                                        wp[((((((size_t)(ch * 13 + st) * 4 + wn) * 2 + j) * 3 + pl) * 64) + ln) * 8 + e] = sp[pl];
+                                }
+                            }
+            CK(hipMalloc((void**)&c->patch_frag[l], wp.size() * 2));
+            CK(hipMemcpy(c->patch_frag[l], wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
         }
         if (c->s3 && conv_is_patch32_layer(l)) {   // 32 -> 64, 3x3: step st = tap st; lane group g -> channels 8g .. 8g+7 (odd groups rotated by 4)
             std::vector<uint16_t> fr((size_t)4 * 9 * 3 * 64 * 8, 0);
@@ -1151,7 +1175,10 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         uint16_t *p_in = nullptr, *p_out = nullptr;
         HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32));
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
-        if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
+        if (c->use_region5 && conv_is_region5_layer(layer) && h == (layer == 1 ? 14 : 28) && w == (layer == 1 ? 20 : 40)) {
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_conv5_region(layer, p_in, n_in, batch, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
+        } else if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
             HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128));
         } else if (conv_is_s3_layer(layer)) {

@@ -30,6 +30,9 @@ bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
                           float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3);
+bool conv_is_region5_layer(int layer);    // block_1_2 / block_2_2 at their network size (conv5_region.h); wpack = [CIN/16][13 steps][3][128][32] bf16
+hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
+                               size_t o_plane, hipStream_t s, int n_planes = 3);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 bool conv_is_patch32_layer(int layer);    // block_3_2 / block_4_3 at their network size 56x80 (conv_patch32_s2_kernel); same launcher, wfrag [4][9][3][64] x 16 B
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,

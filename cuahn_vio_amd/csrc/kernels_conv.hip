@@ -160,6 +160,13 @@ hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag,
                          : launch_conv_first_s2_np<3>(layer, x_in, wfrag, bias, out16, o_plane, batch, s);
 }
 
+bool conv_is_region5_layer(int layer) { return layer == 1 || layer == 4; }   // block_1_2, block_2_2
+hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
+                               size_t o_plane, hipStream_t s, int n_planes) {
+    return n_planes == 1 ? launch_conv5_region_np<1>(layer, in, i_plane, batch, wpack, bias, out16, o_plane, s)
+                         : launch_conv5_region_np<3>(layer, in, i_plane, batch, wpack, bias, out16, o_plane, s);
+}
+
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes, bool b128) {
     return n_planes == 1 ? launch_conv_patch_np<1>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128)

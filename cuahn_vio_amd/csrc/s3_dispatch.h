@@ -7,6 +7,7 @@
 #include "igemm_s3.h"
 #include "conv_b4_fused.h"
 #include "conv_patch_s2.h"
+#include "conv5_region.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -252,6 +253,24 @@ hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, i
     return hipErrorInvalidValue;
 }
 
+// block_1_2 (layer 1) / block_2_2 (layer 4): 5x5 stride 2 from an LDS-resident input region (conv5_region.h); wpack [CIN/16][13][3][128][32] bf16
+template <int NP>
+hipError_t launch_conv5_region_np(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
+                                  size_t o_plane, hipStream_t s) {
+    if (layer == 1) {
+        typedef Conv5Cfg<128, 14, 20, NP> C;
+        hipLaunchKernelGGL((conv5_region_kernel<128, 14, 20, NP>), dim3((unsigned)(batch * C::TILES_Y)), dim3(512), C::LDS_BYTES, s, in, i_plane,
+                           (const u32x4*)wpack, bias, out16, o_plane);
+    } else if (layer == 4) {
+        typedef Conv5Cfg<64, 28, 40, NP> C;
+        hipLaunchKernelGGL((conv5_region_kernel<64, 28, 40, NP>), dim3((unsigned)(batch * C::TILES_Y)), dim3(512), C::LDS_BYTES, s, in, i_plane,
+                           (const u32x4*)wpack, bias, out16, o_plane);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // first FC of both heads on the bf16 matrix cores.  feat fp32 [B][5120]; w1planes [3][512][5120] bf16;
 // scratch: feat16 [3][B][5120] bf16 and mask [B][n_local][2][640] bytes (context-owned)
 template <int NP>
@@ -319,6 +338,8 @@ hipError_t conv_kernels_init_device_np() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<128, 14, 20, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<128, 14, 20, NP>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<64, 28, 40, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<64, 28, 40, NP>::LDS_BYTES);
     return e;
 }
 
@@ -328,6 +349,7 @@ hipError_t conv_kernels_init_device_np() {
                                                       uint16_t*, size_t, int, hipStream_t, int, int);                                    \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
+    KW template hipError_t launch_conv5_region_np<NP>(int, const uint16_t*, size_t, int, const void*, const float*, uint16_t*, size_t, hipStream_t); \
     KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
                                                     size_t, hipStream_t, bool);                                                                \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \

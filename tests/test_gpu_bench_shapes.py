@@ -175,3 +175,24 @@ def test_iekf_reruns_do_not_enter_the_timing_average(blob):
         net.network_inference(prior, it)
     t = net._eng.last_timing()
     assert t["n_inferences"] == 5 and t["n_main_inferences"] == 2
+
+
+@pytest.mark.parametrize("layer,batch", [(1, 5), (4, 5)])
+def test_conv5_region_kernel_opt_in(blob, state, layer, batch, monkeypatch):
+    """conv5_region_kernel (block_1_2 / block_2_2 from an LDS-resident region, weights streamed into registers) is opt-in
+    (HNET_CONV5_REGION=1: measured at parity with the implicit GEMM): every element vs the oracle conv, and a golden forward"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from cuahn_vio_amd.weights import CONV_LAYERS
+    from oracle import pyoracle
+    monkeypatch.setenv("HNET_CONV5_REGION", "1")
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    name, cin, cout, k, s = CONV_LAYERS[layer]
+    h, w = {1: (14, 20), 4: (28, 40)}[layer]
+    rng = np.random.default_rng(200 + layer)
+    x = rng.standard_normal((batch, cin, h, w)).astype(np.float32)
+    got = eng.op_conv(layer, x)
+    for b in range(batch):
+        ref = pyoracle.conv_lrelu(x[b], state["model_part1." + name + ".0.weight"], state["model_part1." + name + ".0.bias"], s)
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
+    eng.close()
