@@ -351,6 +351,10 @@ template <int N>
 __device__ __forceinline__ void wait6(bf16x4 (&a)[6]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "n"(N));
 }
+template <int N>
+__device__ __forceinline__ void wait3(bf16x4 (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
+}
 using s3p::cvt_pk;
 using s3p::split_pair;
 using s3p::lrelu;
@@ -397,6 +401,14 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     for (int st = 0; st < 7; st++)
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) w1[st][pl] = __builtin_bit_cast(bf16x8, w1frag[(st * 3 + pl) * 64 + lane]);
+    // kernel row 6 alone, as v_mfma_f32_16x16x16_bf16 fragments (K = 8 taps x 2 channels of ONE row): the fourth 32-deep step pairs row 6
+    // with a row of zero weights - half of its six MFMAs' work and of its LDS reads (12.5 % of phase 1) multiplied zeros
+    bf16x4 w0t[3];
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++) {
+        const u32x4 t = w0frag[(4 * 3 + pl) * 64 + lane];
+        w0t[pl] = __builtin_bit_cast(bf16x4, uint2{t[0], t[1]});
+    }
     const int dx = g >> 1, co0 = 4 * (g & 1);            // phase 1: D row 4g + r = (dx, co0 + r)
     f32x4_t bv, bv1;
 #pragma unroll
@@ -409,6 +421,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
 #pragma unroll
     for (int st = 0; st < 4; st++)
         p1a[st] = lds0 + 2 * ((wrow + min(2 * st + (g >> 1), 6)) * PROW0 + (16 * whalf + m) * 4 + 8 * (g & 1));
+    // the 16-deep tail step: kernel row 6, lane group g reads taps 2g, 2g + 1 (8 bytes)
+    const uint32_t p1t = lds0 + 2 * ((wrow + 6) * PROW0 + (16 * whalf + m) * 4 + 4 * g);
     // phase-1 store: pixel column 2m + dx of the half, channels co0..co0+3, region row wrow (+ HW*j as immediate)
     const uint32_t st1a = img0 + 2 * (((wrow * 2 + dx) * XH + 16 * whalf + m) * 8 + co0);
     // phase 2, M-tile j: output row wrow + HW*j, half whalf, column 16*whalf + m; tap t = 4*step + g; even groups read the
@@ -554,13 +568,30 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                     for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
                     acc = b4_mfma<NP>(acc, w, a);
                 };
-                constexpr int R = 2 * NP;                    // reads per step
+                constexpr int R = 2 * NP;                    // reads per 32-deep step; the tail step reads NP
+                bf16x4 ft[3];
                 rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
                 wait6<2 * R>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w0[0]);
-                rd(std::integral_constant<int, 3>{});
-                wait6<2 * R>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
-                wait6<1 * R>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
-                wait6<0>(f[3]); __builtin_amdgcn_sched_barrier(0); mm(f[3], w0[3]);
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    ft[pl] = rd64<JR + pl * PPLANE * 2>(p1t);
+                });
+                wait6<R + NP>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
+                wait6<NP>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
+                wait3<0>(ft); __builtin_amdgcn_sched_barrier(0);
+                // its own accumulator: a 16x16x16 MFMA whose SrcC is the result of a 16x16x32 MFMA issued just before returned wrong sums
+                // (the compiler inserts no wait states for that mixed pair here; with two s_nop 15 in between the results were right).
+                // Two chains of one opcode each have no such dependency; they meet in four v_add.
+                f32x4_t acct = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (NP == 3) {
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[2], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[2], ft[0], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], ft[1], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[1], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], ft[0], acct, 0, 0, 0);
+                }
+                acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[0], acct, 0, 0, 0);
+                acc += acct;
                 // epilogue: D (transposed) row 4g + r = (dx, co0 + r), column m = pixel pair.  Outside the image = block_4_1's zero padding.
                 const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
                 float v[4];

@@ -102,7 +102,7 @@ struct hnet_ctx {
     bool b30_s3 = true;
     uint16_t* s2_frag[4] = {};         // block_1_1 / block_2_1 (layers 0, 3) weights as 16x16x32 A-fragments [Cout/16][4][3][64] x 16 B (conv7_c2_s2_s3_kernel)
     bool first_s2 = true;              // HNET_FIRST_S2=0: the round-1 fp32-MFMA implicit GEMM for these two layers
-    uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B
+    uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B, + slot [4]: kernel row 6 as 16x16x16 fragments
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
     uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
     uint16_t* feat16 = nullptr;        // [3][max_batch][5120] bf16: feat * 1/(1-p), split
@@ -461,7 +461,17 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const Tensor* bi = b.find(pre + "bias", {(uint32_t)d.cout});
         if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
         if (c->s3 && l == 13) {     // block_4_0 for the fused kernel: K index 8g+j of step st = (kh = 2st + (g>>1), kk = 8(g&1) + j)
-            std::vector<uint16_t> fr((size_t)4 * 3 * 64 * 8, 0);
+            std::vector<uint16_t> fr((size_t)5 * 3 * 64 * 8, 0);     // slot 4: kernel row 6 alone as 16x16x16 fragments (K = 4 gg + e = tap 2 gg + (e >> 1), ci = e & 1), low 8 bytes
+            for (int ln = 0; ln < 64; ln++) {
+                const int n = ln & 15, gg = ln >> 4, dx = n >> 3, co = n & 7;
+                for (int e = 0; e < 4; e++) {
+                    const int kk = 4 * gg + e, kw = (kk >> 1) - dx, ci = kk & 1;
+                    if (kw < 0 || kw >= 7) continue;
+                    uint16_t sp[3];
+                    split3(w->data[(((size_t)co * 2 + ci) * 7 + 6) * 7 + kw], sp[0], sp[1], sp[2]);
+                    for (int pl = 0; pl < 3; pl++) fr[(((size_t)4 * 3 + pl) * 64 + ln) * 8 + e] = sp[pl];
+                }
+            }
             for (int st = 0; st < 4; st++)
                 for (int ln = 0; ln < 64; ln++) {
                     const int n = ln & 15, gg = ln >> 4, kh = 2 * st + (gg >> 1);
