@@ -197,7 +197,10 @@ def committed_traffic(kernel_substr, batch):
     import glob
     if batch != 256:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    import re
+    # natural order of the round/version tags (r02_v10 after r02_v9)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")),
+                   key=lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))])
     if not files:
         return None, None
     with open(files[-1]) as f:
