@@ -34,6 +34,7 @@ PRECISIONS = {
     "fp32": (0, 1, PEAK_FP32_MFMA_TFLOPS, "f32"),
     "bf16x3": (2, 6, PEAK_BF16_MFMA_TFLOPS, "f32 as 3 x bf16 planes (six bf16 MFMAs per product, fp32 accumulate)"),
     "bf16": (1, 1, PEAK_BF16_MFMA_TFLOPS, "bf16 operands, fp32 accumulate (REPORTED mode: ~1e-2 px, outside the parity gate)"),
+    "f16x2": (3, 3, PEAK_BF16_MFMA_TFLOPS, "f32 as 2 x fp16 planes (three fp16 MFMAs per product, fp32 accumulate)"),   # fp16 MFMA peak = bf16 MFMA peak
 }
 
 
@@ -47,7 +48,8 @@ def parse(argv=None):
     ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
     ap.add_argument("--precision", default="bf16x3", choices=list(PRECISIONS),
                     help="fp32: exact fp32 MFMA; bf16x3 (default): fp32-grade split-bf16 MFMA, passes the same parity tests; "
-                         "bf16: plain bf16 operands (BASELINE config 2's 'bf16'), reported with its error, not gated")
+                         "bf16: plain bf16 operands (BASELINE config 2's 'bf16'), reported with its error, not gated; "
+                         "f16x2: fp32-grade on the fp16 matrix cores with three MFMAs per product, same parity gates as bf16x3")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "mc", "stream"],
                     help="pairs (default, the headline metric): frame pairs sharded over the GPUs.  mc (BASELINE config 4): "
                          "the SAME pairs on every rank, the N MC-dropout samples sharded over the ranks, one all-gather of the "

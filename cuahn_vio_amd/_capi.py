@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HNET_LIB_PATH") or os.path.join(_PKG, "libhnet_hip.so")
 
 HNET_OK = 0
-PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_F16X2 = 0, 1, 2, 3
 PIX_U8, PIX_F32 = 0, 1
 ERR_NOT_READY = 4
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void conv5_region_kernel(const uint16_t* __res
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) w[j][pl] = __builtin_bit_cast(bf16x8, src[(j * 3 + pl) * 64]);
+            for (int pl = 0; pl < s3_wplanes<NP>; pl++) w[j][pl] = __builtin_bit_cast(bf16x8, src[(j * 3 + pl) * 64]);
     };
 
     // ---- accumulators: M-tiles wm + 2 i x output-channel tiles 2 wn + j; bias = initial value
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void conv5_region_kernel(const uint16_t* __res
     for (int j = 0; j < 2; j++) {
         f32x4_m16 bv;
 #pragma unroll
-        for (int r = 0; r < 4; r++) bv[r] = bias[(2 * wn + j) * 16 + 4 * g + r];
+        for (int r = 0; r < 4; r++) bv[r] = bias[(2 * wn + j) * 16 + 4 * g + r] * s3_acc_scale<NP>;
 #pragma unroll
         for (int i = 0; i < MTW; i++) acc[i][j] = bv;
     }
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512) void conv5_region_kernel(const uint16_t* __res
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 uint32_t pa[3], pb[3];
-                s3p::split_pair<NP>(s3p::lrelu(acc[i][j][0]), s3p::lrelu(acc[i][j][1]), pa);
-                s3p::split_pair<NP>(s3p::lrelu(acc[i][j][2]), s3p::lrelu(acc[i][j][3]), pb);
+                s3p::split_pair<NP>(s3p::act<NP>(acc[i][j][0]), s3p::act<NP>(acc[i][j][1]), pa);
+                s3p::split_pair<NP>(s3p::act<NP>(acc[i][j][2]), s3p::act<NP>(acc[i][j][3]), pb);
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + j * 16 + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
             }

@@ -61,14 +61,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 // the split-bf16 product group: six partial products, smallest first (igemm_s3.h); NP = 1: the plain bf16 product
 template <int NP>
 __device__ __forceinline__ f32x4_t b4_mfma(f32x4_t acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
-    if constexpr (NP == 3) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], a[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[0], acc, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[0], acc, 0, 0, 0);
+    return s3_mfma16<NP>(acc, w, a);         // igemm_s3.h: six bf16 / three fp16 / one bf16 product(s)
 }
 
 // four values of one lane (bias, LeakyReLU, optional zeroing) -> NP packed 8-byte pieces
@@ -80,8 +73,8 @@ __device__ __forceinline__ void b4_pack4(const f32x4_t& acc, const float (&bv)[4
         float v = acc[r] + bv[r];
         v = v > 0.f ? v : v * 0.1f;
         v = ok ? v : 0.f;
-        if constexpr (NP == 3) split3(v, s[0][r], s[1][r], s[2][r]);
-        else s[0][r] = f32_to_bf16_rn(v);
+        static_assert(NP != 2, "the v2 kernel is kept for A/B in the bf16 modes only");
+        s3p::split1<NP>(v, s[0][r], s[1][r], s[2][r]);
     }
 #pragma unroll
     for (int pl = 0; pl < NP; pl++)
@@ -392,27 +385,28 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const int wrow = wave >> 1, whalf = wave & 1;
 
     // ---- weights -> registers, once per (persistent) workgroup
+    constexpr int NW = s3_wplanes<NP>;                                 // weight planes of the mode (igemm_s3.h)
     bf16x8 w0[4][3], w1[7][3];
 #pragma unroll
     for (int st = 0; st < 4; st++)
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) w0[st][pl] = __builtin_bit_cast(bf16x8, w0frag[(st * 3 + pl) * 64 + lane]);
+        for (int pl = 0; pl < NW; pl++) w0[st][pl] = __builtin_bit_cast(bf16x8, w0frag[(st * 3 + pl) * 64 + lane]);
 #pragma unroll
     for (int st = 0; st < 7; st++)
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) w1[st][pl] = __builtin_bit_cast(bf16x8, w1frag[(st * 3 + pl) * 64 + lane]);
+        for (int pl = 0; pl < NW; pl++) w1[st][pl] = __builtin_bit_cast(bf16x8, w1frag[(st * 3 + pl) * 64 + lane]);
     // kernel row 6 alone, as v_mfma_f32_16x16x16_bf16 fragments (K = 8 taps x 2 channels of ONE row): the fourth 32-deep step pairs row 6
     // with a row of zero weights - half of its six MFMAs' work and of its LDS reads (12.5 % of phase 1) multiplied zeros
     bf16x4 w0t[3];
 #pragma unroll
-    for (int pl = 0; pl < NP; pl++) {
+    for (int pl = 0; pl < NW; pl++) {
         const u32x4 t = w0frag[(4 * 3 + pl) * 64 + lane];
         w0t[pl] = __builtin_bit_cast(bf16x4, uint2{t[0], t[1]});
     }
     const int dx = g >> 1, co0 = 4 * (g & 1);            // phase 1: D row 4g + r = (dx, co0 + r)
-    f32x4_t bv, bv1;
+    f32x4_t bv, bv1;                                      // bias = initial accumulator, at the accumulator's scale
 #pragma unroll
-    for (int r = 0; r < 4; r++) { bv[r] = bias0[co0 + r]; bv1[r] = bias1[4 * g + r]; }
+    for (int r = 0; r < 4; r++) { bv[r] = bias0[co0 + r] * s3_acc_scale<NP>; bv1[r] = bias1[4 * g + r] * s3_acc_scale<NP>; }
 
     // ---- lane-invariant LDS byte addresses (the per-tile part is an instruction immediate)
     // phase 1, regular M-tile j of this wave: region row wrow + HW*j, half whalf, pixel pair 16*whalf + m;
@@ -583,6 +577,11 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 // (the compiler inserts no wait states for that mixed pair here; with two s_nop 15 in between the results were right).
                 // Two chains of one opcode each have no such dependency; they meet in four v_add.
                 f32x4_t acct = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (NP == 2) {
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[2]), __builtin_bit_cast(f16x4, ft[1]), acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[1]), __builtin_bit_cast(f16x4, ft[0]), acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[0]), __builtin_bit_cast(f16x4, ft[0]), acct, 0, 0, 0);
+                } else {
                 if constexpr (NP == 3) {
                     acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[2], acct, 0, 0, 0);
                     acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[2], ft[0], acct, 0, 0, 0);
@@ -591,12 +590,13 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                     acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], ft[0], acct, 0, 0, 0);
                 }
                 acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[0], acct, 0, 0, 0);
+                }
                 acc += acct;
                 // epilogue: D (transposed) row 4g + r = (dx, co0 + r), column m = pixel pair.  Outside the image = block_4_1's zero padding.
                 const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = ok ? lrelu(acc[r]) : 0.f;
+                for (int r = 0; r < 4; r++) v[r] = ok ? s3p::act<NP>(acc[r]) : 0.f;
                 uint32_t pa[3], pb[3];
                 split_pair<NP>(v[0], v[1], pa);
                 split_pair<NP>(v[2], v[3], pb);
@@ -630,8 +630,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 const int iy = Ry0 + rrow, ix = Rx0 + rcol;
                 const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
                 uint32_t pa[3], pb[3];
-                split_pair<NP>(ok ? lrelu(acc[0]) : 0.f, ok ? lrelu(acc[1]) : 0.f, pa);
-                split_pair<NP>(ok ? lrelu(acc[2]) : 0.f, ok ? lrelu(acc[3]) : 0.f, pb);
+                split_pair<NP>(ok ? s3p::act<NP>(acc[0]) : 0.f, ok ? s3p::act<NP>(acc[1]) : 0.f, pa);
+                split_pair<NP>(ok ? s3p::act<NP>(acc[2]) : 0.f, ok ? s3p::act<NP>(acc[3]) : 0.f, pb);
                 const int e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0;
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&img[pl * PLANE + e]) = make_uint2(pa[pl], pb[pl]);
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 wait6<0>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
                 // D (transposed): row 4g + r = cout, column m = output pixel: 8 bytes (4 channels) per lane and plane
                 uint32_t pa[3], pb[3];
-                split_pair<NP>(lrelu(acc[0]), lrelu(acc[1]), pa);
-                split_pair<NP>(lrelu(acc[2]), lrelu(acc[3]), pb);
+                split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
+                split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
                 unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
                 if constexpr (DMA) {
 #pragma unroll
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                     if constexpr (NP == 3) o1 = rd128(st2r1);
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
                     __builtin_amdgcn_sched_barrier(0);
-                    if (NP == 3 || lane < 32) *reinterpret_cast<u32x4*>(orow + gvo0) = o0;
+                    if (NP >= 2 || lane < 32) *reinterpret_cast<u32x4*>(orow + gvo0) = o0;       // NP x 32 pieces: 64 lanes cover two planes
                     if (NP == 3 && lane < 32) *reinterpret_cast<u32x4*>(orow + gvo1) = o1;
                 }
             }

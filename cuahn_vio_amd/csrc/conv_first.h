@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
 #pragma unroll
     for (int kh = 0; kh < 7; kh++)
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) wv[kh][pl] = __builtin_bit_cast(bf16x8, wfrag[(kh * 3 + pl) * 64 + lane]);
+        for (int pl = 0; pl < s3_wplanes<NP>; pl++) wv[kh][pl] = __builtin_bit_cast(bf16x8, wfrag[(kh * 3 + pl) * 64 + lane]);
 
     constexpr int PPT = (PH * PW + 255) / 256;
     float2 px[PPT];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) bv[q][i] = bias[(8 * q + 4 * hh + i) & 15];
+        for (int i = 0; i < 4; i++) bv[q][i] = bias[(8 * q + 4 * hh + i) & 15] * s3_acc_scale<NP>;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int bid = s3p::xcd_tile(tile, n_tiles, gridDim.x);
@@ -289,14 +289,7 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
                 const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(src + hi4);
                 a[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-            if constexpr (NP == 3) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][2], a[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][1], a[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][1], a[0], acc, 0, 0, 0);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[kh][0], a[0], acc, 0, 0, 0);
+            acc = s3_mfma32<NP>(acc, wv[kh], a);
         }
         // D row 4 (2 q' + hh) + i of group q = (dx, co half c): a lane holds channels 8 c + 4 hh .. + 3 of pixel 2 pair + dx.  The wave's
         // 2 rows x 32 pixels x 16 channels are staged per plane in LDS as 8-byte units and read back so that a lane stores 16 bytes and
@@ -309,8 +302,8 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
         for (int q = 0; q < 4; q++) {
             const int dx = q >> 1, c = q & 1;
             uint32_t pa[3], pb[3];
-            s3p::split_pair<NP>(s3p::lrelu(acc[4 * q]), s3p::lrelu(acc[4 * q + 1]), pa);
-            s3p::split_pair<NP>(s3p::lrelu(acc[4 * q + 2]), s3p::lrelu(acc[4 * q + 3]), pb);
+            s3p::split_pair<NP>(s3p::act<NP>(acc[4 * q]), s3p::act<NP>(acc[4 * q + 1]), pa);
+            s3p::split_pair<NP>(s3p::act<NP>(acc[4 * q + 2]), s3p::act<NP>(acc[4 * q + 3]), pb);
             const int u = ((c * 2 + hh) * 2 + prow) * 32 + 16 * (prow ^ dx) + pair;
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&st[(pl * 256 + u) * 4]) = make_uint2(pa[pl], pb[pl]);
@@ -374,9 +367,9 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
 #pragma unroll
         for (int st = 0; st < 4; st++)
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) wv[t][st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * 4 + st) * 3 + pl) * 64 + lane]);
+            for (int pl = 0; pl < s3_wplanes<NP>; pl++) wv[t][st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * 4 + st) * 3 + pl) * 64 + lane]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) bv[t][r] = bias[nt * 16 + 4 * g + r];
+        for (int r = 0; r < 4; r++) bv[t][r] = bias[nt * 16 + 4 * g + r] * s3_acc_scale<NP>;
     }
 
     // ---- stage the band: input rows 2 oy0 - 3 .. + PH, columns -3 .. + PW, zero outside the image, split into planes
@@ -387,13 +380,8 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
         const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
         const float2 f = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
         uint16_t a[3], c[3];
-        if constexpr (NP == 3) {
-            split3(ok ? f.x : 0.f, a[0], a[1], a[2]);
-            split3(ok ? f.y : 0.f, c[0], c[1], c[2]);
-        } else {
-            a[0] = f32_to_bf16_rn(ok ? f.x : 0.f);
-            c[0] = f32_to_bf16_rn(ok ? f.y : 0.f);
-        }
+        s3p::split1<NP>(ok ? f.x : 0.f, a[0], a[1], a[2]);
+        s3p::split1<NP>(ok ? f.y : 0.f, c[0], c[1], c[2]);
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + i * 2]) = (uint32_t)a[pl] | ((uint32_t)c[pl] << 16);
     }
@@ -422,22 +410,14 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
             f32x4 acc = {bv[t][0], bv[t][1], bv[t][2], bv[t][3]};
 #pragma unroll
             for (int st = 0; st < 4; st++) {
-                if constexpr (NP == 3) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][2], a[st][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][1], a[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][1], a[st][0], acc, 0, 0, 0);
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[t][st][0], a[st][0], acc, 0, 0, 0);
+                acc = s3_mfma16<NP>(acc, wv[t][st], a[st]);
             }
             // D (transposed): row 4g + r = channel 4g + r of n-tile wave + 4t, column m = pixel: 8 bytes per lane and plane
             uint16_t sp[3][4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float v = fmaxf(acc[r], acc[r] * 0.1f);
-                if constexpr (NP == 3) split3(v, sp[0][r], sp[1][r], sp[2][r]);
-                else sp[0][r] = f32_to_bf16_rn(v);
+                const float v = s3p::act<NP>(acc[r]);
+                s3p::split1<NP>(v, sp[0][r], sp[1][r], sp[2][r]);
             }
             if (store) {
                 uint16_t* o = out16 + opix * COUT + (wave + 4 * t) * 16 + 4 * g;

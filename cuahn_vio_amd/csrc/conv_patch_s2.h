@@ -61,12 +61,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
 #pragma unroll
     for (int st = 0; st < NSTEP; st++)
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
+        for (int pl = 0; pl < s3_wplanes<NP>; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
     // operands swapped (weights as A): the MFMA yields the transposed tile, D row 4g + r = cout, column m = output pixel,
     // so that a lane stores four consecutive channels of one pixel with one 8-byte LDS write per plane (conv_b4_fused.h)
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
+    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r] * s3_acc_scale<NP>;
     // element offset of tap t inside a plane (channel half 0): compile-time constants, selected per lane group when used
     // (a 13-entry per-lane table cost 13 VGPRs: with the 156 weight registers of the 5x5 kernel that was one wave per SIMD less)
     auto tap_elem = [](int t) constexpr {
@@ -178,14 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
                         a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
-                if constexpr (NP == 3) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][2], a[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[0], acc, 0, 0, 0);
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[0], acc, 0, 0, 0);
+                acc = s3_mfma16<NP>(acc, wv[st], a);
             }
             // D (transposed): row 4g + r = cout within the half, column m = output column: a lane holds four consecutive channels of one
             // pixel, 8 bytes per plane, and stores them straight to global memory (the 16 lanes of a group x 4 groups cover 32 of the 64
@@ -194,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
             {
                 const int Y = ty0 + oy, X = tx0 + m;
                 uint32_t pa[3], pb[3];
-                s3p::split_pair<NP>(s3p::lrelu(acc[0]), s3p::lrelu(acc[1]), pa);
-                s3p::split_pair<NP>(s3p::lrelu(acc[2]), s3p::lrelu(acc[3]), pb);
+                s3p::split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
+                s3p::split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
                 if (Y < Ho && X < Wo) {
                     uint16_t* o = out16 + (((size_t)b * Ho + Y) * Wo + X) * 32 + nt * 16 + 4 * g;
 #pragma unroll
@@ -250,10 +243,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
 #pragma unroll
     for (int st = 0; st < NSTEP; st++)
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
+        for (int pl = 0; pl < s3_wplanes<NP>; pl++) wv[st][pl] = __builtin_bit_cast(bf16x8, wfrag[((nt * NSTEP + st) * 3 + pl) * 64 + lane]);
     f32x4_p bv;
 #pragma unroll
-    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
+    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r] * s3_acc_scale<NP>;
 
     // element offset of tap t inside a plane (quarter 0, column 0)
     auto tap_elem = [](int t) constexpr {
@@ -339,21 +332,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
                 for (int pl = 0; pl < NP; pl++) {
                     a[pl] = *reinterpret_cast<const bf16x8*>(&img[pl * PLANE + base + tap_elem(st)]);
                 }
-                if constexpr (NP == 3) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][2], a[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][1], a[0], acc, 0, 0, 0);
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[st][0], a[0], acc, 0, 0, 0);
+                acc = s3_mfma16<NP>(acc, wv[st], a);
             }
             // D (transposed): row 4g + r = cout 16 nt + 4g + r, column m = pixel: 8 bytes per lane and plane straight to global memory
             // (forming whole 128-byte lines through LDS first, the four waves' quarters together, measured 0.1028 vs 0.1004 ms: not worth
             // the two extra barriers per tile)
             uint32_t pa[3], pb[3];
-            s3p::split_pair<NP>(s3p::lrelu(acc[0]), s3p::lrelu(acc[1]), pa);
-            s3p::split_pair<NP>(s3p::lrelu(acc[2]), s3p::lrelu(acc[3]), pb);
+            s3p::split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
+            s3p::split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
             uint16_t* o = ob + (size_t)(oy * Wo + ox) * 64;
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,7 +92,7 @@ struct hnet_ctx {
     int b4_cfg = 5;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging
     uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
     size_t x16_plane = 0;              // dwords per plane
-    int n_planes = 3;                  // bf16 planes the matrix-core layers read and write: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16)
+    int n_planes = 3;                  // 16-bit planes the matrix-core layers read and write = their arithmetic mode: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16), 2 = fp16 planes (HNET_PREC_F16X2, fp32-grade)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
@@ -414,20 +415,40 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
-    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16) return HNET_ERR_UNSUPPORTED;
+    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
+        return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
     if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
         return HNET_ERR_INVALID_ARG;
     Blob b;
     if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
 
+    if (g.precision == HNET_PREC_F16X2) {     // fp16 planes carry 4096 w: every matrix-core weight must stay below 16 (s3_format.h)
+        float wmax = 0.f;
+        for (int l = 0; l < 20; l++) {
+            const ConvDesc& d = kConvs[l];
+            const Tensor* w = b.find(std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.weight",
+                                     {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
+            if (!w) return HNET_ERR_BAD_WEIGHTS;
+            for (size_t i = 0; i < (size_t)d.cout * d.cin * d.ks * d.ks; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
+        }
+        for (const char* head : {"fc_block_4_mean", "fc_block_4_uncertainty"}) {
+            const Tensor* w = b.find(std::string("model_last_block_list.0.") + head + ".1.weight", {256, 5120});
+            if (!w) return HNET_ERR_BAD_WEIGHTS;
+            for (size_t i = 0; i < (size_t)256 * 5120; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
+        }
+        if (!(wmax < 15.99f)) {
+            fprintf(stderr, "hnet_create: HNET_PREC_F16X2 needs |weight| < 16 (largest here: %g); use HNET_PREC_BF16X3\n", wmax);
+            return HNET_ERR_UNSUPPORTED;
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
     hnet_ctx* c = new hnet_ctx();
     c->cfg = g;
-    c->s3 = g.precision == HNET_PREC_BF16X3 || g.precision == HNET_PREC_BF16;   // the bf16-matrix-core kernels; plain bf16 = their one-plane form
-    c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : 3;
-    c->fuse_b4 = c->s3 && !(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0);
+    c->s3 = g.precision != HNET_PREC_FP32;   // the 16-bit matrix-core kernels; their arithmetic mode = the number of activation planes (s3_format.h)
+    c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : g.precision == HNET_PREC_F16X2 ? 2 : 3;
+    c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
@@ -468,7 +489,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                     const int kk = 4 * gg + e, kw = (kk >> 1) - dx, ci = kk & 1;
                     if (kw < 0 || kw >= 7) continue;
                     uint16_t sp[3];
-                    split3(w->data[(((size_t)co * 2 + ci) * 7 + 6) * 7 + kw], sp[0], sp[1], sp[2]);
+                    wsplit_np(w->data[(((size_t)co * 2 + ci) * 7 + 6) * 7 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                     for (int pl = 0; pl < 3; pl++) fr[(((size_t)4 * 3 + pl) * 64 + ln) * 8 + e] = sp[pl];
                 }
             }
@@ -481,7 +502,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                         const int kk = 8 * (gg & 1) + j, kw = (kk >> 1) - dx, ci = kk & 1;
                         if (kw < 0 || kw >= 7) continue;
                         uint16_t sp[3];
-                        split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                        wsplit_np(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                         for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                     }
                 }
@@ -497,14 +518,14 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                         const int kk = 8 * hh + j, kw = (kk >> 1) - dx, ci = kk & 1;
                         if (kw < 0 || kw >= 7) continue;
                         uint16_t sp[3];
-                        split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                        wsplit_np(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                         for (int pl = 0; pl < 3; pl++) fr[(((size_t)kh * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                     }
                 }
             CK(hipMalloc((void**)&c->b30_frag, fr.size() * 2));
             CK(hipMemcpy(c->b30_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
             const char* e30 = getenv("HNET_B30_S3");
-            c->b30_s3 = !(e30 && atoi(e30) == 0);
+            c->b30_s3 = !(e30 && atoi(e30) == 0) || c->n_planes == 2;     // (the fp32-MFMA fallback writes bf16 planes: not in the fp16 mode)
         }
         if (c->s3 && conv_is_first_s2(l)) {   // lane (i = channel of the n-tile, g): kernel row 2 st + (g>>1), taps 4 (g&1) + (j>>1), ci = j&1
             const int nt_n = d.cout / 16;
@@ -518,14 +539,14 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                             const int kw = 4 * (gg & 1) + (j >> 1), ci = j & 1;
                             if (kw >= 7) continue;
                             uint16_t sp[3];
-                            split3(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], sp[0], sp[1], sp[2]);
+                            wsplit_np(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * 4 + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                         }
                     }
             CK(hipMalloc((void**)&c->s2_frag[l], fr.size() * 2));
             CK(hipMemcpy(c->s2_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
             const char* e = getenv("HNET_FIRST_S2");
-            c->first_s2 = !(e && atoi(e) == 0);
+            c->first_s2 = !(e && atoi(e) == 0) || c->n_planes == 2;
         }
         if (c->s3 && c->use_region5 && conv_is_region5_layer(l)) {   // MFMA A-fragments [step = chunk * 13 + s][wave wn][tile j][plane][lane]: lane (n, g) holds row n of
             const int nch = d.cin / 16;            // output-channel tile 2 wn + j, K = 8 g + e = tap 2 s + (g >> 1), channel 16 chunk + 8 (g & 1) + e
@@ -539,7 +560,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                                 if (t >= 25) continue;
                                 for (int e = 0; e < 8; e++) {
                                     uint16_t sp[3];
-                                    split3(w->data[(((size_t)n * d.cin + 16 * ch + 8 * (gg & 1) + e) * 5 + t / 5) * 5 + t % 5], sp[0], sp[1], sp[2]);
+                                    wsplit_np(w->data[(((size_t)n * d.cin + 16 * ch + 8 * (gg & 1) + e) * 5 + t / 5) * 5 + t % 5], c->n_planes, sp[0], sp[1], sp[2]);
                                     for (int pl = 0; pl < 3; pl++)
                                         wp[((((((size_t)(ch * 13 + st) * 4 + wn) * 2 + j) * 3 + pl) * 64) + ln) * 8 + e] = sp[pl];
                                 }
@@ -556,7 +577,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                         for (int j = 0; j < 8; j++) {
                             const int ci = 8 * gg + j;
                             uint16_t sp[3];
-                            split3(w->data[(((size_t)n * 32 + ci) * 3 + kh) * 3 + kw], sp[0], sp[1], sp[2]);
+                            wsplit_np(w->data[(((size_t)n * 32 + ci) * 3 + kh) * 3 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * 9 + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                         }
                     }
@@ -576,7 +597,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                             // odd lane groups read their 16-byte chunk high half first (conv_patch_s2.h): element j = channel (j + 4) % 8 of the half
                             const int ci = 8 * (gg & 1) + (((gg & 1) && !c->patch_b128) ? (j + 4) % 8 : j);
                             uint16_t sp[3];
-                            split3(w->data[(((size_t)n * 16 + ci) * ks + kh) * ks + kw], sp[0], sp[1], sp[2]);
+                            wsplit_np(w->data[(((size_t)n * 16 + ci) * ks + kh) * ks + kw], c->n_planes, sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[((((size_t)nt * nstep + st) * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                         }
                     }
@@ -598,7 +619,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                             // odd lane groups read their 16-byte chunk high half first (conv_b4_fused.h): element j = channel (j + 4) % 8
                             const int ci = (gg & 1) ? (j + 4) % 8 : j;
                             uint16_t sp[3];
-                            split3(w->data[(((size_t)n * 8 + ci) * 5 + kh) * 5 + kw], sp[0], sp[1], sp[2]);
+                            wsplit_np(w->data[(((size_t)n * 8 + ci) * 5 + kh) * 5 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
                         }
                     }
@@ -608,7 +629,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             if (c->s3 && conv_is_s3_layer(l)) {     // exact 3-way bf16 split of every weight: planes [3][Cout][Kp]
                 std::vector<uint16_t> pl(packed.size() * 3);
                 for (size_t i = 0; i < packed.size(); i++)
-                    split3(packed[i], pl[i], pl[packed.size() + i], pl[2 * packed.size() + i]);
+                    wsplit_np(packed[i], c->n_planes, pl[i], pl[packed.size() + i], pl[2 * packed.size() + i]);
                 CK(hipMalloc((void**)&c->conv_w16[l], pl.size() * 2));
                 CK(hipMemcpy(c->conv_w16[l], pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
             }
@@ -642,7 +663,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(upload(&c->w1, w1)); CK(upload(&c->b1, b1)); CK(upload(&c->w2, w2)); CK(upload(&c->b2, b2));
         if (c->s3) {
             std::vector<uint16_t> pl(w1.size() * 3);
-            for (size_t i = 0; i < w1.size(); i++) split3(w1[i], pl[i], pl[w1.size() + i], pl[2 * w1.size() + i]);
+            for (size_t i = 0; i < w1.size(); i++) wsplit_np(w1[i], c->n_planes, pl[i], pl[w1.size() + i], pl[2 * w1.size() + i]);
             CK(hipMalloc((void**)&c->w1_16, pl.size() * 2));
             CK(hipMemcpy(c->w1_16, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
         }
@@ -1183,16 +1204,17 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         HIPCHK(c, launch_nhwc_to_nchw(d_c, d_d, batch, d.cout, ho, wo, c->stream));
     } else {   // split-bf16 mode: the layer reads / writes three bf16 planes, exactly as inside the forward
         uint16_t *p_in = nullptr, *p_out = nullptr;
+        int out_np = c->n_planes;            // plane format p_out is written in
         HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32));
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
         if (c->use_region5 && conv_is_region5_layer(layer) && h == (layer == 1 ? 14 : 28) && w == (layer == 1 ? 20 : 40)) {
-            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv5_region(layer, p_in, n_in, batch, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
         } else if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
-            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128));
         } else if (conv_is_s3_layer(layer)) {
-            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream));
+            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
                                      c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes));
         } else {
@@ -1201,10 +1223,12 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
                 HIPCHK(c, launch_conv_first_s2(layer, d_b, c->s2_frag[layer], c->conv_b[layer], p_out, n_out, batch, c->stream, c->n_planes));
             else if (layer == 7 && c->b30_s3 && c->b30_frag)     // the kernel the forward uses for block_3_0
                 HIPCHK(c, launch_conv_first_s3(d_b, c->b30_frag, c->conv_b[layer], p_out, n_out, batch, h, w, c->stream, c->n_planes));
-            else
+            else {   // Cin = 2 layers at other geometries: the fp32-MFMA kernel, which writes three bf16 planes
                 HIPCHK(c, launch_conv(layer, d_b, batch, h, w, c->conv_w[layer], c->conv_b[layer], nullptr, c->stream, nullptr, 0, p_out, n_out));
+                if (out_np == 2) out_np = 3;
+            }
         }
-        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream, c->n_planes));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, d.cout, ho, wo, c->stream, out_np));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));

@@ -27,6 +27,14 @@ namespace hnet {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// NP = number of ACTIVATION planes = the arithmetic mode (s3_format.h): 3 = split-bf16, 1 = plain bf16, 2 = two fp16 planes.
+// s3_wplanes: weight planes of the mode; s3_acc_scale: what the accumulator carries relative to the true sum.
+template <int NP> constexpr int s3_wplanes = NP == 1 ? 1 : 3;
+template <int NP> constexpr float s3_acc_scale = NP == 2 ? S3_F16_SCALE : 1.0f;
+template <int NP> __device__ __forceinline__ float s3_descale(float acc) { return NP == 2 ? acc * S3_F16_INV : acc; }
 
 struct S3Params {
     const uint16_t* A;     // input planes [3][...] NHWC bf16
@@ -125,8 +133,20 @@ __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
     return r;
 }
 // two fp32 values -> their NP bf16 planes, each plane as one packed dword (lo = v0, hi = v1)
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h = {(_Float16)lo, (_Float16)hi};          // round to nearest even (v_cvt_pk_f16_f32 on gfx950)
+    return __builtin_bit_cast(uint32_t, h);
+}
 template <int NP>
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
+    if constexpr (NP == 2) {         // fp16 planes: value = A0 + A1 / 4096
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        pl[0] = cvt_pk_f16(v0, v1);
+        const f16x2 h = __builtin_bit_cast(f16x2, pl[0]);
+        pl[1] = cvt_pk_f16((v0 - (float)h[0]) * S3_F16_SCALE, (v1 - (float)h[1]) * S3_F16_SCALE);
+        return;
+    }
     pl[0] = cvt_pk(v0, v1);
     if constexpr (NP == 3) {
         const float r0 = v0 - __builtin_bit_cast(float, pl[0] << 16), r1 = v1 - __builtin_bit_cast(float, pl[0] & 0xffff0000u);
@@ -136,6 +156,15 @@ __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]
     }
 }
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
+// LeakyReLU of an accumulator of mode NP (bias already inside, at the accumulator's scale)
+template <int NP> __device__ __forceinline__ float act(float acc) { return lrelu(s3_descale<NP>(acc)); }
+// one value -> its planes
+template <int NP>
+__device__ __forceinline__ void split1(float v, uint16_t& a, uint16_t& b, uint16_t& c) {
+    if constexpr (NP == 3) split3(v, a, b, c);
+    else if constexpr (NP == 2) split2h(v, a, b);
+    else a = f32_to_bf16_rn(v);
+}
 
 }  // namespace s3p
 
@@ -214,6 +243,8 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
                 const int m = mw + i * 16 + em;
                 if (m < p.M && n < p.N) {
                     f32x4_e v = acc16[i][j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = s3_descale<NP>(v[e]);      // split-K partials are written at the true scale too
                     if (p.k_split == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
@@ -241,10 +272,9 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
                     uint16_t sp[3][4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        float v = acc16[i][j][e] + bv[e];
+                        float v = s3_descale<NP>(acc16[i][j][e]) + bv[e];
                         v = v > 0.0f ? v : v * 0.1f;
-                        if constexpr (NP == 3) split3(v, sp[0][e], sp[1][e], sp[2][e]);
-                        else sp[0][e] = f32_to_bf16_rn(v);
+                        s3p::split1<NP>(v, sp[0][e], sp[1][e], sp[2][e]);
                     }
                     const int chunk = (nloc >> 3) ^ ((em >> 1) & 3);
                     const int e0 = em * 32 + chunk * 8 + (nloc & 7);
@@ -272,6 +302,11 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
 // NP = 1: the single plain-bf16 product
 template <int NP>
 __device__ __forceinline__ f32x4_m16 s3_mfma16(f32x4_m16 acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+    if constexpr (NP == 2) {     // fp16 planes: W2 A1 + W1 A0 + W0 A0 = 4096 a w (s3_format.h), smallest first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[2]), __builtin_bit_cast(f16x8, a[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, a[0]), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, a[0]), acc, 0, 0, 0);
+    }
     if constexpr (NP == 3) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], a[0], acc, 0, 0, 0);
@@ -280,6 +315,25 @@ __device__ __forceinline__ f32x4_m16 s3_mfma16(f32x4_m16 acc, const bf16x8 (&w)[
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], a[0], acc, 0, 0, 0);
     }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[0], acc, 0, 0, 0);
+}
+
+// the same product group on 32x32x16 tiles (weights as A operand)
+typedef float f32x16_m32 __attribute__((ext_vector_type(16)));
+template <int NP>
+__device__ __forceinline__ f32x16_m32 s3_mfma32(f32x16_m32 acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+    if constexpr (NP == 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[2]), __builtin_bit_cast(f16x8, a[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, a[0]), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, a[0]), acc, 0, 0, 0);
+    }
+    if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], a[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[0], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[0], acc, 0, 0, 0);
 }
 
 // MF = MFMA shape: 32 -> v_mfma_f32_32x32x16_bf16; 16 -> v_mfma_f32_16x16x32_bf16 issued with the weights as A operand
@@ -300,10 +354,11 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     constexpr int A_ROWS = (BM + RPP - 1) / RPP, B_ROWS = (BN + RPP - 1) / RPP;   // rows staged per thread and plane
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
-    static_assert(NP == 3 || (NP == 1 && MF == 16), "plain bf16 exists in the transposed 16x16x32 form");
+    static_assert(NP == 3 || MF == 16, "plain bf16 and the fp16 planes exist in the transposed 16x16x32 form");
+    constexpr int NW = s3_wplanes<NP>;                // weight planes
 
     // [buf][plane][rows][32]; the epilogue reuses it as a store staging area
-    constexpr int SMEM_ELEMS = NBUF * NP * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NBUF * NP * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
+    constexpr int SMEM_ELEMS = NBUF * (NP * TILE_A + NW * TILE_B) > 4 * 3 * 32 * 32 ? NBUF * (NP * TILE_A + NW * TILE_B) : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
     uint16_t* As = smem;
     uint16_t* Bs = smem + NBUF * NP * TILE_A;
@@ -361,7 +416,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
             bok[i] = wvalid[i] && kp < p.Kp;
             const uint16_t* src = bok[i] ? wsrc[i] + it * BK : p.Wp;
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) breg[i][pl] = *reinterpret_cast<const u32x4*>(src + pl * p.w_plane);
+            for (int pl = 0; pl < NW; pl++) breg[i][pl] = *reinterpret_cast<const u32x4*>(src + pl * p.w_plane);
         }
     };
     auto s_store = [&](int buf) {
@@ -391,8 +446,8 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
             const int r = srow + i * RPP;
             if (r < BN) {
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    *reinterpret_cast<u32x4*>(&Bs[(buf * NP + pl) * TILE_B + r * BK + s3_swz<CH>(r, schunk)]) = bok[i] ? breg[i][pl] : z;
+                for (int pl = 0; pl < NW; pl++)
+                    *reinterpret_cast<u32x4*>(&Bs[(buf * NW + pl) * TILE_B + r * BK + s3_swz<CH>(r, schunk)]) = bok[i] ? breg[i][pl] : z;
             }
         }
     };
@@ -426,8 +481,8 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
                 for (int j = 0; j < TN16; j++) {
                     const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                    for (int pl = 0; pl < NP; pl++)
-                        bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * NP + pl) * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
+                    for (int pl = 0; pl < NW; pl++)
+                        bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[(buf * NW + pl) * TILE_B + r * BK + s3_swz<CH>(r, 4 * step + g16)]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM16; i++)
@@ -616,7 +671,8 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
     constexpr int LUT_ELEMS = L::HAS_MASK ? 256 * 8 : 0;          // 256 entries x 16 bytes
-    constexpr int TILES = NP * (TILE_A + TILE_B) > 4 * 3 * 32 * 32 ? NP * (TILE_A + TILE_B) : 4 * 3 * 32 * 32;
+    constexpr int NW = s3_wplanes<NP>;                             // weight planes
+    constexpr int TILES = NP * TILE_A + NW * TILE_B > 4 * 3 * 32 * 32 ? NP * TILE_A + NW * TILE_B : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[TILES + LUT_ELEMS];
     uint16_t* As = smem;
     uint16_t* Bs = smem + NP * TILE_A;
@@ -681,7 +737,7 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++)
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++)
+            for (int pl = 0; pl < NW; pl++)
                 breg[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, wvoff[i], ws + pl * w_pl, 0));
     };
     auto s_store = [&]() {
@@ -699,7 +755,7 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++)
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<u32x4*>(&Bs[pl * TILE_B + b_lds[i]]) = breg[i][pl];
+            for (int pl = 0; pl < NW; pl++) *reinterpret_cast<u32x4*>(&Bs[pl * TILE_B + b_lds[i]]) = breg[i][pl];
     };
 
     if constexpr (L::HAS_MASK) __syncthreads();      // the table is read by s_store
@@ -724,7 +780,7 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++)
+                for (int pl = 0; pl < NW; pl++)
                     bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
             }
 #pragma unroll
@@ -933,15 +989,16 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
                                                          uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                          const uint64_t* __restrict__ seq_dev,
-                                                         uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask) {
+                                                         uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask, int np) {
     // (plain-bf16 mode reads plane 0 only; writing all three costs nothing measurable here)
     const size_t nfeat = (size_t)batch * 5120;
     const size_t nmask = (size_t)batch * n_local * 2 * 640;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nfeat) {
         uint16_t a, b, c;
-        split3(feat[i] * scale, a, b, c);
-        feat16[i] = a; feat16[f_plane + i] = b; feat16[2 * f_plane + i] = c;
+        split_np(feat[i] * scale, np, a, b, c);
+        feat16[i] = a; feat16[f_plane + i] = b;
+        if (np != 2) feat16[2 * f_plane + i] = c;
     }
     if (i < nmask) {
         const int chunk = (int)(i % 640);
@@ -961,7 +1018,7 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
 // S3 variant of splitk_reduce_kernel: out planes <- split3(LeakyReLU(bias + sum_z partial[z]))
 static __global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const float* __restrict__ partial, int k_split, int M, int N,
                                                                const float* __restrict__ bias, uint16_t* __restrict__ out16,
-                                                               size_t o_plane) {   // three planes also in the plain-bf16 mode (plane 0 = bf16(v) is the one read)
+                                                               size_t o_plane, int np) {   // three planes also in the plain-bf16 mode (plane 0 = bf16(v) is the one read)
     const size_t total = (size_t)M * N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -970,20 +1027,21 @@ static __global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const floa
     float v = s + bias[i % N];
     v = v > 0.0f ? v : v * 0.1f;
     uint16_t a, b, c;
-    split3(v, a, b, c);
-    out16[i] = a; out16[o_plane + i] = b; out16[2 * o_plane + i] = c;
+    split_np(v, np, a, b, c);
+    out16[i] = a; out16[o_plane + i] = b;
+    if (np != 2) out16[2 * o_plane + i] = c;
 }
 
 // layout / format conversion helpers (operator-level entry points and debug read-back)
 [[maybe_unused]] static __global__ void nchw_f32_to_nhwc_s3_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t o_plane,
-                                           int batch, int c, int hw) {
+                                           int batch, int c, int hw, int np) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)batch * c * hw) return;
     const int ch = (int)(idx % c);
     const long t = idx / c;
     const int px = (int)(t % hw), b = (int)(t / hw);
     uint16_t x, y, z;
-    split3(in[((size_t)b * c + ch) * hw + px], x, y, z);
+    split_np(in[((size_t)b * c + ch) * hw + px], np, x, y, z);
     out[idx] = x; out[o_plane + idx] = y; out[2 * o_plane + idx] = z;
 }
 [[maybe_unused]] static __global__ void nhwc_s3_to_nchw_f32_kernel(const uint16_t* __restrict__ in, size_t i_plane, float* __restrict__ out,
@@ -994,8 +1052,8 @@ static __global__ __launch_bounds__(256) void splitk_reduce_s3_kernel(const floa
     const long t = idx / hw;
     const int ch = (int)(t % c), b = (int)(t / c);
     const size_t src = ((size_t)b * hw + px) * c + ch;
-    out[idx] = n_planes == 3 ? (bf16_to_f32(in[src]) + bf16_to_f32(in[i_plane + src])) + bf16_to_f32(in[2 * i_plane + src])
-                             : bf16_to_f32(in[src]);      // plain-bf16 mode: planes 1, 2 are never written by the NP = 1 kernels
+    // plain-bf16 mode: planes 1, 2 are never written by the NP = 1 kernels; fp16 mode: plane 2 is not
+    out[idx] = join_np(in[src], n_planes >= 2 ? in[i_plane + src] : (uint16_t)0, n_planes == 3 ? in[2 * i_plane + src] : (uint16_t)0, n_planes);
 }
 
 }  // namespace hnet

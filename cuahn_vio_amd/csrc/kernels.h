@@ -23,7 +23,8 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
                        const float* bias, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0,
                        uint16_t* out16 = nullptr, size_t o_plane = 0);
 
-// n_planes (all bf16-matrix-core launchers): 3 = split-bf16 (fp32-grade), 1 = plain bf16 operands (only plane 0 is read / written)
+// n_planes (all matrix-core launchers) = the arithmetic mode (s3_format.h): 3 = split-bf16 (fp32-grade), 1 = plain bf16 operands (only plane 0
+// is read / written), 2 = two fp16 planes (fp32-grade, three MFMAs per product; planes 0 and 1)
 // split-bf16 (S3) convolution of the layers with Cin >= 8: in / out16 are [3][B][H][W][C] bf16 planes
 // (plane stride in elements), wplanes [3][Cout][Kp]; out32 != nullptr selects an fp32 [B][Ho][Wo][Cout] output
 bool conv_is_s3_layer(int layer);
@@ -56,7 +57,7 @@ hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
                                float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3);
-hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s);
+hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 
 // first FC of both heads with MC-dropout on the input: feat [B][5120] (NHWC flatten) -> hidden [B*n_local][512]

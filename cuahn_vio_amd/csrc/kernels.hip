@@ -228,14 +228,12 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint16_t a0, a1, a2, w0, w1, w2;
-            split3(a[i], a0, a1, a2);
-            split3(w[i], w0, w1, w2);
+            split_np(a[i], n_planes, a0, a1, a2);
+            split_np(w[i], n_planes, w0, w1, w2);
             const size_t idx = ((size_t)b * B4_HP + (v0 + r0 + i + B4_PADY)) * B4_WP + u + B4_PADX;
             out_s3[idx] = (uint32_t)a0 | ((uint32_t)w0 << 16);
-            if (n_planes == 3) {
-                out_s3[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
-                out_s3[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
-            }
+            if (n_planes >= 2) out_s3[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
+            if (n_planes == 3) out_s3[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
         }
     } else if constexpr (K == 1) {
 #pragma unroll
@@ -351,14 +349,12 @@ __global__ void f32_nhwc_to_s3pad_kernel(const float* __restrict__ x, uint32_t* 
     const int b = (int)(i / NPIX), pix = (int)(i - (long)b * NPIX), v = pix / IMG_W, u = pix - v * IMG_W;
     const float2 f = *reinterpret_cast<const float2*>(x + (size_t)i * 2);
     uint16_t a0, a1, a2, w0, w1, w2;
-    split3(f.x, a0, a1, a2);
-    split3(f.y, w0, w1, w2);
+    split_np(f.x, n_planes, a0, a1, a2);
+    split_np(f.y, n_planes, w0, w1, w2);
     const size_t idx = ((size_t)b * B4_HP + v + B4_PADY) * B4_WP + u + B4_PADX;
     out[idx] = (uint32_t)a0 | ((uint32_t)w0 << 16);
-    if (n_planes == 3) {
-        out[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
-        out[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
-    }
+    if (n_planes >= 2) out[s3_plane + idx] = (uint32_t)a1 | ((uint32_t)w1 << 16);
+    if (n_planes == 3) out[2 * s3_plane + idx] = (uint32_t)a2 | ((uint32_t)w2 << 16);
 }
 __global__ void s3pad_to_f32_nhwc_kernel(const uint32_t* __restrict__ in, size_t s3_plane, float* __restrict__ x, int batch, int n_planes) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,6 +362,11 @@ __global__ void s3pad_to_f32_nhwc_kernel(const uint32_t* __restrict__ in, size_t
     const int b = (int)(i / NPIX), pix = (int)(i - (long)b * NPIX), v = pix / IMG_W, u = pix - v * IMG_W;
     const size_t idx = ((size_t)b * B4_HP + v + B4_PADY) * B4_WP + u + B4_PADX;
     float lo = 0.f, hi = 0.f;
+    if (n_planes == 2) {                                  // fp16 planes: A0 + A1 / 4096
+        const uint32_t d0 = in[idx], d1 = in[s3_plane + idx];
+        lo = join2h((uint16_t)(d0 & 0xffffu), (uint16_t)(d1 & 0xffffu));
+        hi = join2h((uint16_t)(d0 >> 16), (uint16_t)(d1 >> 16));
+    } else
     for (int pl = n_planes - 1; pl >= 0; pl--) {         // smallest plane first: the sum of the three planes is the exact fp32 value
         const uint32_t d = in[pl * s3_plane + idx];
         lo += bf16_to_f32((uint16_t)(d & 0xffffu));

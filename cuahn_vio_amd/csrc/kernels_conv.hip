@@ -132,67 +132,63 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
 // ---------------------------------------------------------------------------------------------
 HNET_S3_DISPATCH_INSTANCES(, 3)
 HNET_S3_DISPATCH_INSTANCES(extern, 1)
+HNET_S3_DISPATCH_INSTANCES(extern, 2)
 
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
 bool conv_is_patch_layer(int layer) { return layer == 8 || layer == 15; }   // block_3_1 (5x5), block_4_2 (3x3)
 bool conv_is_patch32_layer(int layer) { return layer == 9 || layer == 16; }   // block_3_2, block_4_3 (3x3, 32 -> 64)
 
 hipError_t conv_kernels_init_device() {
-    const hipError_t e = conv_kernels_init_device_np<3>();
-    return e != hipSuccess ? e : conv_kernels_init_device_np<1>();
+    hipError_t e = conv_kernels_init_device_np<3>();
+    if (e == hipSuccess) e = conv_kernels_init_device_np<1>();
+    return e != hipSuccess ? e : conv_kernels_init_device_np<2>();
 }
+
+// arithmetic mode of the bf16 / fp16 matrix-core layers = number of activation planes (s3_format.h)
+#define HNET_NP(fn, ...) (n_planes == 1 ? fn<1>(__VA_ARGS__) : n_planes == 2 ? fn<2>(__VA_ARGS__) : fn<3>(__VA_ARGS__))
 
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg, int n_planes) {
-    return n_planes == 1 ? launch_block4_fused_np<1>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg)
-                         : launch_block4_fused_np<3>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
+    return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
 }
 
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 int h, int w, hipStream_t s, int n_planes) {
-    return n_planes == 1 ? launch_conv_first_s3_np<1>(x_in, wfrag, bias, out16, o_plane, batch, h, w, s)
-                         : launch_conv_first_s3_np<3>(x_in, wfrag, bias, out16, o_plane, batch, h, w, s);
+    return HNET_NP(launch_conv_first_s3_np, x_in, wfrag, bias, out16, o_plane, batch, h, w, s);
 }
 
 hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 hipStream_t s, int n_planes) {
-    return n_planes == 1 ? launch_conv_first_s2_np<1>(layer, x_in, wfrag, bias, out16, o_plane, batch, s)
-                         : launch_conv_first_s2_np<3>(layer, x_in, wfrag, bias, out16, o_plane, batch, s);
+    return HNET_NP(launch_conv_first_s2_np, layer, x_in, wfrag, bias, out16, o_plane, batch, s);
 }
 
 bool conv_is_region5_layer(int layer) { return layer == 1 || layer == 4; }   // block_1_2, block_2_2
 hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
                                size_t o_plane, hipStream_t s, int n_planes) {
-    return n_planes == 1 ? launch_conv5_region_np<1>(layer, in, i_plane, batch, wpack, bias, out16, o_plane, s)
-                         : launch_conv5_region_np<3>(layer, in, i_plane, batch, wpack, bias, out16, o_plane, s);
+    return HNET_NP(launch_conv5_region_np, layer, in, i_plane, batch, wpack, bias, out16, o_plane, s);
 }
 
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes, bool b128) {
-    return n_planes == 1 ? launch_conv_patch_np<1>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128)
-                         : launch_conv_patch_np<3>(layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128);
+    return HNET_NP(launch_conv_patch_np, layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128);
 }
 
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
                                const uint64_t* seq_dev, int n_planes) {
-    return n_planes == 1 ? launch_heads_fc1_s3_np<1>(feat, batch, n_local, s_begin, p_drop, mc_seed, pair_seq0, w1planes, b1, hidden, feat16,
-                                                     f_plane, mask, s, ws, wsn, seq_dev)
-                         : launch_heads_fc1_s3_np<3>(feat, batch, n_local, s_begin, p_drop, mc_seed, pair_seq0, w1planes, b1, hidden, feat16,
-                                                     f_plane, mask, s, ws, wsn, seq_dev);
+    return HNET_NP(launch_heads_fc1_s3_np, feat, batch, n_local, s_begin, p_drop, mc_seed, pair_seq0, w1planes, b1, hidden, feat16, f_plane, mask, s, ws, wsn, seq_dev);
 }
 
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
                           float* ws, size_t wsn, const uint16_t* zeros, int n_planes) {
-    return n_planes == 1 ? launch_conv_s3_np<1>(layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, zeros)
-                         : launch_conv_s3_np<3>(layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, zeros);
+    return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, zeros);
 }
 
-hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s) {
+hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes) {
     const long n = (long)batch * c * h * w;
-    hipLaunchKernelGGL(nchw_f32_to_nhwc_s3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, o_plane, batch, c, h * w);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_s3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, o_plane, batch, c, h * w, n_planes);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes) {

@@ -17,7 +17,7 @@ namespace hnet {
 int splitk_min_iters(long tiles);        // kernels_conv.hip
 int splitk_target_blocks(long tiles);
 
-template <bool OUT32>
+template <bool OUT32, int NP>
 static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hipStream_t s) {
     if (split > 1) {
         if (OUT32) {
@@ -25,12 +25,12 @@ static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hip
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out32);
         } else {
             const size_t total = (size_t)p.M * p.N;
-            hipLaunchKernelGGL(splitk_reduce_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out16, p.o_plane);
+            hipLaunchKernelGGL(splitk_reduce_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, split, p.M, p.N, p.bias, p.out16, p.o_plane, NP);
         }
     }
     return hipGetLastError();
 }
-#define finish_split(p, split, ws, s) finish_split_impl<OUT32>(p, split, ws, s)
+#define finish_split(p, split, ws, s) finish_split_impl<OUT32, NP>(p, split, ws, s)
 
 template <class L, int BM, int BN, int WGM, bool OUT32, int NP>
 static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
@@ -54,7 +54,21 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     // the lean staging of round 2 (0.1116 vs 0.1086 ms on block_3_2, profiles/r02_ab_s3_dma.log) -> off in split-bf16 mode, on in plain bf16
     static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : (NP == 3 ? 0 : 3);
 
-    if constexpr (NP == 1) {
+    if constexpr (NP == 2) {
+        // fp16 planes: the lean kernel (the measured winner of the split-bf16 dispatch below) on every layer it covers, its 64-wide K tiles
+        // where a tap holds >= 64 channels; the register-staged kernel in its 16x16x32 form for the rest (ragged operator-level shapes)
+        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
+            if constexpr (L::template lean_ok<64>()) {
+                hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
+                return finish_split(p, split, ws, s);
+            }
+        }
+        if constexpr (L::template lean_ok<32>() && BM != 96)
+            hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, NP>), grid, dim3(256), 0, s, p);
+        return finish_split(p, split, ws, s);
+    } else if constexpr (NP == 1) {
         // plain bf16 operands: the measured winners of the split-bf16 dispatch below, in their 16x16x32 form (the only form
         // the NP = 1 kernels exist in), no experiment switches
         if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
@@ -171,8 +185,10 @@ hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* 
     // for in-process A/B (tools/ab_bench.py) and as the reference implementation of the same arithmetic
     // 4 / 5: v3 with LDS-DMA staging from the padded bf16-plane input
     if (cfg == 0) return run_b4<8, 512, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 2) return run_b4<8, 512, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 3) return run_b4<7, 256, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if constexpr (NP != 2) {      // the v2 kernel exists in the bf16 modes only
+        if (cfg == 2) return run_b4<8, 512, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+        if (cfg == 3) return run_b4<7, 256, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    }
     if (cfg == 4) return run_b4<8, 512, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
     if (cfg == 5) return run_b4<7, 256, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
     return run_b4<7, 256, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
@@ -280,7 +296,7 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
                                   const uint64_t* seq_dev) {
     const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
-                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask);
+                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP);
     S3Params p = {};
     p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
     p.out32 = hidden;
@@ -331,8 +347,10 @@ hipError_t conv_kernels_init_device_np() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP, true>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
+    if constexpr (NP != 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
+    }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
@@ -343,7 +361,7 @@ hipError_t conv_kernels_init_device_np() {
     return e;
 }
 
-// the explicit instantiations live in kernels_conv.hip (NP = 3) and kernels_conv_bf16.hip (NP = 1)
+// the explicit instantiations live in kernels_conv.hip (NP = 3), kernels_conv_bf16.hip (NP = 1) and kernels_conv_f16x2.hip (NP = 2)
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
                                                       uint16_t*, size_t, int, hipStream_t, int, int);                                    \

@@ -44,8 +44,13 @@ enum {
  *                    (an exact split of its 24-bit significand) and each product is six bf16 MFMAs (csrc/igemm_s3.h)
  *   HNET_PREC_BF16   plain bf16 operands, fp32 accumulation: the same kernels reading ONE bf16 plane, one MFMA per product.
  *                    A REPORTED mode (BASELINE config 2 names "bf16"): ~2x the throughput at ~4e-3 .. 1e-1 px from the reference,
- *                    i.e. outside the 1e-4 px parity gate; tests/test_gpu_bf16_mode.py pins what it computes */
-enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1, HNET_PREC_BF16X3 = 2 };
+ *                    i.e. outside the 1e-4 px parity gate; tests/test_gpu_bf16_mode.py pins what it computes
+ *   HNET_PREC_F16X2  fp32-grade accuracy on the fp16 matrix cores with THREE MFMAs per product: an activation is two fp16 planes
+ *                    (a = A0 + A1 / 4096, 22 + 2 significand bits), a weight three (4096 w = W0 + W1, W0 / 4096), the accumulator
+ *                    carries 4096 x the sum (csrc/s3_format.h).  Same parity gates as HNET_PREC_BF16X3.  Range: |weight| < 16
+ *                    (checked by hnet_create: HNET_ERR_UNSUPPORTED otherwise) and |activation| < 65504 (an overflow shows as a
+ *                    non-finite result, never as a silently wrong one) */
+enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1, HNET_PREC_BF16X3 = 2, HNET_PREC_F16X2 = 3 };
 enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buffers */
 
 /* Replaces: the variant choice the reference bakes into the traced .pt file

@@ -13,7 +13,7 @@ from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE
 pytestmark = pytest.mark.gpu
 
 MC_SEED = 0x5EED5EED12345678
-PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")]
+PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(3, id="f16x2"), pytest.param(0, id="fp32")]
 
 
 def _batch(first_seed, n_distinct, batch):
@@ -76,10 +76,10 @@ def _conv2(state, x):
     return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("prec,cfg", [(2, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (3, 0), (3, 1), (3, 4), (3, 5)])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 5])
-def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg):
+def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg, prec):
     """block4_fused_kernel (block_4_0 + block_4_1 in one launch, the 8-channel map never leaves LDS) against
     conv_lrelu(conv_lrelu(.)) of the oracle, every element of every pair, random inputs that are non-zero up to the image
     border (so the zero padding of BOTH layers matters), forward and reverse tile walk, batches that give every persistent
@@ -90,7 +90,7 @@ def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg):
     old = os.environ.get("HNET_B4_CFG")
     os.environ["HNET_B4_CFG"] = str(cfg)          # read by hnet_create
     try:
-        eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+        eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=prec)
     finally:
         if old is None:
             del os.environ["HNET_B4_CFG"]
@@ -153,10 +153,10 @@ def test_round2_kernels_real_geometry_multi_pair(eng_s3, state, layer, batch):
         assert np.array_equal(alone[0], got[b]), (name, b)
 
 
-@pytest.fixture(scope="module")
-def eng_s3(blob):
+@pytest.fixture(scope="module", params=[pytest.param(2, id="bf16x3"), pytest.param(3, id="f16x2")])
+def eng_s3(blob, request):
     from cuahn_vio_amd.homography_net import HnetEngine
-    e = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
+    e = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=request.param)
     yield e
     e.close()
 

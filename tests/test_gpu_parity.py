@@ -15,7 +15,7 @@ MC_SEED = 0x5EED5EED12345678
 
 
 # both arithmetic modes in every run: the split-bf16 path (default, the one bench.py reports) and the exact-fp32 MFMA path
-PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")]
+PRECISIONS = [pytest.param(2, id="bf16x3"), pytest.param(3, id="f16x2"), pytest.param(0, id="fp32")]
 
 
 @pytest.fixture(scope="module", params=PRECISIONS)
@@ -199,7 +199,7 @@ def test_forward_golden(blob, oracle, name, precision):
         with open(table, "a") as f:
             if new:
                 f.write("case,precision,abs_err_vs_ref_fp32_px,abs_err_vs_ref_fp64_px,abs_err_vs_oracle_px,cov_rel_err_vs_ref_fp64\n")
-            f.write(f"{name},{ {0: 'fp32', 1: 'bf16', 2: 'bf16x3'}[precision]},{d32:.3e},{d64:.3e},{dor:.3e},"
+            f.write(f"{name},{ {0: 'fp32', 1: 'bf16', 2: 'bf16x3', 3: 'f16x2'}[precision]},{d32:.3e},{d64:.3e},{dor:.3e},"
                     f"{np.abs(cov[0] - g['cov64']).max() / np.abs(g['cov64']).max():.3e}\n")
     assert d32 < TOL_PX_VS_REF32 and d64 < TOL_PX_VS_REF64 and dor < TOL_PX_VS_ORACLE
     for ref in (g["cov"], g["cov64"], o["cov"]):

@@ -8,7 +8,7 @@ from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", [pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")])
+@pytest.mark.parametrize("precision", [pytest.param(2, id="bf16x3"), pytest.param(3, id="f16x2"), pytest.param(0, id="fp32")])
 def test_replayed_pairs_match_the_oracle(blob, oracle, precision):
     from cuahn_vio_amd import replay
     from cuahn_vio_amd.homography_net import HnetEngine
