@@ -25,7 +25,7 @@ SYMBOLS = [
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
-    "hnet_op_block4_fused",
+    "hnet_op_block4_fused", "hnet_precision",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
     L.hnet_push_raw_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     L.hnet_op_undistort.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.hnet_image_count.argtypes = [vp]
+    L.hnet_precision.argtypes = [vp]
     L.hnet_latest_time.argtypes = [vp]
     L.hnet_latest_time.restype = C.c_double
     L.hnet_infer.argtypes = [vp, dp, C.c_int, fp, fp, u8p]

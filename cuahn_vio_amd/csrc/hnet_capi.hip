@@ -76,6 +76,7 @@ struct hnet_ctx {
     hnet_config cfg;
     hipStream_t stream = nullptr;
     std::string err;
+    std::vector<uint8_t> blob_copy;    // HNET_PREC_F16X2 only: the weight blob, kept so that an activation overflow can demote the context to HNET_PREC_BF16X3
     // weights (device)
     float* conv_w[20] = {};
     float* conv_b[20] = {};
@@ -406,81 +407,31 @@ hipGraphExec_t capture_graph(hnet_ctx* c, F&& body) {
     return exec;
 }
 
-int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet_ctx** out) {
-    if (!cfg_in || !out) return HNET_ERR_INVALID_ARG;
-    hnet_config g;
-    hnet_default_config(&g);
-    memcpy(&g, cfg_in, std::min<size_t>(cfg_in->struct_size ? cfg_in->struct_size : sizeof(g), sizeof(g)));
-    g.struct_size = sizeof(g);
-    if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
-        return HNET_ERR_INVALID_ARG;
-    if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
-    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
-        return HNET_ERR_UNSUPPORTED;
-    if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
-    if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
-        return HNET_ERR_INVALID_ARG;
-    Blob b;
-    if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
-
-    if (g.precision == HNET_PREC_F16X2) {     // fp16 planes carry 4096 w: every matrix-core weight must stay below 16 (s3_format.h)
-        float wmax = 0.f;
-        for (int l = 0; l < 20; l++) {
-            const ConvDesc& d = kConvs[l];
-            const Tensor* w = b.find(std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.weight",
-                                     {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
-            if (!w) return HNET_ERR_BAD_WEIGHTS;
-            for (size_t i = 0; i < (size_t)d.cout * d.cin * d.ks * d.ks; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
-        }
-        for (const char* head : {"fc_block_4_mean", "fc_block_4_uncertainty"}) {
-            const Tensor* w = b.find(std::string("model_last_block_list.0.") + head + ".1.weight", {256, 5120});
-            if (!w) return HNET_ERR_BAD_WEIGHTS;
-            for (size_t i = 0; i < (size_t)256 * 5120; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
-        }
-        if (!(wmax < 15.99f)) {
-            fprintf(stderr, "hnet_create: HNET_PREC_F16X2 needs |weight| < 16 (largest here: %g); use HNET_PREC_BF16X3\n", wmax);
-            return HNET_ERR_UNSUPPORTED;
-        }
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
-    hnet_ctx* c = new hnet_ctx();
-    c->cfg = g;
-    c->s3 = g.precision != HNET_PREC_FP32;   // the 16-bit matrix-core kernels; their arithmetic mode = the number of activation planes (s3_format.h)
-    c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : g.precision == HNET_PREC_F16X2 ? 2 : 3;
-    c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
-    c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
-    c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
-    c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
-    c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
-    c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
-    if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
-    // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
-    // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
-    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(5, atoi(getenv("HNET_B4_CFG")))) : 5;
-    c->n_local = g.mc_sample_end - g.mc_sample_begin;
-    c->s_begin = g.mc_sample_begin;
+// Weights -> device, in the layouts of the kernels of the context's arithmetic mode (c->s3, c->n_planes).  Called by hnet_create and again by
+// demote_to_bf16x3 (buffers of an earlier call are released first).  On failure the caller destroys the context.
+int upload_weights(hnet_ctx* c, const Blob& b) {
 #define CK(expr)                                                                    \
     do {                                                                            \
         hipError_t e_ = (expr);                                                     \
         if (e_ != hipSuccess) {                                                     \
-            fprintf(stderr, "hnet_create: %s: %s\n", #expr, hipGetErrorString(e_)); \
-            hnet_destroy(c);                                                        \
+            fprintf(stderr, "hnet weights: %s: %s\n", #expr, hipGetErrorString(e_)); \
             return HNET_ERR_DEVICE;                                                 \
         }                                                                           \
     } while (0)
-    CK(hipSetDevice(g.device_id));
-    CK(conv_kernels_init_device());      // dynamic-LDS limits of the patch / fused kernels: per device, so set at every create
-    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CK(hipEventCreate(&c->ev0));
-    CK(hipEventCreate(&c->ev1));
+    {
+        auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+        for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); }
+        for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
+        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16);
+        fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
+    }
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
     for (int l = 0; l < 20; l++) {
         const ConvDesc& d = kConvs[l];
         const std::string pre = std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.";
         const Tensor* w = b.find(pre + "weight", {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
         const Tensor* bi = b.find(pre + "bias", {(uint32_t)d.cout});
-        if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+        if (!w || !bi) return HNET_ERR_BAD_WEIGHTS;
         if (c->s3 && l == 13) {     // block_4_0 for the fused kernel: K index 8g+j of step st = (kh = 2st + (g>>1), kk = 8(g&1) + j)
             std::vector<uint16_t> fr((size_t)5 * 3 * 64 * 8, 0);     // slot 4: kernel row 6 alone as 16x16x16 fragments (K = 4 gg + e = tap 2 gg + (e >> 1), ci = e & 1), low 8 bytes
             for (int ln = 0; ln < 64; ln++) {
@@ -640,7 +591,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const std::string pre = "model_part1.fc_block_" + std::to_string(k + 1) + ".";
         const Tensor* w = b.find(pre + "weight", {8, 5120});
         const Tensor* bi = b.find(pre + "bias", {8});
-        if (!w || !bi) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+        if (!w || !bi) return HNET_ERR_BAD_WEIGHTS;
         CK(upload(&c->fc_w[k], permute_fc(w->data, 8)));
         CK(upload(&c->fc_b[k], std::vector<float>(bi->data, bi->data + 8)));
     }
@@ -653,7 +604,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             const Tensor* tb1 = b.find(pre + "1.bias", {256});
             const Tensor* tw2 = b.find(pre + "4.weight", {8, 256});
             const Tensor* tb2 = b.find(pre + "4.bias", {8});
-            if (!tw1 || !tb1 || !tw2 || !tb2) { hnet_destroy(c); return HNET_ERR_BAD_WEIGHTS; }
+            if (!tw1 || !tb1 || !tw2 || !tb2) return HNET_ERR_BAD_WEIGHTS;
             std::vector<float> p = permute_fc(tw1->data, 256);
             w1.insert(w1.end(), p.begin(), p.end());
             b1.insert(b1.end(), tb1->data, tb1->data + 256);
@@ -668,6 +619,81 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             CK(hipMemcpy(c->w1_16, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
         }
     }
+
+    return HNET_OK;
+#undef CK
+}
+
+int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet_ctx** out) {
+    if (!cfg_in || !out) return HNET_ERR_INVALID_ARG;
+    hnet_config g;
+    hnet_default_config(&g);
+    memcpy(&g, cfg_in, std::min<size_t>(cfg_in->struct_size ? cfg_in->struct_size : sizeof(g), sizeof(g)));
+    g.struct_size = sizeof(g);
+    if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
+        return HNET_ERR_INVALID_ARG;
+    if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
+    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
+        return HNET_ERR_UNSUPPORTED;
+    if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
+    if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
+        return HNET_ERR_INVALID_ARG;
+    Blob b;
+    if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
+
+    if (g.precision == HNET_PREC_F16X2) {     // fp16 planes carry 4096 w: every matrix-core weight must stay below 16 (s3_format.h)
+        float wmax = 0.f;
+        for (int l = 0; l < 20; l++) {
+            const ConvDesc& d = kConvs[l];
+            const Tensor* w = b.find(std::string(d.block == 4 ? "model_last_block_list.0." : "model_part1.") + d.name + ".0.weight",
+                                     {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
+            if (!w) return HNET_ERR_BAD_WEIGHTS;
+            for (size_t i = 0; i < (size_t)d.cout * d.cin * d.ks * d.ks; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
+        }
+        for (const char* head : {"fc_block_4_mean", "fc_block_4_uncertainty"}) {
+            const Tensor* w = b.find(std::string("model_last_block_list.0.") + head + ".1.weight", {256, 5120});
+            if (!w) return HNET_ERR_BAD_WEIGHTS;
+            for (size_t i = 0; i < (size_t)256 * 5120; i++) wmax = std::max(wmax, std::fabs(w->data[i]));
+        }
+        if (!(wmax < 15.99f)) {    // same results, twice the matrix-core work: not an error
+            fprintf(stderr, "hnet_create: HNET_PREC_F16X2 needs |weight| < 16 (largest here: %g): using HNET_PREC_BF16X3\n", wmax);
+            g.precision = HNET_PREC_BF16X3;
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || g.device_id < 0 || g.device_id >= ndev) return HNET_ERR_DEVICE;
+    hnet_ctx* c = new hnet_ctx();
+    c->cfg = g;
+    c->s3 = g.precision != HNET_PREC_FP32;   // the 16-bit matrix-core kernels; their arithmetic mode = the number of activation planes (s3_format.h)
+    c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : g.precision == HNET_PREC_F16X2 ? 2 : 3;
+    c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
+    c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
+    c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
+    c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
+    c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
+    c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
+    if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
+    // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
+    // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
+    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(5, atoi(getenv("HNET_B4_CFG")))) : 5;
+    c->n_local = g.mc_sample_end - g.mc_sample_begin;
+    c->s_begin = g.mc_sample_begin;
+#define CK(expr)                                                                    \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "hnet_create: %s: %s\n", #expr, hipGetErrorString(e_)); \
+            hnet_destroy(c);                                                        \
+            return HNET_ERR_DEVICE;                                                 \
+        }                                                                           \
+    } while (0)
+    CK(hipSetDevice(g.device_id));
+    CK(conv_kernels_init_device());      // dynamic-LDS limits of the patch / fused kernels: per device, so set at every create
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+    { const int rc_w = upload_weights(c, b); if (rc_w != HNET_OK) { hnet_destroy(c); return rc_w; } }
+    if (c->n_planes == 2) c->blob_copy.assign(blob, blob + len);
 
     // ---- persistent activation buffers (NHWC fp32), one per layer so every intermediate can be read back
     const size_t MB = (size_t)g.max_batch;
@@ -763,7 +789,7 @@ void hnet_default_config(hnet_config* cfg) {
     cfg->blocks_to_run = 3;
     cfg->mc_samples = 16;        // model_to_trace.py:202
     cfg->dropout_p = 0.05f;      // trace_model.py:16
-    cfg->precision = HNET_PREC_BF16X3;   // fp32-grade results on the bf16 matrix cores (1.4x the exact-fp32 MFMA path; same parity tests)
+    cfg->precision = HNET_PREC_F16X2;    // fp32-grade results on the fp16 matrix cores, three MFMAs per product (same parity tests as HNET_PREC_BF16X3 / FP32)
     cfg->max_batch = 1;
 }
 
@@ -938,6 +964,31 @@ static void note_timing(hnet_ctx* c, float dev_ms, double host_ms, bool main_mod
     }
 }
 
+// HNET_PREC_F16X2 carries activations in fp16 planes (|a| < 65504).  An overflow turns into infinities / NaNs that reach the outputs; the
+// host-result entry points then re-pack the weights for HNET_PREC_BF16X3 (fp32 range, same kernels in their six-product form), run the call
+// again and stay in that mode: a finite answer of the reference is never lost to the faster arithmetic.
+static bool all_finite(const float* v, size_t n) {
+    for (size_t i = 0; i < n; i++) if (!std::isfinite(v[i])) return false;
+    return true;
+}
+static int demote_to_bf16x3(hnet_ctx* c) {
+    if (c->n_planes != 2 || c->blob_copy.empty()) return HNET_ERR_UNSUPPORTED;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Blob b;
+    if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
+    c->n_planes = 3;
+    c->cfg.precision = HNET_PREC_BF16X3;
+    const int rc = upload_weights(c, b);
+    if (rc != HNET_OK) return fail(c, rc, "re-packing the weights for HNET_PREC_BF16X3");
+    for (int i = 0; i < 2; i++) if (c->g_infer[i]) { (void)hipGraphExecDestroy(c->g_infer[i]); c->g_infer[i] = nullptr; }   // captured with the old kernels
+    if (c->g_batch) { (void)hipGraphExecDestroy(c->g_batch); c->g_batch = nullptr; }
+    c->blob_copy.clear();
+    c->blob_copy.shrink_to_fit();
+    fprintf(stderr, "hnet: activation beyond the fp16 range in HNET_PREC_F16X2: context demoted to HNET_PREC_BF16X3\n");
+    return HNET_OK;
+}
+int hnet_precision(const hnet_ctx* c) { return c ? c->cfg.precision : -1; }
+
 int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_out[8], float cov_out[64], uint8_t* err_map_out) {
     if (!c || !mean_out || !cov_out) return HNET_ERR_INVALID_ARG;
     if (c->img_counter < 2) return fail(c, HNET_ERR_NOT_READY, "HNet cannot inference! Only has one image!");   // :155-158
@@ -972,6 +1023,10 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             HIPCHK(c, hipGraphLaunch(c->g_infer[slot], c->stream));
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->n_planes == 2 && !(all_finite(pin->mean, 8) && all_finite(pin->cov, 64))) {
+                const int rd = demote_to_bf16x3(c);
+                return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
+            }
             memcpy(mean_out, pin->mean, 32);
             memcpy(cov_out, pin->cov, 256);
             if (err_map_out) memcpy(err_map_out, pin->err, NPIX);
@@ -998,6 +1053,10 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (err_map_out) HIPCHK(c, hipMemcpyAsync(err_map_out, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->n_planes == 2 && !(all_finite(mean_out, 8) && all_finite(cov_out, 64))) {
+        const int rd = demote_to_bf16x3(c);
+        return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
+    }
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), iteration == 0);
@@ -1039,6 +1098,10 @@ int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fm
     HIPCHK(c, hipMemcpyAsync(cov, c->d_cov, (size_t)batch * 64 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (err_map) HIPCHK(c, hipMemcpyAsync(err_map, c->d_err, (size_t)batch * NPIX * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (c->n_planes == 2 && !(all_finite(mean, (size_t)batch * 8) && all_finite(cov, (size_t)batch * 64))) {
+        const int rd = demote_to_bf16x3(c);
+        return rd != HNET_OK ? rd : hnet_infer_batch(c, prev, curr, pix_fmt, prior, batch, pair_seq0, mean, cov, err_map);
+    }
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

@@ -32,10 +32,10 @@ class HnetEngine:
     def __init__(self, weights, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1,
                  emit_error_map=False, device_id=0, mc_shard=None, precision=None):
         L = lib()
-        if precision is None:   # default: split-bf16 (fp32-grade) MFMA path; HNET_PRECISION=0 selects the exact-fp32 MFMA path
-            precision = int(os.environ.get("HNET_PRECISION", str(_capi.PREC_BF16X3)))
         cfg = Config()
         L.hnet_default_config(C.byref(cfg))
+        if precision is None:   # default: the library's (fp16 planes, fp32-grade); HNET_PRECISION=2 / 0 select split-bf16 / the exact-fp32 MFMA path
+            precision = int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
         cfg.device_id = device_id
         cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant]
         cfg.mc_samples, cfg.dropout_p, cfg.mc_seed = mc_samples, dropout_p, mc_seed
@@ -51,6 +51,10 @@ class HnetEngine:
             rc = L.hnet_create(C.byref(cfg), str(weights).encode(), C.byref(self._h))
         check(None, rc)
         self.n_local = (cfg.mc_sample_end - cfg.mc_sample_begin) if mc_shard else mc_samples
+
+    def precision(self):
+        """the arithmetic mode in effect (hnet_precision: HNET_PREC_F16X2 falls back to HNET_PREC_BF16X3 outside the fp16 range)"""
+        return int(self._L.hnet_precision(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

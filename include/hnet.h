@@ -48,8 +48,8 @@ enum {
  *   HNET_PREC_F16X2  fp32-grade accuracy on the fp16 matrix cores with THREE MFMAs per product: an activation is two fp16 planes
  *                    (a = A0 + A1 / 4096, 22 + 2 significand bits), a weight three (4096 w = W0 + W1, W0 / 4096), the accumulator
  *                    carries 4096 x the sum (csrc/s3_format.h).  Same parity gates as HNET_PREC_BF16X3.  Range: |weight| < 16
- *                    (checked by hnet_create: HNET_ERR_UNSUPPORTED otherwise) and |activation| < 65504 (an overflow shows as a
- *                    non-finite result, never as a silently wrong one) */
+ *                    and |activation| < 65504; outside it the context runs HNET_PREC_BF16X3 instead (hnet_precision below):
+ *                    an overflow shows as a non-finite result, never as a silently wrong one, and is recovered from */
 enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1, HNET_PREC_BF16X3 = 2, HNET_PREC_F16X2 = 3 };
 enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buffers */
 
@@ -82,8 +82,8 @@ typedef struct hnet_timing {
 } hnet_timing;
 
 /* fills `cfg` with the reference's launch defaults — full model, N=16, p=0.05, max_batch 1 — and precision =
- * HNET_PREC_BF16X3 (fp32-grade results on the bf16 matrix cores; passes the same parity gates as HNET_PREC_FP32, which is
- * the reference's own fp32 arithmetic and stays selectable) */
+ * HNET_PREC_F16X2 (fp32-grade results on the fp16 matrix cores; passes the same parity gates as HNET_PREC_BF16X3 and as
+ * HNET_PREC_FP32, which is the reference's own fp32 arithmetic; both stay selectable) */
 void hnet_default_config(hnet_config* cfg);
 
 /* Replaces HomographyNet::load_network_model (HomographyNet.cpp:81-103): `weights_path` names an HNETW001
@@ -96,6 +96,11 @@ void hnet_destroy(hnet_ctx* ctx);
 const char* hnet_status_string(int status);
 const char* hnet_last_error(const hnet_ctx* ctx);   /* text of the last HNET_ERR_DEVICE etc.; never NULL */
 const char* hnet_version(void);
+/* the arithmetic mode in effect (HNET_PREC_*).  It differs from the requested one in two cases, both HNET_PREC_F16X2 -> HNET_PREC_BF16X3
+ * (same results, twice the matrix-core work): a weight >= 16 at hnet_create, or an activation beyond the fp16 range seen by hnet_infer /
+ * hnet_infer_batch (non-finite outputs): the context re-packs its weights, repeats the call and stays in HNET_PREC_BF16X3.  The
+ * device-resident entry points cannot look at their results: there such an overflow shows as non-finite outputs. */
+int hnet_precision(const hnet_ctx* ctx);
 
 /* Replaces HomographyNet::load_current_img (HomographyNet.cpp:127-151): copies the 224x320 8-bit image
  * (row_stride in bytes) to the device, prev <- curr, curr <- img; counts images; records `t` from the second

@@ -1,0 +1,65 @@
+"""HNET_PREC_F16X2 (the default arithmetic: two fp16 planes per activation, three fp16 MFMAs per product, csrc/s3_format.h) has a
+range: |weight| < 16, |activation| < 65504.  Outside it the context must give the answer of HNET_PREC_BF16X3 — never a silently
+wrong or a non-finite one — and say so through hnet_precision."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PREC_BF16X3, PREC_F16X2 = 2, 3
+
+
+def _pair(seed):
+    from cuahn_vio_amd import synth
+    i1, i2, _ = synth.make_pair(seed)
+    return i1, i2
+
+
+def test_default_is_f16x2_and_stays_there_on_ordinary_input(blob):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    i1, i2 = _pair(3)
+    e = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=2)
+    assert e.precision() == PREC_F16X2
+    mean, cov = e.infer_batch(np.stack([i1, i2]), np.stack([i2, i1]), None)
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    assert e.precision() == PREC_F16X2
+    e.close()
+
+
+def test_activation_overflow_demotes_to_bf16x3_and_returns_its_result(blob):
+    """float images scaled far beyond [0, 1]: block_1_1's outputs exceed 65504, the fp16 planes overflow, the outputs turn non-finite;
+    hnet_infer_batch re-packs the weights for split-bf16, repeats the call and returns exactly what a BF16X3 context returns"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    i1, i2 = _pair(5)
+    big1 = (i1.astype(np.float32) / 255.0 * 3.0e6)[None]
+    big2 = (i2.astype(np.float32) / 255.0 * 3.0e6)[None]
+    ref = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=1, precision=PREC_BF16X3)
+    m_ref, c_ref = ref.infer_batch(big1, big2, None)
+    ref.close()
+    assert np.isfinite(m_ref).all(), "the test input must be finite in fp32-range arithmetic"
+    e = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=1, precision=PREC_F16X2)
+    assert e.precision() == PREC_F16X2
+    m, c = e.infer_batch(big1, big2, None)
+    assert e.precision() == PREC_BF16X3
+    assert np.array_equal(m, m_ref) and np.array_equal(c, c_ref)
+    # and it stays usable: an ordinary pair afterwards equals the BF16X3 context's answer too
+    m2, _ = e.infer_batch(i1[None], i2[None], None)
+    ref = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=1, precision=PREC_BF16X3)
+    m2_ref, _ = ref.infer_batch(i1[None], i2[None], None)
+    ref.close()
+    e.close()
+    assert np.array_equal(m2, m2_ref)
+
+
+def test_weights_beyond_the_fp16_plane_range_select_bf16x3_at_create(state):
+    from cuahn_vio_amd import weights
+    from cuahn_vio_amd.homography_net import HnetEngine
+    st = {k: v.copy() for k, v in state.items()}
+    k = "model_part1.block_2_2.0.weight"
+    st[k].reshape(-1)[7] = 20.0                     # one weight >= 16
+    e = HnetEngine(weights.pack_state_dict(st), variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=PREC_F16X2)
+    assert e.precision() == PREC_BF16X3
+    i1, i2 = _pair(2)
+    mean, _ = e.infer_batch(i1[None], i2[None], None)
+    assert np.isfinite(mean).all()
+    e.close()
