@@ -348,6 +348,19 @@ template <int N>
 __device__ __forceinline__ void wait3(bf16x4 (&a)[3]) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
 }
+// the same with only the 2 NP (fragment) / NP (tail) registers a mode loads: naming registers that were never loaded would keep them alive
+template <int N, int NP>
+__device__ __forceinline__ void waitF(bf16x4 (&a)[6]) {
+    if constexpr (NP == 3) wait6<N>(a);
+    else if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+}
+template <int N, int NP>
+__device__ __forceinline__ void waitT(bf16x4 (&a)[3]) {
+    if constexpr (NP == 3) wait3<N>(a);
+    else if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[0]) : "n"(N));
+}
 using s3p::cvt_pk;
 using s3p::split_pair;
 using s3p::lrelu;
@@ -359,7 +372,10 @@ using s3p::lrelu;
 // split, no bounds logic: the zero border is in memory), the copy of tile t+1 runs under phase 2 of tile t, and phase 2 stores
 // its 8-byte pieces straight to global memory (the patch area is busy, and 64 lanes x 8 bytes already cover whole 512-byte
 // runs).  DMA = false: fp32 NHWC input, split while staged (the round-2 first version of this kernel).
-template <int TH1, int THREADS, int NP, bool DMA = false>
+// REUSE (4-wave geometry): a wave's consecutive phase-1 M-tiles are two region rows apart, so step st of tile j + 1 reads exactly what
+// step st + 1 of tile j read (same lanes, same addresses): the fragments stay in registers and a tile fetches ONE new 32-deep fragment plus
+// its 16-deep tail instead of three plus tail (LDS reads of phase 1: 7 -> 3 ds_read_b64 per plane and tile), prefetched one tile ahead.
+template <int TH1, int THREADS, int NP, bool DMA = false, bool REUSE = false>
 __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __restrict__ x_in_v, size_t x_plane, const u32x4* __restrict__ w0frag,
                                                                   const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
                                                                   const float* __restrict__ bias1, uint16_t* __restrict__ out16,
@@ -542,6 +558,90 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
         // ---- phase 1: block_4_0 over the region, into the S3 image.  Regular M-tiles: fully unrolled, immediate addressing.
         // column validity of this lane's pixel (row validity is wave-uniform per M-tile)
         const bool col_ok = (unsigned)(Rx0 + whalf * 32 + 2 * m + dx) < (unsigned)W0;
+        if constexpr (REUSE && HW == 2) {
+            constexpr int R = 2 * NP;                        // reads per 32-deep fragment; a tail fragment is NP reads
+            bf16x4 F[J1 + 2][6];                             // fragment q = region rows wrow + 2q, 2q + 1 (tile j uses q = j, j + 1, j + 2)
+            bf16x4 T[J1][3];                                 // tail fragment of tile j = region row wrow + 2j + 6
+            auto rdF = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    F[q][2 * pl] = rd64<2 * q * PROW0 * 2 + pl * PPLANE * 2>(p1a[0]);
+                    F[q][2 * pl + 1] = rd64<2 * q * PROW0 * 2 + pl * PPLANE * 2 + 8>(p1a[0]);
+                });
+            };
+            auto rdT = [&](auto jc2) {
+                constexpr int j2 = decltype(jc2)::value;
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    T[j2][pl] = rd64<HW * j2 * PROW0 * 2 + pl * PPLANE * 2>(p1t);
+                });
+            };
+            // in flight on entry of tile j > 0: F[j + 2] (R reads) then T[j] (NP reads), issued by tile j - 1.  lgkmcnt counts to 15: never more
+            // than 2 R + NP = 15 (NP = 3) operations are outstanding when a wait is issued (this tile's LDS stores included, which only makes
+            // a wait conservative: LDS operations complete in order)
+            rdF(std::integral_constant<int, 0>{}); rdF(std::integral_constant<int, 1>{});
+            static_for<J1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (wave + WAVES * j < N_REG) {              // wave-uniform
+                    // the next tile exists for every wave (compile time) / for some waves only (then nothing is prefetched and the waits
+                    // below are the conservative ones: waiting for fewer outstanding operations than there are is always correct)
+                    constexpr bool next_all = WAVES * (j + 2) <= N_REG;
+                    f32x4_t acc = bv;
+                    auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
+                        bf16x8 a[3];
+#pragma unroll
+                        for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc = b4_mfma<NP>(acc, w, a);
+                    };
+                    constexpr bool pre = j > 0 && WAVES * (j + 1) <= N_REG;      // F[j + 2], T[j] were prefetched by tile j - 1
+                    if constexpr (j == 0) {
+                        waitF<R, NP>(F[0]); __builtin_amdgcn_sched_barrier(0); mm(F[0], w0[0]);
+                        rdF(std::integral_constant<int, 2>{});
+                        rdT(std::integral_constant<int, 0>{});
+                        waitF<R + NP, NP>(F[1]); __builtin_amdgcn_sched_barrier(0); mm(F[1], w0[1]);
+                        if constexpr (next_all) rdF(std::integral_constant<int, 3>{});
+                    } else {
+                        if constexpr (!pre) { rdF(std::integral_constant<int, j + 2>{}); rdT(std::integral_constant<int, j>{}); }
+                        if constexpr (next_all) rdF(std::integral_constant<int, j + 3>{});
+                        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: without it the scheduler interleaves tiles and runs out of registers
+                        mm(F[j], w0[0]);
+                        mm(F[j + 1], w0[1]);
+                    }
+                    waitF<(next_all ? R : 0) + NP, NP>(F[j + 2]); __builtin_amdgcn_sched_barrier(0); mm(F[j + 2], w0[2]);
+                    if constexpr (next_all) rdT(std::integral_constant<int, j + 1>{});
+                    waitT<(next_all ? R + NP : 0), NP>(T[j]); __builtin_amdgcn_sched_barrier(0);
+                    f32x4_t acct = {0.f, 0.f, 0.f, 0.f};     // own accumulator chain: see the non-REUSE path
+                    if constexpr (NP == 2) {
+                        acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[2]), __builtin_bit_cast(f16x4, T[j][1]), acct, 0, 0, 0);
+                        acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[1]), __builtin_bit_cast(f16x4, T[j][0]), acct, 0, 0, 0);
+                        acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[0]), __builtin_bit_cast(f16x4, T[j][0]), acct, 0, 0, 0);
+                    } else {
+                        if constexpr (NP == 3) {
+                            acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], T[j][2], acct, 0, 0, 0);
+                            acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[2], T[j][0], acct, 0, 0, 0);
+                            acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], T[j][1], acct, 0, 0, 0);
+                            acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], T[j][1], acct, 0, 0, 0);
+                            acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], T[j][0], acct, 0, 0, 0);
+                        }
+                        acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], T[j][0], acct, 0, 0, 0);
+                    }
+                    acc += acct;
+                    const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = ok ? s3p::act<NP>(acc[r]) : 0.f;
+                    uint32_t pa[3], pb[3];
+                    split_pair<NP>(v[0], v[1], pa);
+                    split_pair<NP>(v[2], v[3], pb);
+                    constexpr int JW = HW * j * 2 * XH * 16;
+                    static_for<NP>([&](auto pc) {
+                        constexpr int pl = decltype(pc)::value;
+                        wr64<JW + pl * PLANE * 2>(st1a, make_uint2(pa[pl], pb[pl]));
+                    });
+                }
+            });
+        } else
         static_for<J1>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (wave + WAVES * j < N_REG) {                  // wave-uniform
@@ -565,14 +665,14 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 constexpr int R = 2 * NP;                    // reads per 32-deep step; the tail step reads NP
                 bf16x4 ft[3];
                 rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
-                wait6<2 * R>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w0[0]);
+                waitF<2 * R, NP>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w0[0]);
                 static_for<NP>([&](auto pc) {
                     constexpr int pl = decltype(pc)::value;
                     ft[pl] = rd64<JR + pl * PPLANE * 2>(p1t);
                 });
-                wait6<R + NP>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
-                wait6<NP>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
-                wait3<0>(ft); __builtin_amdgcn_sched_barrier(0);
+                waitF<R + NP, NP>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
+                waitF<NP, NP>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
+                waitT<0, NP>(ft); __builtin_amdgcn_sched_barrier(0);
                 // its own accumulator: a 16x16x16 MFMA whose SrcC is the result of a 16x16x32 MFMA issued just before returned wrong sums
                 // (the compiler inserts no wait states for that mixed pair here; with two s_nop 15 in between the results were right).
                 // Two chains of one opcode each have no such dependency; they meet in four v_add.
@@ -670,17 +770,17 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 };
                 constexpr int R = 2 * NP;                    // reads per step
                 rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
-                wait6<2 * R>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w1[0]);
+                waitF<2 * R, NP>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w1[0]);
                 rd(std::integral_constant<int, 3>{});
-                wait6<2 * R>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w1[1]);
+                waitF<2 * R, NP>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w1[1]);
                 rd(std::integral_constant<int, 4>{});
-                wait6<2 * R>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w1[2]);
+                waitF<2 * R, NP>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w1[2]);
                 rd(std::integral_constant<int, 5>{});
-                wait6<2 * R>(f[3]); __builtin_amdgcn_sched_barrier(0); mm(f[3], w1[3]);
+                waitF<2 * R, NP>(f[3]); __builtin_amdgcn_sched_barrier(0); mm(f[3], w1[3]);
                 rd(std::integral_constant<int, 6>{});
-                wait6<2 * R>(f[4]); __builtin_amdgcn_sched_barrier(0); mm(f[4], w1[4]);
-                wait6<1 * R>(f[5]); __builtin_amdgcn_sched_barrier(0); mm(f[5], w1[5]);
-                wait6<0>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
+                waitF<2 * R, NP>(f[4]); __builtin_amdgcn_sched_barrier(0); mm(f[4], w1[4]);
+                waitF<1 * R, NP>(f[5]); __builtin_amdgcn_sched_barrier(0); mm(f[5], w1[5]);
+                waitF<0, NP>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
                 // D (transposed): row 4g + r = cout, column m = output pixel: 8 bytes (4 channels) per lane and plane
                 uint32_t pa[3], pb[3];
                 split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);

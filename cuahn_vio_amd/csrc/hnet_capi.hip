@@ -90,12 +90,13 @@ struct hnet_ctx {
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
     int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments); bit 4: no XCD-aware tile order (HNET_B4_XCD=0)
-    int b4_cfg = 5;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging
+    int b4_cfg = 6;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging, 6 = 5 + phase-1 fragment reuse
     uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
     size_t x16_plane = 0;              // dwords per plane
     int n_planes = 3;                  // 16-bit planes the matrix-core layers read and write = their arithmetic mode: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16), 2 = fp16 planes (HNET_PREC_F16X2, fp32-grade)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
+    int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
     bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
@@ -341,7 +342,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
-                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes));
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes, c->s3_tile));
             else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
@@ -358,7 +359,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     float* hidden = c->hidden + P0 * c->n_local * 512;
     if (c->s3)
         STAGE(launch_heads_fc1_s3(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1_16, c->b1, hidden,
-                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes));
+                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes, c->s3_tile));
     else
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
     if (a.partial) {
@@ -409,6 +410,11 @@ hipGraphExec_t capture_graph(hnet_ctx* c, F&& body) {
 
 // Weights -> device, in the layouts of the kernels of the context's arithmetic mode (c->s3, c->n_planes).  Called by hnet_create and again by
 // demote_to_bf16x3 (buffers of an earlier call are released first).  On failure the caller destroys the context.
+// weight planes of the implicit-GEMM layers (igemm_s3.h): the fp16 mode uses the two-plane activation split there (s3_wplanes_gemm)
+static inline void wsplit_gemm(float w, int np, uint16_t& a, uint16_t& b, uint16_t& c3) {
+    if (np == 2) { split2h(w, a, b); c3 = 0; }
+    else split3(w, a, b, c3);
+}
 int upload_weights(hnet_ctx* c, const Blob& b) {
 #define CK(expr)                                                                    \
     do {                                                                            \
@@ -580,7 +586,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
             if (c->s3 && conv_is_s3_layer(l)) {     // exact 3-way bf16 split of every weight: planes [3][Cout][Kp]
                 std::vector<uint16_t> pl(packed.size() * 3);
                 for (size_t i = 0; i < packed.size(); i++)
-                    wsplit_np(packed[i], c->n_planes, pl[i], pl[packed.size() + i], pl[2 * packed.size() + i]);
+                    wsplit_gemm(packed[i], c->n_planes, pl[i], pl[packed.size() + i], pl[2 * packed.size() + i]);
                 CK(hipMalloc((void**)&c->conv_w16[l], pl.size() * 2));
                 CK(hipMemcpy(c->conv_w16[l], pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
             }
@@ -614,7 +620,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
         CK(upload(&c->w1, w1)); CK(upload(&c->b1, b1)); CK(upload(&c->w2, w2)); CK(upload(&c->b2, b2));
         if (c->s3) {
             std::vector<uint16_t> pl(w1.size() * 3);
-            for (size_t i = 0; i < w1.size(); i++) wsplit_np(w1[i], c->n_planes, pl[i], pl[w1.size() + i], pl[2 * w1.size() + i]);
+            for (size_t i = 0; i < w1.size(); i++) wsplit_gemm(w1[i], c->n_planes, pl[i], pl[w1.size() + i], pl[2 * w1.size() + i]);
             CK(hipMalloc((void**)&c->w1_16, pl.size() * 2));
             CK(hipMemcpy(c->w1_16, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
         }
@@ -669,13 +675,14 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
+    c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
     c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
     if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
     // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
     // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
-    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(5, atoi(getenv("HNET_B4_CFG")))) : 5;
+    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(6, atoi(getenv("HNET_B4_CFG")))) : 6;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \

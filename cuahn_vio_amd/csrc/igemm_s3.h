@@ -35,6 +35,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int NP> constexpr int s3_wplanes = NP == 1 ? 1 : 3;
 template <int NP> constexpr float s3_acc_scale = NP == 2 ? S3_F16_SCALE : 1.0f;
 template <int NP> __device__ __forceinline__ float s3_descale(float acc) { return NP == 2 ? acc * S3_F16_INV : acc; }
+// The implicit-GEMM kernels of this file run the fp16 mode with TWO weight planes (w = W0 + W1 / 4096, the activation split) and two
+// accumulators per tile: hi += W0 A0, lo += W1 A0 + W0 A1, result = hi + lo / 4096 - the same three MFMAs per product, a third less
+// weight traffic through LDS (these kernels are LDS bound in this mode) and two shorter dependent MFMA chains.  The kernels that keep
+// their weights in registers use the three-plane form above (one accumulator).
+template <int NP> constexpr int s3_wplanes_gemm = NP == 1 ? 1 : NP;
 
 struct S3Params {
     const uint16_t* A;     // input planes [3][...] NHWC bf16
@@ -54,6 +59,7 @@ struct S3Params {
     int n_local;
     const uint16_t* zeros; // >= 16 bytes of zeros in global memory: source of padding / out-of-range chunks for the LDS-DMA kernel
     int xcd_remap;         // 1: XCD-aware workgroup -> tile mapping (s3_tile_origin)
+    int tile;              // tile-shape experiment of the context (HNET_S3_TILE at hnet_create; 0 = the measured defaults of s3_dispatch.h)
 #ifdef HNET_S3_TRACE
     unsigned long long* trace;   // tools/trace_s3.hip only: [block < 8][wave][S3T_SLOTS] s_memtime stamps
 #endif
@@ -226,7 +232,7 @@ __device__ __forceinline__ int s3_swz(int row, int chunk) {
 // epilogue of the transposed 16x16x32 tiles (shared by the register-staged and the LDS-DMA kernel): lane (m = lane&15,
 // g = lane>>4) holds channels 4g .. 4g+3 of GEMM row m of every 16x16 tile; (mw, nw) = origin of the wave's tile
 typedef float f32x4_m16 __attribute__((ext_vector_type(4)));
-template <int TM16, int TN16, bool OUT32, int NP = 3>
+template <int TM16, int TN16, bool OUT32, int NP = 3, bool SCALED = (NP == 2)>
 __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], const S3Params& p, uint16_t* st_wave, int mw, int nw, int lane) {
     // ---- epilogue of the transposed 16x16 tiles: lane (m = lane&15, g = lane>>4) holds channels n = 4g .. 4g+3 of GEMM row m
     typedef float f32x4_e __attribute__((ext_vector_type(4)));
@@ -244,7 +250,7 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
                 if (m < p.M && n < p.N) {
                     f32x4_e v = acc16[i][j];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = s3_descale<NP>(v[e]);      // split-K partials are written at the true scale too
+                    for (int e = 0; e < 4; e++) v[e] = SCALED ? s3_descale<NP>(v[e]) : v[e];      // split-K partials are written at the true scale too
                     if (p.k_split == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
@@ -272,7 +278,7 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
                     uint16_t sp[3][4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        float v = s3_descale<NP>(acc16[i][j][e]) + bv[e];
+                        float v = (SCALED ? s3_descale<NP>(acc16[i][j][e]) : acc16[i][j][e]) + bv[e];
                         v = v > 0.0f ? v : v * 0.1f;
                         s3p::split1<NP>(v, sp[0][e], sp[1][e], sp[2][e]);
                     }
@@ -317,6 +323,12 @@ __device__ __forceinline__ f32x4_m16 s3_mfma16(f32x4_m16 acc, const bf16x8 (&w)[
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], a[0], acc, 0, 0, 0);
 }
 
+// fp16 mode of the GEMM kernels: two weight planes, two accumulators (see s3_wplanes_gemm)
+__device__ __forceinline__ void s3_mfma16_2acc(f32x4_m16& hi, f32x4_m16& lo, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, a[1]), lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[1]), __builtin_bit_cast(f16x8, a[0]), lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[0]), __builtin_bit_cast(f16x8, a[0]), hi, 0, 0, 0);
+}
 // the same product group on 32x32x16 tiles (weights as A operand)
 typedef float f32x16_m32 __attribute__((ext_vector_type(16)));
 template <int NP>
@@ -355,7 +367,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows");
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK; // bf16 elements per plane and buffer
     static_assert(NP == 3 || MF == 16, "plain bf16 and the fp16 planes exist in the transposed 16x16x32 form");
-    constexpr int NW = s3_wplanes<NP>;                // weight planes
+    constexpr int NW = s3_wplanes_gemm<NP>;           // weight planes
 
     // [buf][plane][rows][32]; the epilogue reuses it as a store staging area
     constexpr int SMEM_ELEMS = NBUF * (NP * TILE_A + NW * TILE_B) > 4 * 3 * 32 * 32 ? NBUF * (NP * TILE_A + NW * TILE_B) : 4 * 3 * 32 * 32;
@@ -394,6 +406,11 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     for (int i = 0; i < TM16; i++)
 #pragma unroll
         for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+    f32x4_m16 acc16l[NP == 2 ? TM16 : 1][NP == 2 ? TN16 : 1];     // fp16 mode: the cross terms, scaled by 4096
+#pragma unroll
+    for (int i = 0; i < (NP == 2 ? TM16 : 1); i++)
+#pragma unroll
+        for (int j = 0; j < (NP == 2 ? TN16 : 1); j++) acc16l[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
 
     u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
     bool aok[A_ROWS], bok[B_ROWS];
@@ -487,8 +504,10 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
 #pragma unroll
                 for (int i = 0; i < TM16; i++)
 #pragma unroll
-                    for (int j = 0; j < TN16; j++)   // weights as A operand: D' row 4g + r = output channel, column = GEMM row
-                        acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                    for (int j = 0; j < TN16; j++) { // weights as A operand: D' row 4g + r = output channel, column = GEMM row
+                        if constexpr (NP == 2) s3_mfma16_2acc(acc16[i][j], acc16l[i][j], bf[j], af[i]);
+                        else acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                    }
             }
         } else
 #pragma unroll
@@ -540,7 +559,13 @@ static __global__ __launch_bounds__(256) void igemm_s3_kernel(S3Params p) {
     }
 
     if constexpr (MF == 16) {
-        s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int i = 0; i < TM16; i++)
+#pragma unroll
+                for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
+        }
+        s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
         return;
     }
     // ---- epilogue: bias + LeakyReLU(0.1); D layout: col n = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
     constexpr int LUT_ELEMS = L::HAS_MASK ? 256 * 8 : 0;          // 256 entries x 16 bytes
-    constexpr int NW = s3_wplanes<NP>;                             // weight planes
+    constexpr int NW = s3_wplanes_gemm<NP>;                        // weight planes
     constexpr int TILES = NP * TILE_A + NW * TILE_B > 4 * 3 * 32 * 32 ? NP * TILE_A + NW * TILE_B : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[TILES + LUT_ELEMS];
     uint16_t* As = smem;
@@ -715,6 +740,11 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
     for (int i = 0; i < TM16; i++)
 #pragma unroll
         for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+    f32x4_m16 acc16l[NP == 2 ? TM16 : 1][NP == 2 ? TN16 : 1];     // fp16 mode: the cross terms, scaled by 4096
+#pragma unroll
+    for (int i = 0; i < (NP == 2 ? TM16 : 1); i++)
+#pragma unroll
+        for (int j = 0; j < (NP == 2 ? TN16 : 1); j++) acc16l[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
 
     u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
     uint32_t amask[A_ROWS];
@@ -786,14 +816,23 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
 #pragma unroll
             for (int i = 0; i < TM16; i++)
 #pragma unroll
-                for (int j = 0; j < TN16; j++) acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                for (int j = 0; j < TN16; j++) {
+                    if constexpr (NP == 2) s3_mfma16_2acc(acc16[i][j], acc16l[i][j], bf[j], af[i]);
+                    else acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the consumers of the prefetched registers behind the MFMAs (see igemm.h)
         __syncthreads();                     // every wave has read tile `it`
         if (it + 1 < n_iter) s_store();
         __syncthreads();
     }
-    s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int i = 0; i < TM16; i++)
+#pragma unroll
+            for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
+    }
+    s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
 bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3);
+                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3, int tile = 0);
 bool conv_is_region5_layer(int layer);    // block_1_2 / block_2_2 at their network size (conv5_region.h); wpack = [CIN/16][13 steps][3][128][32] bf16
 hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
                                size_t o_plane, hipStream_t s, int n_planes = 3);
@@ -47,7 +47,7 @@ hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag,
                                 hipStream_t s, int n_planes = 3);
 // cfg (s3_dispatch.h): 0 / 1 fp32 NHWC input (8x32 tiles x 512 threads / 7x32 x 256, two workgroups per CU), 2 / 3 the older v2 kernel,
 // 4 / 5 the same geometries fed from the padded bf16 planes (B4_* above, x_plane dwords per plane) by LDS-DMA
-inline bool b4_cfg_is_dma(int cfg) { return cfg == 4 || cfg == 5; }
+inline bool b4_cfg_is_dma(int cfg) { return cfg >= 4 && cfg <= 6; }
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */,
                                int cfg = 1, int n_planes = 3);
@@ -56,7 +56,7 @@ hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
-                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3);
+                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3, int tile = 0);
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 

@@ -101,7 +101,7 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
         // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
         // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
         static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
-        static const int t96 = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;
+        const int t96 = p.tile;
         const bool bk64_ok = BM != 96 || t96 == 6;               // 96-row tiles: 32-wide K tiles keep three workgroups per CU (61 KB of LDS at BK 64)
         // lean operand staging (igemm_s3.h: buffer loads with scalar tap offsets, no selects): same tiles, bit-identical results,
         // a fraction of the VALU instructions per MFMA (HNET_S3_LEAN=0: the round-1 staging)
@@ -137,25 +137,26 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
 template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
 static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
-    static const int tile = std::getenv("HNET_S3_TILE") ? std::atoi(std::getenv("HNET_S3_TILE")) : 0;   // experiments
+    const int tile = p.tile;                                 // experiments (HNET_S3_TILE, read by hnet_create)
     if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
     else {
         // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
         const bool big_m = p.M >= 4096;
-        if constexpr (NP == 3) {
+        if constexpr (NP != 1) {
             if (tile == 1) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn);
             if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
-            if constexpr (CIN == 128 && KS == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
+            if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         }
         if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
-        if constexpr (CIN == 128 && KS == 5) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+        // (fp16 mode: two accumulators per tile - the 128x128 tile would need 128 accumulator registers: 0.091 ms against 0.080 ms with 64x64)
+        if constexpr (CIN == 128 && KS == 5 && NP != 2) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
     }
 }
 
 // block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
 // cfg 0: 8 x 32 tiles, one 512-thread workgroup per CU;  cfg 1: 7 x 32 tiles, two 256-thread workgroups per CU
-template <int TH1, int THREADS, int NP, bool V2 = false, bool DMA = false>
+template <int TH1, int THREADS, int NP, bool V2 = false, bool DMA = false, bool REUSE = false>
 static hipError_t run_b4(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                          uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
     typedef B4Cfg<TH1, THREADS, NP, DMA> C;
@@ -166,7 +167,7 @@ static hipError_t run_b4(const void* x_in, size_t x_plane, const void* w0frag, c
         hipLaunchKernelGGL((block4_fused_kernel_v2<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, (const float*)x_in,
                            (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
     else
-        hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP, DMA>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, x_plane,
+        hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP, DMA, REUSE>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, x_plane,
                            (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
     return hipGetLastError();
 }
@@ -191,6 +192,7 @@ hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* 
     }
     if (cfg == 4) return run_b4<8, 512, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
     if (cfg == 5) return run_b4<7, 256, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if (cfg == 6) return run_b4<7, 256, NP, false, true, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);   // 5 + phase-1 fragment reuse
     return run_b4<7, 256, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
@@ -293,7 +295,7 @@ template <int NP>
 hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                                   uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                   uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
-                                  const uint64_t* seq_dev) {
+                                  const uint64_t* seq_dev, int tile) {
     const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
                        hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP);
@@ -301,7 +303,8 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
     p.out32 = hidden;
     p.M = batch * n_local; p.N = 512; p.Kp = 5120;
-    p.mask = mask; p.n_local = n_local;
+    p.mask = mask; p.n_local = n_local; p.tile = tile;
+    if constexpr (NP == 2) { if (tile == 2 && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn); }
     // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
     if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn);
     return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, ws, wsn);
@@ -310,13 +313,14 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
 template <int NP>
 hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                              size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                             float* ws, size_t wsn, const uint16_t* zeros) {
+                             float* ws, size_t wsn, const uint16_t* zeros, int tile) {
     if (layer < 0 || layer >= 20 || !conv_is_s3_layer(layer)) return hipErrorInvalidValue;
     const ConvDesc& d = kConvs[layer];
     S3Params p = {};
     p.A = in; p.a_plane = in_plane; p.Wp = wplanes; p.w_plane = w_plane; p.bias = bias;
     p.out16 = out16; p.o_plane = o_plane; p.out32 = out32;
     p.zeros = zeros;
+    p.tile = tile;
     p.H = h; p.W = w;
     p.Ho = conv_out_dim(h, d.ks, d.stride);
     p.Wo = conv_out_dim(w, d.ks, d.stride);
@@ -347,6 +351,7 @@ hipError_t conv_kernels_init_device_np() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP, true>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if constexpr (NP != 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
@@ -372,9 +377,9 @@ hipError_t conv_kernels_init_device_np() {
                                                     size_t, hipStream_t, bool);                                                                \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \
                                                       const float*, float*, uint16_t*, size_t, uint8_t*, hipStream_t, float*, size_t,    \
-                                                      const uint64_t*);                                                                  \
+                                                      const uint64_t*, int);                                                             \
     KW template hipError_t launch_conv_s3_np<NP>(int, const uint16_t*, size_t, int, int, int, const uint16_t*, size_t, const float*,     \
-                                                 uint16_t*, size_t, float*, hipStream_t, float*, size_t, const uint16_t*);               \
+                                                 uint16_t*, size_t, float*, hipStream_t, float*, size_t, const uint16_t*, int);          \
     KW template hipError_t conv_kernels_init_device_np<NP>();
 
 }  // namespace hnet

@@ -76,7 +76,7 @@ def _conv2(state, x):
     return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
 
 
-@pytest.mark.parametrize("prec,cfg", [(2, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (3, 0), (3, 1), (3, 4), (3, 5)])
+@pytest.mark.parametrize("prec,cfg", [(2, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (2, 6), (3, 0), (3, 1), (3, 4), (3, 5), (3, 6)])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 5])
 def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg, prec):

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--mc", type=int, default=32)
     ap.add_argument("--variant", default="full")
-    ap.add_argument("--precision", type=int, default=2)
+    ap.add_argument("--precision", type=int, default=3)
     ap.add_argument("--stages", default="")
     a = ap.parse_args()
     import torch
