@@ -469,7 +469,7 @@ def main():
         print(json.dumps(res), flush=True)
     if rank == 0 and not mc_mode and not stream_mode:
         # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on.
-        # executed FLOP = 2 x MACs x (MFMAs per MAC): six bf16 MFMAs stand behind every MAC of the split-bf16 mode;
+        # executed FLOP = 2 x MACs x (MFMAs per MAC): three fp16 MFMAs stand behind every MAC of the default mode, six bf16 ones in split-bf16;
         # peak = dense peak of the instruction actually issued.  The fp32-equivalent rate (2 x MACs / time) is a separate field.
         stages = eng.stages()
         # the oracle check above kept the host busy and the GPU idle for seconds: bring the clocks back to the state of the timed

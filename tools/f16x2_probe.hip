@@ -1,7 +1,7 @@
 // f16x2_probe.hip — can an fp32 product be carried on the fp16 matrix cores with THREE MFMAs instead of the six of the split-bf16 format?
 //   activation a = A0 + A1 / 4096   (A0 = f16(a), A1 = f16((a - A0) * 4096): 11 + 11 significand bits, the residual scaled into the normal range)
-//   weight     w = (W0 + W1) / 4096 (W0 = f16(4096 w), W1 = f16(4096 (4096 w - W0) / 4096 ...)), W0' = W0 / 4096
-//   4096 * a * w ~= W0 A0 + W1 A0 + W0' A1        (dropped: A1 W1 <= 2^-24 relative)
+//   weight planes W0 = f16(4096 w), W1 = f16(4096 w - W0), W0' = W0 / 4096
+//   4096 * a * w ~= W0 A0 + W1 A0 + W0' A1        (dropped: A1 W1 / 4096 <= 2^-22 |a w| 4096)
 // Checks on the device: (1) the three builtins exist for gfx950, (2) fp16 subnormal inputs are not flushed by the MFMA, (3) the error of the
 // scheme against double, next to the six-product split-bf16 scheme and a serial fp32 FMA chain, on conv-like data.
 // build: hipcc --offload-arch=gfx950 -O2 -o /tmp/f16x2_probe tools/f16x2_probe.hip
@@ -90,7 +90,7 @@ int main() {
         A[i] = a;
         float w = 0.05f * nd(rng);
         if (row == 15) w *= 1e-3f;
-        if (row == 14) w *= 100.f;
+        if (row == 14) w *= 50.f;                  // |w| up to ~12: inside the |w| < 16 range of the 4096 w planes
         B[i] = w;
     }
     float *dA, *dB, *dh, *db, *df, *dm;
@@ -115,6 +115,9 @@ int main() {
             const double e[3] = {std::fabs(H[wr * 16 + m] - ref) / scale, std::fabs(Bf[wr * 16 + m] - ref) / scale, std::fabs(F[wr * 16 + m] - ref) / scale};
             for (int s = 0; s < 3; s++) { worst[s] = std::max(worst[s], e[s]); rms[s] += e[s] * e[s]; }
         }
+    int nonfinite = 0;
+    for (int i = 0; i < 256; i++) nonfinite += !std::isfinite(H[i]);
+    printf("non-finite fp16x2 results: %d of 256\n", nonfinite);
     const char* name[3] = {"fp16x2, 3 MFMAs", "bf16x3, 6 MFMAs", "fp32 FMA chain"};
     for (int s = 0; s < 3; s++) printf("%-16s |err| / sum|w a|: worst %.3e  rms %.3e\n", name[s], worst[s], std::sqrt(rms[s] / 256));
     return 0;
