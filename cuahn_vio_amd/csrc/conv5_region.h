@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512) void conv5_region_kernel(const uint16_t* __res
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 uint32_t pa[3], pb[3];
-                s3p::split_pair<NP>(s3p::act<NP>(acc[i][j][0]), s3p::act<NP>(acc[i][j][1]), pa);
-                s3p::split_pair<NP>(s3p::act<NP>(acc[i][j][2]), s3p::act<NP>(acc[i][j][3]), pb);
+                s3p::act_split<NP>(acc[i][j][0], acc[i][j][1], pa);
+                s3p::act_split<NP>(acc[i][j][2], acc[i][j][3], pb);
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + j * 16 + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
             }

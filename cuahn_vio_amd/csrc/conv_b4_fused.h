@@ -628,12 +628,9 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                     }
                     acc += acct;
                     const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = ok ? s3p::act<NP>(acc[r]) : 0.f;
                     uint32_t pa[3], pb[3];
-                    split_pair<NP>(v[0], v[1], pa);
-                    split_pair<NP>(v[2], v[3], pb);
+                    s3p::act_split<NP>(acc[0], acc[1], pa, ok);
+                    s3p::act_split<NP>(acc[2], acc[3], pb, ok);
                     constexpr int JW = HW * j * 2 * XH * 16;
                     static_for<NP>([&](auto pc) {
                         constexpr int pl = decltype(pc)::value;
@@ -694,12 +691,9 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 acc += acct;
                 // epilogue: D (transposed) row 4g + r = (dx, co0 + r), column m = pixel pair.  Outside the image = block_4_1's zero padding.
                 const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = ok ? s3p::act<NP>(acc[r]) : 0.f;
                 uint32_t pa[3], pb[3];
-                split_pair<NP>(v[0], v[1], pa);
-                split_pair<NP>(v[2], v[3], pb);
+                s3p::act_split<NP>(acc[0], acc[1], pa, ok);
+                s3p::act_split<NP>(acc[2], acc[3], pb, ok);
                 constexpr int JW = HW * j * 2 * XH * 16;     // bytes: HW image rows down
                 static_for<NP>([&](auto pc) {
                     constexpr int pl = decltype(pc)::value;
@@ -730,8 +724,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 const int iy = Ry0 + rrow, ix = Rx0 + rcol;
                 const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
                 uint32_t pa[3], pb[3];
-                split_pair<NP>(ok ? s3p::act<NP>(acc[0]) : 0.f, ok ? s3p::act<NP>(acc[1]) : 0.f, pa);
-                split_pair<NP>(ok ? s3p::act<NP>(acc[2]) : 0.f, ok ? s3p::act<NP>(acc[3]) : 0.f, pb);
+                s3p::act_split<NP>(acc[0], acc[1], pa, ok);
+                s3p::act_split<NP>(acc[2], acc[3], pb, ok);
                 const int e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0;
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&img[pl * PLANE + e]) = make_uint2(pa[pl], pb[pl]);
@@ -783,8 +777,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 waitF<0, NP>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
                 // D (transposed): row 4g + r = cout, column m = output pixel: 8 bytes (4 channels) per lane and plane
                 uint32_t pa[3], pb[3];
-                split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
-                split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
+                s3p::act_split<NP>(acc[0], acc[1], pa);
+                s3p::act_split<NP>(acc[2], acc[3], pb);
                 unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
                 if constexpr (DMA) {
 #pragma unroll

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void conv7_c2_s1_s3_kernel(const float* __rest
         for (int q = 0; q < 4; q++) {
             const int dx = q >> 1, c = q & 1;
             uint32_t pa[3], pb[3];
-            s3p::split_pair<NP>(s3p::act<NP>(acc[4 * q]), s3p::act<NP>(acc[4 * q + 1]), pa);
-            s3p::split_pair<NP>(s3p::act<NP>(acc[4 * q + 2]), s3p::act<NP>(acc[4 * q + 3]), pb);
+            s3p::act_split<NP>(acc[4 * q], acc[4 * q + 1], pa);
+            s3p::act_split<NP>(acc[4 * q + 2], acc[4 * q + 3], pb);
             const int u = ((c * 2 + hh) * 2 + prow) * 32 + 16 * (prow ^ dx) + pair;
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&st[(pl * 256 + u) * 4]) = make_uint2(pa[pl], pb[pl]);

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
             {
                 const int Y = ty0 + oy, X = tx0 + m;
                 uint32_t pa[3], pb[3];
-                s3p::split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
-                s3p::split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
+                s3p::act_split<NP>(acc[0], acc[1], pa);
+                s3p::act_split<NP>(acc[2], acc[3], pb);
                 if (Y < Ho && X < Wo) {
                     uint16_t* o = out16 + (((size_t)b * Ho + Y) * Wo + X) * 32 + nt * 16 + 4 * g;
 #pragma unroll
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
             // (forming whole 128-byte lines through LDS first, the four waves' quarters together, measured 0.1028 vs 0.1004 ms: not worth
             // the two extra barriers per tile)
             uint32_t pa[3], pb[3];
-            s3p::split_pair<NP>(s3p::act<NP>(acc[0]), s3p::act<NP>(acc[1]), pa);
-            s3p::split_pair<NP>(s3p::act<NP>(acc[2]), s3p::act<NP>(acc[3]), pb);
+            s3p::act_split<NP>(acc[0], acc[1], pa);
+            s3p::act_split<NP>(acc[2], acc[3], pb);
             uint16_t* o = ob + (size_t)(oy * Wo + ox) * 64;
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);

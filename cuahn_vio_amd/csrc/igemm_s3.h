@@ -144,13 +144,26 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
     const f16x2 h = {(_Float16)lo, (_Float16)hi};          // round to nearest even (v_cvt_pk_f16_f32 on gfx950)
     return __builtin_bit_cast(uint32_t, h);
 }
+// the two halves of a packed fp16 pair back to fp32: one instruction each (left to the compiler, the high half was re-converted from
+// the fp32 source with a second v_cvt_f16_f32 instead of being read from the packed register)
+__device__ __forceinline__ float cvt_f32_f16_lo(uint32_t packed) {
+    float f;
+    asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(f) : "v"(packed));
+    return f;
+}
+__device__ __forceinline__ float cvt_f32_f16_hi(uint32_t packed) {
+    float f;
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(packed));
+    return f;
+}
+typedef float f32x2_p __attribute__((ext_vector_type(2)));      // value pairs: v_pk_mul_f32 / v_pk_fma_f32
 template <int NP>
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
     if constexpr (NP == 2) {         // fp16 planes: value = A0 + A1 / 4096
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
         pl[0] = cvt_pk_f16(v0, v1);
-        const f16x2 h = __builtin_bit_cast(f16x2, pl[0]);
-        pl[1] = cvt_pk_f16((v0 - (float)h[0]) * S3_F16_SCALE, (v1 - (float)h[1]) * S3_F16_SCALE);
+        const f32x2_p v = {v0, v1}, h = {cvt_f32_f16_lo(pl[0]), cvt_f32_f16_hi(pl[0])};
+        const f32x2_p r = (v - h) * S3_F16_SCALE;
+        pl[1] = cvt_pk_f16(r[0], r[1]);
         return;
     }
     pl[0] = cvt_pk(v0, v1);
@@ -164,6 +177,27 @@ __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
 // LeakyReLU of an accumulator of mode NP (bias already inside, at the accumulator's scale)
 template <int NP> __device__ __forceinline__ float act(float acc) { return lrelu(s3_descale<NP>(acc)); }
+// two accumulator values of mode NP (bias inside) -> LeakyReLU -> the planes of the pair; `ok` = false writes zeros.
+// fp16 mode: the accumulator carries 4096 x the sum.  u = max(acc, 0.1 acc) at that scale, v = u / 4096 (exact), A0 = f16(v),
+// A1 = f16((v - A0) 4096) = f16(u - 4096 A0): bit for bit split_pair(act(acc0), act(acc1)) - scaling by a power of two commutes with the
+// rounding of the 0.1 multiple - in 11 vector instructions per pair instead of 18.
+template <int NP>
+__device__ __forceinline__ void act_split(float a0, float a1, uint32_t (&pl)[3], bool ok = true) {
+    if constexpr (NP == 2) {
+        f32x2_p u = {a0, a1};
+        const f32x2_p t = u * 0.1f;
+        u[0] = fmaxf(u[0], t[0]);
+        u[1] = fmaxf(u[1], t[1]);
+        if (!ok) u = f32x2_p{0.f, 0.f};
+        const f32x2_p v = u * S3_F16_INV;
+        pl[0] = cvt_pk_f16(v[0], v[1]);
+        const f32x2_p h = {cvt_f32_f16_lo(pl[0]), cvt_f32_f16_hi(pl[0])};
+        const f32x2_p r = u - h * S3_F16_SCALE;
+        pl[1] = cvt_pk_f16(r[0], r[1]);
+    } else {
+        split_pair<NP>(ok ? act<NP>(a0) : 0.f, ok ? act<NP>(a1) : 0.f, pl);
+    }
+}
 // one value -> its planes
 template <int NP>
 __device__ __forceinline__ void split1(float v, uint16_t& a, uint16_t& b, uint16_t& c) {
@@ -851,10 +885,11 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && !L::HAS_MASK, "DMA variant: 64-row multiples, no mask");
     constexpr int A_INST = BM / 64, B_INST = BN / 64;        // wave-instructions per wave, plane and stage (16 rows each)
-    static_assert(NP == 3 || (NP == 1 && MF == 16), "plain bf16 exists in the transposed 16x16x32 form");
-    constexpr int PER_STAGE = NP * (A_INST + B_INST);        // DMA instructions a wave issues per K-tile
+    static_assert(NP == 3 || MF == 16, "plain bf16 and the fp16 planes exist in the transposed 16x16x32 form");
+    constexpr int NW = s3_wplanes_gemm<NP>;                  // weight planes
+    constexpr int PER_STAGE = NP * A_INST + NW * B_INST;     // DMA instructions a wave issues per K-tile
     constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
-    constexpr int STAGE = NP * (TILE_A + TILE_B);            // bf16 elements per ring stage
+    constexpr int STAGE = NP * TILE_A + NW * TILE_B;         // 16-bit elements per ring stage
     constexpr int SMEM_ELEMS = NSTAGE * STAGE > 4 * 3 * 32 * 32 ? NSTAGE * STAGE : 4 * 3 * 32 * 32;
     __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
 
@@ -895,6 +930,11 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     for (int i = 0; i < TM16; i++)
 #pragma unroll
         for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+    f32x4_m16 acc16l[NP == 2 ? TM16 : 1][NP == 2 ? TN16 : 1];     // fp16 mode: the cross terms, scaled by 4096
+#pragma unroll
+    for (int i = 0; i < (NP == 2 ? TM16 : 1); i++)
+#pragma unroll
+        for (int j = 0; j < (NP == 2 ? TN16 : 1); j++) acc16l[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
 
     const int n_iter = (p.Kp + BK - 1) / BK;                 // no split-K in this variant
 
@@ -916,7 +956,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
         for (int i = 0; i < B_INST; i++) {
             const bool ok = wvalid[i] && (it * BK < p.Kp);   // Kp is a multiple of 8 and chunks never straddle it
 #pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
+            for (int pl = 0; pl < NW; pl++) {
                 const uint16_t* src = ok ? wsrc[i] + it * BK + pl * p.w_plane : p.zeros;
                 uint16_t* dst = sbase + NP * TILE_A + pl * TILE_B + (wave + 4 * i) * 16 * BK;
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
@@ -942,12 +982,15 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
+                for (int pl = 0; pl < NW; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
             }
 #pragma unroll
             for (int i = 0; i < TM16; i++)
 #pragma unroll
-                for (int j = 0; j < TN16; j++) acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                for (int j = 0; j < TN16; j++) {
+                    if constexpr (NP == 2) s3_mfma16_2acc(acc16[i][j], acc16l[i][j], bf[j], af[i]);
+                    else acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
+                }
             return;
         }
 #pragma unroll
@@ -996,7 +1039,13 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     __builtin_amdgcn_s_barrier();                            // all fragment reads done before the epilogue reuses the LDS
 
     if constexpr (MF == 16) {
-        s3_epilogue_m16<TM16, TN16, OUT32, NP>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int i = 0; i < TM16; i++)
+#pragma unroll
+                for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
+        }
+        s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
         return;
     }
     const int col = lane & 31, rbase = 4 * fh;

@@ -57,6 +57,12 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     if constexpr (NP == 2) {
         // fp16 planes: the lean kernel (the measured winner of the split-bf16 dispatch below) on every layer it covers, its 64-wide K tiles
         // where a tap holds >= 64 channels; the register-staged kernel in its 16x16x32 form for the rest (ragged operator-level shapes)
+        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
+            if (p.tile == 7 && split == 1 && p.zeros) {      // experiment: LDS-DMA ring for the 32-channel layers (HNET_PATCH32=0 routes them here)
+                hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, NP>), grid, dim3(256), 0, s, p);
+                return hipGetLastError();
+            }
+        }
         if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
             if constexpr (L::template lean_ok<64>()) {
                 hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
