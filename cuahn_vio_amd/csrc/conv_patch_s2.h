@@ -41,7 +41,7 @@ typedef float f32x4_p __attribute__((ext_vector_type(4)));
 typedef short bf16x4_p __attribute__((ext_vector_type(4)));
 
 // in: S3 planes [3][B][H][W][16];  wfrag: [2 halves of cout][NSTEP][3][64 lanes] x 16 B;  out16: [3][B][H/2][W/2][32]
-template <int KS, int NP, bool B128 = false>
+template <int KS, int NP, bool B128 = false, int RB5 = 1>
 __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* __restrict__ in, size_t i_plane,
                                                             const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
                                                             uint16_t* __restrict__ out16, size_t o_plane, int H, int W,
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_s2_kernel(const uint16_t* _
     const int second = 4 - 8 * (g & 1);                         // element offset from the first to the second 8-byte read
     // staging items of one region row: (plane, column, channel half), NP*RW*2 of them, ITEMS per lane
     constexpr int ROW_ITEMS = NP * RW * 2, ITEMS = (ROW_ITEMS + 63) / 64;
-    constexpr int RB = KS == 5 ? 1 : 5;                         // region rows loaded per batch (register budget)
+    constexpr int RB = KS == 5 ? RB5 : 5;                       // region rows loaded per batch (register budget: RB5 = 1 in split-bf16)
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // reverse: walk the tiles from the end of the batch.  The producer wrote this 440 MB input front to back and the

@@ -96,6 +96,7 @@ struct hnet_ctx {
     int n_planes = 3;                  // 16-bit planes the matrix-core layers read and write = their arithmetic mode: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16), 2 = fp16 planes (HNET_PREC_F16X2, fp32-grade)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
     bool use_patch = false;
+    int patch_rb5 = 5;                 // HNET_PATCH_RB5: region rows per batch of staging loads in the 5x5 patch kernel (1 / 2 / as many as fit: 5 in the fp16 mode, 3 in split-bf16)
     int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
@@ -339,7 +340,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             else if (c->s3 && c->use_region5 && conv_is_region5_layer(l) && h == (l == 1 ? 14 : 28) && w == (l == 1 ? 20 : 40))
                 STAGE(launch_conv5_region(l, in16, in_plane, B, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
-                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128));
+                STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128, c->patch_rb5));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
                                      c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes, c->s3_tile));
@@ -676,6 +677,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
     c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
+    c->patch_rb5 = getenv("HNET_PATCH_RB5") ? atoi(getenv("HNET_PATCH_RB5")) : 5;     // measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
     c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
     c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
@@ -1282,7 +1284,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
             HIPCHK(c, launch_conv5_region(layer, p_in, n_in, batch, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
         } else if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
-            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128));
+            HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128, c->patch_rb5));
         } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),

@@ -38,7 +38,8 @@ bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s
 bool conv_is_patch32_layer(int layer);    // block_3_2 / block_4_3 at their network size 56x80 (conv_patch32_s2_kernel); same launcher, wfrag [4][9][3][64] x 16 B
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
                              const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes = 3,
-                             bool b128 = false /* block_3_1 / block_4_2: interleaved-half region layout + ds_read_b128 (wfrag packed without the odd-group rotation) */);
+                             bool b128 = false /* block_3_1 / block_4_2: interleaved-half region layout + ds_read_b128 (wfrag packed without the odd-group rotation) */,
+                             int rb5 = 1 /* 5x5 kernel, fp16 mode: region rows staged per batch of loads (1, 2 or 5) */);
 hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 int h, int w, hipStream_t s, int n_planes = 3);
 // block_1_1 (layer 0) / block_2_1 (layer 3): 7x7 stride 2, Cin 2, fp32 [B][h][w][2] in -> S3 planes out (conv_first.h)

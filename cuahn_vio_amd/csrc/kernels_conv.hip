@@ -169,8 +169,8 @@ hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, in
 }
 
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
-                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes, bool b128) {
-    return HNET_NP(launch_conv_patch_np, layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128);
+                             const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, int n_planes, bool b128, int rb5) {
+    return HNET_NP(launch_conv_patch_np, layer, in, i_plane, batch, h, w, wfrag, bias, out16, o_plane, s, b128, rb5);
 }
 
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,

@@ -244,7 +244,7 @@ hipError_t launch_conv_first_s2_np(int layer, const float* x_in, const void* wfr
 // block_3_1 (5x5) / block_4_2 (3x3): 16 -> 32 channels, stride 2, from an LDS-resident patch (conv_patch_s2.h)
 template <int KS, int NP>
 static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfrag, const float* bias, uint16_t* out16,
-                            size_t o_plane, int batch, int h, int w, hipStream_t s, bool b128) {
+                            size_t o_plane, int batch, int h, int w, hipStream_t s, bool b128, int rb5) {
     typedef PatchS2Cfg<KS, NP> C;
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
@@ -252,6 +252,19 @@ static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfra
     // bit 0: reverse the 5x5 kernel (block_3_1), bit 1: reverse the 3x3 kernel (block_4_2)
     static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
     const int r = KS == 5 ? (rev & 1) : ((rev >> 1) & 1);
+    if constexpr (KS == 5 && NP != 1) {      // more region rows per batch of staging loads (HNET_PATCH_RB5): the staging was latency bound
+        constexpr int RBMAX = NP == 2 ? 5 : 3;   // what fits the 256 registers next to the 156 weight registers
+        if (b128 && rb5 >= RBMAX) {
+            hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true, RBMAX>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
+                               out16, o_plane, h, w, n_tiles, r);
+            return hipGetLastError();
+        }
+        if (b128 && rb5 >= 2) {
+            hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true, 2>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
+                               out16, o_plane, h, w, n_tiles, r);
+            return hipGetLastError();
+        }
+    }
     if (b128)
         hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
                            out16, o_plane, h, w, n_tiles, r);
@@ -263,9 +276,9 @@ static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfra
 
 template <int NP>
 hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
-                                const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, bool b128) {
-    if (layer == 8) return run_patch<5, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s, b128);
-    if (layer == 15) return run_patch<3, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s, b128);
+                                const float* bias, uint16_t* out16, size_t o_plane, hipStream_t s, bool b128, int rb5) {
+    if (layer == 8) return run_patch<5, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s, b128, rb5);
+    if (layer == 15) return run_patch<3, NP>(in, i_plane, wfrag, bias, out16, o_plane, batch, h, w, s, b128, rb5);
     if ((layer == 9 || layer == 16) && h == 56 && w == 80) {     // block_3_2 / block_4_3
         typedef Patch32Cfg<NP> C;
         const int n_tiles = batch * (28 / C::TH) * (40 / C::TW);
@@ -366,6 +379,10 @@ hipError_t conv_kernels_init_device_np() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
+    if constexpr (NP != 1) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true, (NP == 2 ? 5 : 3)>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
+    }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<128, 14, 20, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<128, 14, 20, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<64, 28, 40, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<64, 28, 40, NP>::LDS_BYTES);
@@ -380,7 +397,7 @@ hipError_t conv_kernels_init_device_np() {
     KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv5_region_np<NP>(int, const uint16_t*, size_t, int, const void*, const float*, uint16_t*, size_t, hipStream_t); \
     KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
-                                                    size_t, hipStream_t, bool);                                                                \
+                                                    size_t, hipStream_t, bool, int);                                                           \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \
                                                       const float*, float*, uint16_t*, size_t, uint8_t*, hipStream_t, float*, size_t,    \
                                                       const uint64_t*, int);                                                             \
