@@ -59,7 +59,7 @@ fe, wr = one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collect
 if fe and wr:
     f, w = per_kernel_max(fe, "FETCH_SIZE"), per_kernel_max(wr, "WRITE_SIZE")
     with open(os.path.join(dst, tag + "_pmc_hbm_traffic.csv"), "w") as out:
-        out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) of `python3 bench.py --steps 2 --warmup 1`, batch 256, bf16x3 path.\n")
+        out.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) of `python3 bench.py --steps 2 --warmup 1`, batch 256, default arithmetic mode of that build.\n")
         out.write("# Values are per launch at batch 256 (max over launches: the batch-1 warm-up launch of hnet_create is excluded). Raw counter values in KiB;\n")
         out.write("# gfx950 correction (MI355X_MICROARCH.md §HBM, re-calibrated for the access shapes of these kernels with tools/traffic_calib.hip on known\n")
         out.write("# byte counts - profiles/r02_traffic_calibration.log): FETCH_SIZE reports exactly half the bytes for 16-, 8- and 4-byte-per-lane loads and for\n")
