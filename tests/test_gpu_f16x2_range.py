@@ -63,3 +63,37 @@ def test_weights_beyond_the_fp16_plane_range_select_bf16x3_at_create(state):
     mean, _ = e.infer_batch(i1[None], i2[None], None)
     assert np.isfinite(mean).all()
     e.close()
+
+
+@pytest.mark.parametrize("seed,conv_gain", [(1, 1.0), (2, 4.0), (3, 0.5)])
+def test_other_weight_sets_stay_at_fp32_level(seed, conv_gain):
+    """the golden cases all use one weight set; here other seeds, and convolution weights scaled up (activations of O(10^3)) and down
+    (features of O(0.1), first-plane residuals in the fp16 subnormal range unless scaled) - both matrix-core fp32-grade modes
+    against the oracle's double accumulation, and against each other"""
+    from conftest import TOL_PX_VS_ORACLE
+    from cuahn_vio_amd import weights
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from oracle import pyoracle
+    st = weights.synthetic_state(seed)
+    if conv_gain != 1.0:                       # scale the trunk of every block; the FC layers see the scaled features and scale the offsets back
+        for k in st:
+            if ".block_" in k and k.endswith(".0.weight"):
+                st[k] = (st[k] * np.float32(conv_gain)).astype(np.float32)
+        # keep the corner offsets at O(1-10) px: undo the gain of the 3 / 7 convolutions in front of each offset FC
+        for k in st:
+            if "fc_block_" in k and k.endswith("weight") and st[k].shape[-1] == 5120:
+                depth = 7 if "model_last_block_list" in k else (3 if "fc_block_1" in k else (4 if "fc_block_2" in k else 6))
+                st[k] = (st[k] / np.float32(conv_gain) ** depth).astype(np.float32)
+    blob = weights.pack_state_dict(st)
+    i1, i2 = _pair(10 + seed)
+    ref = pyoracle.Oracle(blob).forward(i1, i2, n_mc=4, p=0.05, mc_seed=3, pair_seq=0)
+    got = {}
+    for prec in (PREC_F16X2, PREC_BF16X3):
+        e = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=3, max_batch=1, precision=prec)
+        got[prec], _ = e.infer_batch(i1[None], i2[None], None)
+        assert e.precision() == prec
+        e.close()
+        d = float(np.abs(got[prec][0] - ref["mean"]).max())
+        print(f"seed {seed} gain {conv_gain} precision {prec}: |hip - oracle| = {d:.2e} px, offsets up to {np.abs(ref['mean']).max():.1f} px")
+        assert d < TOL_PX_VS_ORACLE
+    assert float(np.abs(got[PREC_F16X2] - got[PREC_BF16X3]).max()) < 1e-4
