@@ -39,13 +39,40 @@ __device__ inline void fill_lut(float* lut) {
 //   image contribute 0.  fp32 throughout like the reference; fp32 division is IEEE (hipcc default).
 // sampling position of output pixel (u, v) in img2, in pixels: the normalise / un-normalise round trip of
 // grid_sample(align_corners=True) is kept (it is not the identity in fp32)
+// X / Z and Y / Z share their denominator.  hipcc expands an IEEE fp32 division into v_div_scale x 2, v_rcp, five FMAs, v_div_fmas and
+// v_div_fixup; when the operands are far from the ends of the exponent range (no scaling: the case of a homography's Z ~ 1) that is the FMA
+// chain below, whose first three steps depend on Z only.  tools/div_pair_check.hip: 2^32 operand pairs, every quotient bit-identical to
+// x / z.  ZSAFE says |Z| is known to lie in [2^-60, 2^60] (the tiled kernel proves it once per tile from the tile's corners: Z is affine
+// in the pixel position); otherwise the test is made here and the compiler's division used outside the range.  Where the two forms
+// could differ at all - quotients that are denormal or overflow - the sampled value does not depend on the quotient's low bits (the
+// coordinate is then -1 after the normalisation, or the tap is outside the image).
+__device__ __forceinline__ float warp_rcp_refined(float z) {
+    const float r = __builtin_amdgcn_rcpf(z);
+    return fmaf(fmaf(-z, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float warp_div_with(float x, float z, float r1) {
+    const float m = x * r1;
+    const float f3 = fmaf(fmaf(-z, m, x), r1, m);
+    return fmaf(fmaf(-z, f3, x), r1, f3);
+}
+__device__ __forceinline__ bool warp_z_safe(float Z) { return fabsf(Z) > 8.7e-19f && fabsf(Z) < 1.15e18f; }     // 2^-60 .. 2^60; false for NaN
+template <bool ZSAFE = false>
 __device__ inline void warp_coords(const float* h, int u, int v, float& ix, float& iy, float& Z) {
     const float fu = (float)u, fv = (float)v;
     const float X = fmaf(h[0], fu, fmaf(h[1], fv, h[2]));
     const float Y = fmaf(h[3], fu, fmaf(h[4], fv, h[5]));
     Z = fmaf(h[6], fu, fmaf(h[7], fv, h[8]));
-    const float gx = (X / Z) * (float)(2.0 / (IMG_W - 1)) - 1.0f;
-    const float gy = (Y / Z) * (float)(2.0 / (IMG_H - 1)) - 1.0f;
+    float qx, qy;
+    if (ZSAFE || warp_z_safe(Z)) {
+        const float r1 = warp_rcp_refined(Z);
+        qx = warp_div_with(X, Z, r1);
+        qy = warp_div_with(Y, Z, r1);
+    } else {
+        qx = X / Z;
+        qy = Y / Z;
+    }
+    const float gx = qx * (float)(2.0 / (IMG_W - 1)) - 1.0f;
+    const float gy = qy * (float)(2.0 / (IMG_H - 1)) - 1.0f;
     ix = ((gx + 1.0f) * 0.5f) * (float)(IMG_W - 1);
     iy = ((gy + 1.0f) * 0.5f) * (float)(IMG_H - 1);
 }
@@ -108,24 +135,26 @@ template <> __device__ __forceinline__ float4 load_px4<uint8_t>(const uint8_t* p
 }
 template <> __device__ __forceinline__ float4 load_px4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-struct WarpBox { int gx0, ry0, pitch, rows; bool ok; };
+struct WarpBox { int gx0, ry0, pitch, rows; bool ok; bool zsafe; };
 
 template <typename PIX>
 __device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const float* h, int u0, int v0, float* __restrict__ reg) {
     WarpBox bx;
     float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
-    bool pos = true, neg = true, finite = true;
+    bool pos = true, neg = true, finite = true, zs = true;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float ix, iy, Z;
         warp_coords(h, u0 + (c & 1) * (WT_W - 1), v0 + (c >> 1) * (WT_H - 1), ix, iy, Z);
         pos = pos && Z > 0.0f;
         neg = neg && Z < 0.0f;
+        zs = zs && warp_z_safe(Z);
         finite = finite && fabsf(ix) < 1.0e6f && fabsf(iy) < 1.0e6f;      // false for NaN
         lo_x = fminf(lo_x, ix); hi_x = fmaxf(hi_x, ix);
         lo_y = fminf(lo_y, iy); hi_y = fmaxf(hi_y, iy);
     }
     bx.ok = (pos || neg) && finite;
+    bx.zsafe = (pos || neg) && zs;        // Z is affine in (u, v) and keeps its sign over the tile: |Z| inside the tile lies between the corners' values
     // taps of pixels that survive the far-out test lie in [-1, W] x [-1, H] (+1): clip the box to that frame
     const int rx0 = max((int)floorf(bx.ok ? lo_x : 0.0f) - 1, -1), rx1 = min((int)floorf(bx.ok ? hi_x : 0.0f) + 2, IMG_W + 1);
     const int ry0 = max((int)floorf(bx.ok ? lo_y : 0.0f) - 1, -1), ry1 = min((int)floorf(bx.ok ? hi_y : 0.0f) + 2, IMG_H + 1);
@@ -154,10 +183,11 @@ __device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const floa
 // pixels of a thread are independent instruction streams the scheduler can interleave (with a branch per pixel the
 // LDS and v_rcp latencies of each pixel were exposed one after the other).  `fallback` is set when the pixel has
 // taps outside the staged box (or the tile has no box); the caller then recomputes it with warp_taps_global.
+template <bool ZSAFE>
 __device__ __forceinline__ float warp_sample_box(const float* h, int u, int v, const WarpBox& bx, const float* reg, bool& fallback,
                                                  float& ix, float& iy) {
     float Z;
-    warp_coords(h, u, v, ix, iy, Z);
+    warp_coords<ZSAFE>(h, u, v, ix, iy, Z);
     const float x0f = floorf(ix), y0f = floorf(iy);
     const bool near = x0f >= -1.0f && x0f <= (float)IMG_W && y0f >= -1.0f && y0f <= (float)IMG_H;   // false for NaN
     const int cx = (int)(near ? x0f : 0.0f) - bx.gx0, cy = (int)(near ? y0f : 0.0f) - bx.ry0;
@@ -212,12 +242,22 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     const int u = u0 + lane;
     float a[8], w[8], fx[8], fy[8];
     uint32_t fb = 0;
+    if (bx.zsafe) {                                                     // workgroup-uniform: the shared-reciprocal division without its range test
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        bool f;
-        a[i] = a1[r0 + i][lane];
-        w[i] = warp_sample_box(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
-        fb |= (uint32_t)f << i;
+        for (int i = 0; i < 8; i++) {
+            bool f;
+            a[i] = a1[r0 + i][lane];
+            w[i] = warp_sample_box<true>(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
+            fb |= (uint32_t)f << i;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            bool f;
+            a[i] = a1[r0 + i][lane];
+            w[i] = warp_sample_box<false>(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
+            fb |= (uint32_t)f << i;
+        }
     }
     if (__builtin_expect(__any(fb != 0), 0)) {                          // rare: taps outside the staged box -> direct gathers
 #pragma unroll
