@@ -314,14 +314,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
     constexpr int HO = IMG_H / K, WO = IMG_W / K;
     constexpr int RPL = K >= 2 ? 2 : 1;          // window rows per lane: 2K independent samples in flight per lane
     constexpr int G = K / RPL;                   // lanes per output pixel
-    const long total = (long)batch * HO * WO * G;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // 32-bit index arithmetic (the launcher refuses batches whose pixel count does not fit): 64-bit divisions by HO * WO are ~20 instructions
+    const uint32_t total = (uint32_t)batch * HO * WO * G;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = idx < total;
-    const long ii = active ? idx : 0;
+    const uint32_t ii = active ? idx : 0u;
     const int j = (int)(ii % G);
-    const long opix = ii / G;
-    const int b = (int)(opix / (HO * WO));
-    const int rem = (int)(opix - (long)b * HO * WO);
+    const uint32_t opix = ii / G;
+    const int b = (int)(opix / (uint32_t)(HO * WO));
+    const int rem = (int)(opix - (uint32_t)b * (HO * WO));
     const int oy = rem / WO, ox = rem - oy * WO;
     const PIX* i1 = img1 + (size_t)b * NPIX;
     const PIX* i2 = img2 + (size_t)b * NPIX;
@@ -461,6 +462,7 @@ static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, in
         return hipGetLastError();
     }
     const long total = (long)batch * NPIX / k / (k >= 2 ? 2 : 1);   // (224/k)*(320/k) outputs x k/2 lanes each
+    if (total + 256 >= (1l << 32)) return hipErrorInvalidValue;     // prep_kernel indexes in 32 bits (batch < ~59 000 pairs)
     const int blocks = (int)((total + 255) / 256);
 #define HNET_PREP(KK)                                                                                     \
     if (H) hipLaunchKernelGGL((prep_kernel<PIX, KK, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, batch); \
