@@ -660,12 +660,18 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
     const int nc = min(FC2_CHUNK, n_local - c0);
     const int tid = threadIdx.x;
     for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
-    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
+    // the hash prefix of a (sample, head) row - four hnet_mix32 - once per row, not once per element
+    __shared__ uint32_t pre_row[FC2_CHUNK * 2];
+    if (tid < FC2_CHUNK * 2) {
+        const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
+        pre_row[tid] = hnet_mask_prefix(key, (uint32_t)(2 * (tid & 1) + 1), (uint32_t)(s_begin + c0 + (tid >> 1)));
+    }
+    __syncthreads();
     for (int i = tid; i < FC2_CHUNK * 512; i += 256) {
         const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
         float v = 0.0f;
         if (sl < nc) {
-            const uint32_t pre = hnet_mask_prefix(key, (uint32_t)(2 * head + 1), (uint32_t)(s_begin + c0 + sl));
+            const uint32_t pre = pre_row[sl * 2 + head];
             const float x = hidden[((size_t)b * n_local + c0 + sl) * 512 + col];
             v = hnet_mask_keep(pre, (uint32_t)j, thr) ? x * scale : 0.0f;
         }
