@@ -535,7 +535,7 @@ def main():
                            "mfma_per_mac": mfma_per_mac if pk == peak_tf else 1,
                            "fp32_equivalent_tflops": round(alg / (ms[k] * 1e-3) / 1e12, 2),
                            "note": ("three fp16 MFMAs per multiply-accumulate (two fp16 planes per value); the same kernel issues six bf16 MFMAs per MAC in "
-                                    "--precision bf16x3 and reaches 0.39-0.40 of the peak there at 0.72x the throughput (profiles/r02_v13_bench_bf16x3.json)"
+                                    "--precision bf16x3 and reaches 0.39-0.40 of the peak there at 0.72x the throughput (profiles/r02_v15_bench_bf16x3.json)"
                                     if args.precision == "f16x2" else None),
                            "peak_of": ("dense fp16 MFMA (v_mfma_f32_16x16x32_f16; same rate as bf16)" if args.precision == "f16x2" else
                                        "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)") if pk == PEAK_BF16_MFMA_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
