@@ -15,8 +15,9 @@ def _pair(seed):
     return i1, i2
 
 
-def test_default_is_f16x2_and_stays_there_on_ordinary_input(blob):
+def test_default_is_f16x2_and_stays_there_on_ordinary_input(blob, monkeypatch):
     from cuahn_vio_amd.homography_net import HnetEngine
+    monkeypatch.delenv("HNET_PRECISION", raising=False)       # the library default, not the environment's choice
     i1, i2 = _pair(3)
     e = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=2)
     assert e.precision() == PREC_F16X2
