@@ -65,7 +65,7 @@ public:
         cfg.mc_samples = env_int("HNET_MC_SAMPLES", 16);
         cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", 0.05);
         cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);
-        cfg.precision = env_int("HNET_PRECISION", cfg.precision);      // HNET_PREC_FP32 (0) or HNET_PREC_BF16X3 (2)
+        cfg.precision = env_int("HNET_PRECISION", cfg.precision);      // HNET_PREC_F16X2 (3, default), HNET_PREC_BF16X3 (2), HNET_PREC_FP32 (0), HNET_PREC_BF16 (1)
         cfg.emit_error_map = show_phtometric_error ? 1 : 0;
         cfg.max_batch = 1;
         std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());

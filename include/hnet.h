@@ -65,7 +65,7 @@ typedef struct hnet_config {
     float    dropout_p;        /* drop probability (reference 0.05); 0 = deterministic */
     uint64_t mc_seed;          /* key of the mask function, include/hnet_rng.h */
     int32_t  emit_error_map;   /* 1: "_showError" variant, the photometric error map is computed */
-    int32_t  precision;        /* HNET_PREC_*; hnet_default_config: HNET_PREC_BF16X3 */
+    int32_t  precision;        /* HNET_PREC_*; hnet_default_config: HNET_PREC_F16X2 */
     int32_t  max_batch;        /* capacity (frame pairs) of the persistent activation buffers, >= 1 */
     int32_t  mc_sample_begin;  /* this context evaluates global samples [begin, end) in the *_partial entry points; */
     int32_t  mc_sample_end;    /* 0,0 = all */

@@ -1,5 +1,6 @@
 """Image pre-processing ahead of load_current_img: map construction and the remap kernel.
-Parity is pinned against the numpy restatement oracle/undistort_oracle.py only (OpenCV is not available, see its header)."""
+The kernel is bit-exact against the numpy restatement oracle/undistort_oracle.py; parity with cv::remap itself cannot be pinned here (OpenCV is
+absent from the image): the deviation class is stated in include/hnet.h, and an end-to-end distort -> undistort property test bounds it."""
 import numpy as np
 import pytest
 
