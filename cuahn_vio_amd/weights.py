@@ -126,6 +126,24 @@ def synthetic_state(seed: int = 0, offset_gain: float = 30.0, offset_bias: float
     return state
 
 
+def variant_state(seed: int = 0, conv_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """synthetic_state(seed) with every trunk convolution scaled by `conv_gain` (activations of O(gain^depth)) and the
+    5120-input FC layers scaled back so the corner offsets stay at O(1-10) px.  gain 4 drives activations to O(10^3),
+    gain 0.5 drives the features to O(0.1): the two ends of the fp16-plane format's range that the golden vectors pin
+    (tools/gen_golden.py `weights_seed` / `conv_gain`)."""
+    st = synthetic_state(seed)
+    if conv_gain != 1.0:
+        g = np.float32(conv_gain)
+        for k in st:
+            if ".block_" in k and k.endswith(".0.weight"):
+                st[k] = (st[k] * g).astype(np.float32)
+        for k in st:      # undo the gain of the 3 / 4 / 6 / 7 convolutions in front of each 5120-input FC
+            if "fc_block_" in k and k.endswith("weight") and st[k].shape[-1] == 5120:
+                depth = 7 if "model_last_block_list" in k else (3 if "fc_block_1" in k else (4 if "fc_block_2" in k else 6))
+                st[k] = (st[k] / g ** depth).astype(np.float32)
+    return st
+
+
 def pack_state_dict(state) -> bytes:
     """Serialise a name->array mapping (reference state_dict layouts) into the HNETW001 blob.
     Accepts numpy arrays or anything with ``.numpy()`` / ``.detach()`` (torch tensors)."""

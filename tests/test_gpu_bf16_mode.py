@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_case
+from conftest import case_weights, golden_cases, load_case
 
 pytestmark = pytest.mark.gpu
 PREC_BF16 = 1
@@ -81,6 +81,7 @@ def test_bf16_forward_error_is_reported(blob, oracle, name):
     bounded only loosely (a broken kernel gives O(10) px)"""
     from cuahn_vio_amd.homography_net import HnetEngine
     g, i1, i2, prior, btr = load_case(name)
+    blob = case_weights(g)[1]
     eng = HnetEngine(blob, variant=str(g["variant"]), mc_samples=int(g["n_mc"]), dropout_p=float(g["p"]),
                      mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0, max_batch=1, precision=PREC_BF16)
     seq = int(g["pair_seq"]) if "pair_seq" in g else 0

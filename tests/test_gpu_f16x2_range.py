@@ -75,16 +75,7 @@ def test_other_weight_sets_stay_at_fp32_level(seed, conv_gain):
     from cuahn_vio_amd import weights
     from cuahn_vio_amd.homography_net import HnetEngine
     from oracle import pyoracle
-    st = weights.synthetic_state(seed)
-    if conv_gain != 1.0:                       # scale the trunk of every block; the FC layers see the scaled features and scale the offsets back
-        for k in st:
-            if ".block_" in k and k.endswith(".0.weight"):
-                st[k] = (st[k] * np.float32(conv_gain)).astype(np.float32)
-        # keep the corner offsets at O(1-10) px: undo the gain of the 3 / 7 convolutions in front of each offset FC
-        for k in st:
-            if "fc_block_" in k and k.endswith("weight") and st[k].shape[-1] == 5120:
-                depth = 7 if "model_last_block_list" in k else (3 if "fc_block_1" in k else (4 if "fc_block_2" in k else 6))
-                st[k] = (st[k] / np.float32(conv_gain) ** depth).astype(np.float32)
+    st = weights.variant_state(seed, conv_gain)
     blob = weights.pack_state_dict(st)
     i1, i2 = _pair(10 + seed)
     ref = pyoracle.Oracle(blob).forward(i1, i2, n_mc=4, p=0.05, mc_seed=3, pair_seq=0)

@@ -6,8 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (GOLDEN_DIR, TOL_COV_REL, TOL_PX_VS_ORACLE, TOL_PX_VS_REF32, TOL_PX_VS_REF64, golden_cases,
-                      load_case)
+from conftest import (GOLDEN_DIR, TOL_COV_REL, TOL_PX_VS_ORACLE, TOL_PX_VS_REF32, TOL_PX_VS_REF64, case_oracle, case_weights,
+                      golden_cases, load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -184,6 +184,7 @@ def test_op_conv_small_ragged_shapes(eng_full, state):
 @pytest.mark.parametrize("name", golden_cases())
 def test_forward_golden(blob, oracle, name, precision):
     g, i1, i2, prior, btr = load_case(name)
+    blob, oracle = case_weights(g)[1], case_oracle(g)      # the weight set of the case (seed 0 unless the case says otherwise)
     eng = _engine_for(blob, g, precision=precision)
     seq = int(g["pair_seq"]) if "pair_seq" in g else 0
     mean, cov, err = eng.infer_batch(i1[None], i2[None], None if prior is None else prior[None], pair_seq0=seq, want_err=True)
@@ -201,7 +202,10 @@ def test_forward_golden(blob, oracle, name, precision):
                 f.write("case,precision,abs_err_vs_ref_fp32_px,abs_err_vs_ref_fp64_px,abs_err_vs_oracle_px,cov_rel_err_vs_ref_fp64\n")
             f.write(f"{name},{ {0: 'fp32', 1: 'bf16', 2: 'bf16x3', 3: 'f16x2'}[precision]},{d32:.3e},{d64:.3e},{dor:.3e},"
                     f"{np.abs(cov[0] - g['cov64']).max() / np.abs(g['cov64']).max():.3e}\n")
-    assert d32 < TOL_PX_VS_REF32 and d64 < TOL_PX_VS_REF64 and dor < TOL_PX_VS_ORACLE
+    # vs the fp32 golden: the reference's own fp32 run sits |mean - mean64| from its fp64 evaluation (up to 2.7e-4 px on these cases);
+    # the gate that binds is the fp64 one (north_star's 1e-4 px), the fp32 one is that plus the case's own fp32 noise
+    floor32 = float(np.abs(g["mean"] - g["mean64"]).max())
+    assert d32 < max(TOL_PX_VS_REF32, floor32 + TOL_PX_VS_REF64) and d64 < TOL_PX_VS_REF64 and dor < TOL_PX_VS_ORACLE
     for ref in (g["cov"], g["cov64"], o["cov"]):
         assert np.abs(cov[0] - ref).max() / np.abs(ref).max() < TOL_COV_REL
     assert np.abs(eng.debug_h_part1(0) - g["H_part1_64"]).max() < 2e-5

@@ -5,12 +5,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, TOL_COV_REL, golden_cases, load_case
+from conftest import GOLDEN_DIR, TOL_COV_REL, case_oracle, case_weights, golden_cases, load_case
 from oracle import pyoracle
 
 
-def _run(orc, name):
+def _run(orc, name, f32=False):
     g, i1, i2, prior, btr = load_case(name)
+    orc = case_oracle(g, f32)          # the oracle on the weight set the case was generated on (seed 0 for the round-1 cases)
     o = orc.forward(i1, i2, prior, btr, int(g["n_mc"]), float(g["p"]),
                     int(g["mc_seed"]) if "mc_seed" in g else 0, int(g["pair_seq"]) if "pair_seq" in g else 0,
                     want_err=True, want_trace=True)
@@ -23,7 +24,8 @@ def test_oracle_matches_reference(oracle, name):
     # offsets: the double-accumulating oracle tracks the reference's fp64 evaluation; the fp32 golden sits
     # up to 1.4e-4 px from that (tools/gen_golden.py prints the floor)
     assert np.abs(o["mean"] - g["mean64"]).max() < 1e-4
-    assert np.abs(o["mean"] - g["mean"]).max() < 2e-4
+    # (per case: |mean - mean64| is stored in the vector; 2.7e-4 px on the seed-1 weight set)
+    assert np.abs(o["mean"] - g["mean"]).max() < max(2e-4, float(np.abs(g["mean"] - g["mean64"]).max()) + 1e-4)
     assert np.abs(o["cov"] - g["cov64"]).max() / np.abs(g["cov64"]).max() < TOL_COV_REL
     assert np.abs(o["cov"] - g["cov"]).max() / np.abs(g["cov"]).max() < TOL_COV_REL
     # block-diagonal structure, symmetric (model_to_trace.py:313-317)
@@ -57,7 +59,7 @@ def test_oracle_matches_reference(oracle, name):
 @pytest.mark.parametrize("name", ["full_p0_s1", "prior3_mask16_s10", "const_prior10"])
 def test_oracle_f32_build_matches_reference(oracle_f32, name):
     """the plain-fp32 build (the timed CPU port) stays within the reference's own fp32 noise"""
-    g, o = _run(oracle_f32, name)
+    g, o = _run(oracle_f32, name, f32=True)
     assert np.abs(o["mean"] - g["mean"]).max() < 4e-4
     assert np.abs(o["cov"] - g["cov"]).max() / np.abs(g["cov"]).max() < 1e-4
 
@@ -71,10 +73,12 @@ def test_libtorch_cpu_restatement_matches_reference(state, name):
     import torch
     from oracle.torch_cpu import TorchCpuNet
     g, i1, i2, prior, btr = load_case(name)
+    state = case_weights(g)[0]
     kw = dict(n_mc=int(g["n_mc"]), p=float(g["p"]), mc_seed=int(g["mc_seed"]) if "mc_seed" in g else 0,
               pair_seq=int(g["pair_seq"]) if "pair_seq" in g else 0, want_err=True)
     o64 = TorchCpuNet(state, torch.float64).forward(i1, i2, prior, btr, **kw)
-    assert np.abs(o64["mean"] - g["mean64"]).max() < 2e-6
+    # (the restatement returns float32 outputs: offsets of 175 px, as on the trajectory pairs, carry 8e-6 px of output rounding)
+    assert np.abs(o64["mean"] - g["mean64"]).max() < max(2e-6, 1.2e-7 * float(np.abs(g["mean64"]).max()))
     assert np.abs(o64["cov"] - g["cov64"]).max() / np.abs(g["cov64"]).max() < 1e-6
     assert np.abs(o64["H_part1"] - g["H_part1_64"]).max() < 1e-6
     o32 = TorchCpuNet(state).forward(i1, i2, prior, btr, **kw)
