@@ -25,7 +25,7 @@ SYMBOLS = [
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
-    "hnet_op_block4_fused", "hnet_precision",
+    "hnet_op_block4_fused", "hnet_precision", "hnet_overflow_flag",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
     L.hnet_infer_mc_partial_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]
     L.hnet_mc_finish_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hnet_synchronize.argtypes = [vp, vp]
+    L.hnet_overflow_flag.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.hnet_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.hnet_time_batch_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_uint64, vp, vp, C.c_int, fp, fp]
     L.hnet_stage_count.argtypes = [vp]

@@ -142,6 +142,7 @@ struct hnet_ctx {
     bool use_graph = false;            // hnet_infer replays the forward as one hipGraph (default on; HNET_GRAPH=0: eager launches)
     bool graph_timing = false;         // hnet_time_batch_device too (HNET_GRAPH=1 only: the bare device time is 3 % better eager)
     uint64_t* d_seq = nullptr;
+    uint32_t* d_flag = nullptr;        // hnet_overflow_flag: bit 0 = a forward produced a non-finite output since the last poll
     struct Pinned { uint64_t seq; float prior[8]; float mean[8]; float cov[64]; uint8_t err[HNET_IMG_ROWS * HNET_IMG_COLS]; };
     Pinned* pinned = nullptr;
     uint8_t* pinned_img[2] = {nullptr, nullptr};         // host staging of the pushed frame, one per ring slot
@@ -365,7 +366,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
     if (a.partial) {
         STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2,
-                               a.mean_s, a.logvar_s, s, a.seq_dev));
+                               a.mean_s, a.logvar_s, s, a.seq_dev, c->d_flag));
         if (a.h_part1) {
             hipError_t e = hipMemcpyAsync(a.h_part1, Hm, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return fail(c, HNET_ERR_DEVICE, "copy H_part1");
@@ -375,7 +376,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     float* ms = c->mean_s + P0 * c->n_local * 8;
     float* lv = c->logvar_s + P0 * c->n_local * 8;
     STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s, a.seq_dev));
-    STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s));
+    STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag));
     if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
         STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, Htot, a.err, a.err_u8, B, s));
     return HNET_OK;
@@ -640,6 +641,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
+    if ((size_t)g.max_batch * (size_t)g.mc_samples * 1280 + 256 >= ((size_t)1 << 32)) return HNET_ERR_CAPACITY;   // 32-bit indices of the keep-bit kernel (s3_dispatch.h)
     if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
         return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
@@ -728,6 +730,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->graph_timing = getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) == 1;
     CK(hipMalloc((void**)&c->d_seq, 8));
     CK(hipMemset(c->d_seq, 0, 8));
+    CK(hipMalloc((void**)&c->d_flag, 4));
+    CK(hipMemset(c->d_flag, 0, 4));
     CK(hipHostMalloc((void**)&c->pinned, sizeof(hnet_ctx::Pinned), hipHostMallocDefault));
     for (int i = 0; i < 2; i++) {
         CK(hipHostMalloc((void**)&c->pinned_img[i], NPIX, hipHostMallocDefault));
@@ -839,7 +843,7 @@ void hnet_destroy(hnet_ctx* c) {
         if (c->pinned_img[i]) (void)hipHostFree(c->pinned_img[i]);
         if (c->ev_img[i]) (void)hipEventDestroy(c->ev_img[i]);
     }
-    fr(c->d_seq);
+    fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
@@ -973,7 +977,7 @@ static void note_timing(hnet_ctx* c, float dev_ms, double host_ms, bool main_mod
     }
 }
 
-// HNET_PREC_F16X2 carries activations in fp16 planes (|a| < 65504).  An overflow turns into infinities / NaNs that reach the outputs; the
+// HNET_PREC_F16X2 carries activations in fp16 planes (|a| < 32768 guaranteed, s3_format.h).  An overflow turns into infinities / NaNs that reach the outputs; the
 // host-result entry points then re-pack the weights for HNET_PREC_BF16X3 (fp32 range, same kernels in their six-product form), run the call
 // again and stay in that mode: a finite answer of the reference is never lost to the faster arithmetic.
 static bool all_finite(const float* v, size_t n) {
@@ -997,6 +1001,24 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     return HNET_OK;
 }
 int hnet_precision(const hnet_ctx* c) { return c ? c->cfg.precision : -1; }
+
+int hnet_overflow_flag(hnet_ctx* c, void* stream, int* flags) {
+    if (!c || !flags) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    uint32_t v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_flag, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *flags = (int)v;
+    return HNET_OK;
+}
+// A non-finite output only means "activation beyond the fp16-plane range" when the inputs were finite: a NaN prior of a diverged filter or a
+// NaN float image gives NaN outputs in every arithmetic (the reference's too) and must not cost the context its mode.
+static bool prior_finite(const double* p, size_t n) {
+    for (size_t i = 0; p && i < n; i++) if (!std::isfinite(p[i])) return false;
+    return true;
+}
 
 int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_out[8], float cov_out[64], uint8_t* err_map_out) {
     if (!c || !mean_out || !cov_out) return HNET_ERR_INVALID_ARG;
@@ -1032,7 +1054,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             HIPCHK(c, hipGraphLaunch(c->g_infer[slot], c->stream));
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (c->n_planes == 2 && !(all_finite(pin->mean, 8) && all_finite(pin->cov, 64))) {
+            if (c->n_planes == 2 && !(all_finite(pin->mean, 8) && all_finite(pin->cov, 64)) && prior_finite(c->cfg.use_prior ? prior_px : nullptr, 8)) {
                 const int rd = demote_to_bf16x3(c);
                 return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
             }
@@ -1062,7 +1084,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (err_map_out) HIPCHK(c, hipMemcpyAsync(err_map_out, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->n_planes == 2 && !(all_finite(mean_out, 8) && all_finite(cov_out, 64))) {
+    if (c->n_planes == 2 && !(all_finite(mean_out, 8) && all_finite(cov_out, 64)) && prior_finite(c->cfg.use_prior ? prior_px : nullptr, 8)) {
         const int rd = demote_to_bf16x3(c);
         return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
     }
@@ -1107,7 +1129,9 @@ int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fm
     HIPCHK(c, hipMemcpyAsync(cov, c->d_cov, (size_t)batch * 64 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (err_map) HIPCHK(c, hipMemcpyAsync(err_map, c->d_err, (size_t)batch * NPIX * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (c->n_planes == 2 && !(all_finite(mean, (size_t)batch * 8) && all_finite(cov, (size_t)batch * 64))) {
+    if (c->n_planes == 2 && !(all_finite(mean, (size_t)batch * 8) && all_finite(cov, (size_t)batch * 64)) &&
+        (!prior || all_finite(prior, (size_t)batch * 8)) &&
+        (pix_fmt == HNET_PIX_U8 || (all_finite((const float*)prev, (size_t)batch * NPIX) && all_finite((const float*)curr, (size_t)batch * NPIX)))) {
         const int rd = demote_to_bf16x3(c);
         return rd != HNET_OK ? rd : hnet_infer_batch(c, prev, curr, pix_fmt, prior, batch, pair_seq0, mean, cov, err_map);
     }
@@ -1130,7 +1154,7 @@ int hnet_mc_finish_device(hnet_ctx* c, const float* d_mean_s, const float* d_log
     if (!c || !d_mean_s || !d_logvar_s || !d_h_part1 || !d_mean || !d_cov || n_total < 1 || batch < 1) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, launch_mc_finish(d_mean_s, d_logvar_s, n_total, d_h_part1, batch, d_mean, d_cov, nullptr,
-                               stream ? (hipStream_t)stream : c->stream));
+                               stream ? (hipStream_t)stream : c->stream, c->d_flag));
     return HNET_OK;
 }
 

@@ -101,11 +101,11 @@ hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float*
 //   hidden [B*n_local][512]
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
-                            hipStream_t s, const uint64_t* seq_dev = nullptr);
+                            hipStream_t s, const uint64_t* seq_dev = nullptr, uint32_t* flag = nullptr /* bit 0 is ORed when an output is not finite */);
 
 // ensemble/transfer from gathered per-sample outputs [B][n][8]
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
-                            float* mean, float* cov, float* Htot, hipStream_t s);
+                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag = nullptr);
 
 // layout helpers for the operator-level entry points
 hipError_t launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s);

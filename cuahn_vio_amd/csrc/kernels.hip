@@ -652,7 +652,7 @@ constexpr int FC2_CHUNK = 4;
 __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
                                                         uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                         const uint64_t* __restrict__ seq_dev, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        float* __restrict__ mean_s, float* __restrict__ logvar_s) {
+                                                        float* __restrict__ mean_s, float* __restrict__ logvar_s, uint32_t* __restrict__ flag) {
     __shared__ float w2s[4096];                  // [2][8][256]
     __shared__ float hid[FC2_CHUNK * 512];       // after dropout
     const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
@@ -696,16 +696,17 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
         float* dst = head == 0 ? mean_s : logvar_s;
         if (head == 1) v *= 1e-3f;
         dst[((size_t)b * n_local + c0 + sl) * 8 + oi] = v;
+        if (flag && !(fabsf(v) <= 3.0e38f)) atomicOr(flag, 1u);       // hnet_overflow_flag: a non-finite per-sample output (the *_partial path ends here)
     }
 }
 
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                             uint64_t pair_seq0, const float* w2, const float* b2, float* mean_s, float* logvar_s,
-                            hipStream_t s, const uint64_t* seq_dev) {
+                            hipStream_t s, const uint64_t* seq_dev, uint32_t* flag) {
     if (n_local < 1 || !mean_s || !logvar_s) return hipErrorInvalidValue;
     const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
     hipLaunchKernelGGL(heads_fc2_kernel, dim3((unsigned)(batch * n_chunks)), dim3(256), 0, s, hidden, n_local, s_begin,
-                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, seq_dev, w2, b2, mean_s, logvar_s);
+                       hnet_drop_threshold(p), 1.0f / (1.0f - p), mc_seed, pair_seq0, seq_dev, w2, b2, mean_s, logvar_s, flag);
     return hipGetLastError();
 }
 
@@ -722,7 +723,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 }
 __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
                                                        const float* __restrict__ H1, int batch, float* __restrict__ mean,
-                                                       float* __restrict__ cov, float* __restrict__ Htot) {
+                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag) {
     const int t = threadIdx.x, i = t & 7, c = t >> 3;
     const int b = blockIdx.x;
     const float* ms = mean_s + (size_t)b * n * 8;
@@ -747,12 +748,20 @@ __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__
         pbar[k] = __hiloint2double(__shfl(__double2hiint(pb), k), __shfl(__double2loint(pb), k));
         ens[k] = __hiloint2double(__shfl(__double2hiint(en), k), __shfl(__double2loint(en), k));
     }
-    if (t == 0) transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
+    if (t == 0) {
+        transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
+        if (flag) {                                  // hnet_overflow_flag: any non-finite output of this pair (the 8 x 8 covariance is block diagonal:
+            bool bad = false;                        // its 2 x 2 blocks hold every non-zero entry)
+            for (int k = 0; k < 8; k++) bad = bad || !(fabsf(mean[b * 8 + k]) <= 3.0e38f);
+            for (int k = 0; k < 64; k++) bad = bad || !(fabsf(cov[b * 64 + k]) <= 3.0e38f);
+            if (bad) atomicOr(flag, 1u);
+        }
+    }
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
-                            float* mean, float* cov, float* Htot, hipStream_t s) {
-    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot);
+                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag) {
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot, flag);
     return hipGetLastError();
 }
 

@@ -6,7 +6,10 @@
 //             weight planes W0 = f16(4096 w), W1 = f16(4096 w - W0), W2 = W0 / 4096
 //             4096 a w = W0 A0 + W1 A0 + W2 A1      (dropped: A1 W1 / 4096 <= 2^-24 |a w|; fp16 x fp16 products are exact in fp32)
 //             the accumulator carries 4096 x the sum (bias enters as 4096 b) and is scaled back (exactly) in the epilogue.
-//             Range: |a| < 65504, |w| < 16 (hnet_create checks the weights); fp16 subnormals are not flushed by the gfx950 MFMAs
+//             Range: |a| < 32768 guaranteed, |w| < 16 (hnet_create checks the weights).  In [32768, 65520) the first plane is finite but 0.04 % of the
+//             fp32 values (those within 2^-8 ulp of an fp16 rounding tie) scale their residual to >= 65520: the second plane becomes an infinity, the
+//             result is non-finite and is DETECTED (hnet_overflow_flag / demotion), never silently wrong; from 65520 on A0 overflows as well
+//             (tests/cpp/s3_format_check.cpp walks both bands exhaustively); fp16 subnormals are not flushed by the gfx950 MFMAs
 //             (tools/f16x2_probe.hip), so small values only lose ABSOLUTE precision below 2^-37.
 // Host + device helpers shared by the kernels (igemm_s3.h) and the weight packer (hnet_capi.hip).
 #pragma once

@@ -111,6 +111,14 @@ class HnetEngine:
     def synchronize(self, stream=None):
         check(self._h, self._L.hnet_synchronize(self._h, self._stream(stream)))
 
+    def overflow_flag(self, stream=None):
+        """hnet_overflow_flag: synchronises, returns and clears the device word the forwards OR into when an output is not finite (bit 0).
+        The device-resident entry points cannot look at their results; in HNET_PREC_F16X2 a set bit with finite inputs means an
+        activation left the fp16-plane range and the batch should be repeated on a HNET_PREC_BF16X3 context."""
+        v = C.c_int(0)
+        check(self._h, self._L.hnet_overflow_flag(self._h, self._stream(stream), C.byref(v)))
+        return int(v.value)
+
     def time_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, iters):
         per = np.zeros(iters, np.float32)
         tot = C.c_float(0)

@@ -48,8 +48,10 @@ enum {
  *   HNET_PREC_F16X2  fp32-grade accuracy on the fp16 matrix cores with THREE MFMAs per product: an activation is two fp16 planes
  *                    (a = A0 + A1 / 4096, 22 + 2 significand bits), a weight three (4096 w = W0 + W1, W0 / 4096), the accumulator
  *                    carries 4096 x the sum (csrc/s3_format.h).  Same parity gates as HNET_PREC_BF16X3.  Range: |weight| < 16
- *                    and |activation| < 65504; outside it the context runs HNET_PREC_BF16X3 instead (hnet_precision below):
- *                    an overflow shows as a non-finite result, never as a silently wrong one, and is recovered from */
+ *                    and |activation| < 32768 (guaranteed; up to 65520 all but 0.04 % of the values still split finitely, s3_format.h).
+ *                    Outside it an overflow shows as a NON-FINITE result, never as a silently wrong one: the host-buffer entry points
+ *                    (hnet_infer, hnet_infer_batch) then repeat the call in HNET_PREC_BF16X3 (hnet_precision below); the device-resident
+ *                    entry points raise hnet_overflow_flag, which the caller polls after its own synchronisation */
 enum { HNET_PREC_FP32 = 0, HNET_PREC_BF16 = 1, HNET_PREC_BF16X3 = 2, HNET_PREC_F16X2 = 3 };
 enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buffers */
 
@@ -96,10 +98,18 @@ void hnet_destroy(hnet_ctx* ctx);
 const char* hnet_status_string(int status);
 const char* hnet_last_error(const hnet_ctx* ctx);   /* text of the last HNET_ERR_DEVICE etc.; never NULL */
 const char* hnet_version(void);
+/* Device-resident entry points and the fp16-plane range.  Every forward ORs bit 0 of a device word when one of its outputs (mean / cov, or
+ * the per-sample head outputs of the *_partial path) is not finite; this call synchronises `stream` (NULL = the context's), returns the word in
+ * *flags and clears it.  In HNET_PREC_F16X2 a set bit with finite inputs means an activation left the fp16-plane range: run that batch
+ * again on a HNET_PREC_BF16X3 context (same results as fp32 arithmetic, fp32 range).  Costs no extra launch. */
+int hnet_overflow_flag(hnet_ctx* ctx, void* stream, int* flags);
+
 /* the arithmetic mode in effect (HNET_PREC_*).  It differs from the requested one in two cases, both HNET_PREC_F16X2 -> HNET_PREC_BF16X3
  * (same results, twice the matrix-core work): a weight >= 16 at hnet_create, or an activation beyond the fp16 range seen by hnet_infer /
  * hnet_infer_batch (non-finite outputs): the context re-packs its weights, repeats the call and stays in HNET_PREC_BF16X3.  The
- * device-resident entry points cannot look at their results: there such an overflow shows as non-finite outputs. */
+ * device-resident entry points cannot look at their results: there such an overflow shows as non-finite outputs and raises
+ * hnet_overflow_flag.  A non-finite INPUT (NaN prior from a diverged filter, NaN float image) is not an overflow: the call returns
+ * the non-finite outputs as the reference would and the context keeps its mode. */
 int hnet_precision(const hnet_ctx* ctx);
 
 /* Replaces HomographyNet::load_current_img (HomographyNet.cpp:127-151): copies the 224x320 8-bit image

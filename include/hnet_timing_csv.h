@@ -12,7 +12,10 @@
 #ifndef HNET_TIMING_CSV_H
 #define HNET_TIMING_CSV_H
 
+#include <cerrno>
 #include <cstdio>
+#include <string>
+#include <sys/stat.h>
 
 namespace hnet_csv {
 
@@ -28,6 +31,7 @@ class TimingCsv {
     /* VioManager.cpp:85-99: delete an old file, open in append mode, write the header */
     bool open(const char* path) {
         close();
+        make_parent_dirs(path);                /* boost::filesystem::create_directories(p.parent_path()), VioManager.cpp:92-93 */
         std::remove(path);
         f_ = std::fopen(path, "a");
         if (!f_) return false;
@@ -48,6 +52,18 @@ class TimingCsv {
     }
 
   private:
+    /* mkdir -p of the file's directory; failures surface as a failed fopen */
+    static void make_parent_dirs(const char* path) {
+        std::string p(path);
+        const size_t last = p.find_last_of('/');
+        if (last == std::string::npos) return;
+        for (size_t i = 1; i <= last; i++)
+            if (p[i] == '/') {
+                const std::string dir = p.substr(0, i);
+                if (::mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) return;
+            }
+    }
+
     std::FILE* f_;
 };
 

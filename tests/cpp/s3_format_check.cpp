@@ -44,6 +44,27 @@ int main() {
             worst_g = std::fmax(worst_g, std::fabs((double)f16_to_f32(z) * 4096.0 - (double)f16_to_f32(x)) / std::fmax(std::ldexp(1.0, -11) * std::fabs(f16_to_f32(x)), std::ldexp(1.0, -12)));
         }
     }
+    // the RANGE of the activation split, exhaustively over every fp32 value of the bands concerned: both planes stay finite for
+    // |a| < 32768 (proven bound: half an fp16 ulp there is <= 8, x 4096 = 32768 < 65520); in [32768, 65520) the first plane is still
+    // finite but the residual of values within 2^-8 ulp of a rounding tie scales to >= 65520 and the SECOND plane becomes an infinity
+    // (a non-finite result that the library detects, never a silently wrong one); from 65520 on the first plane overflows too.
+    long inf_lo = 0, inf_mid = 0, fin_mid = 0, bad_err = 0;
+    auto finite16 = [](uint16_t h) { return (h & 0x7C00u) != 0x7C00u; };
+    for (uint32_t u = 0x46800000u; u < 0x47000000u; u++) {            // [16384, 32768): the top binade of the guaranteed range
+        float a; memcpy(&a, &u, 4);
+        uint16_t x, y; split2h(a, x, y);
+        if (!finite16(x) || !finite16(y)) inf_lo++;
+        else if (std::fabs((double)join2h(x, y) - a) > std::ldexp(1.0, -22) * a) bad_err++;
+    }
+    for (uint32_t u = 0x47000000u; u < 0x477FF000u; u++) {            // [32768, 65520)
+        float a; memcpy(&a, &u, 4);
+        uint16_t x, y; split2h(a, x, y);
+        if (!finite16(x)) { inf_lo++; continue; }                      // must not happen below 65520
+        if (!finite16(y)) inf_mid++; else { fin_mid++; if (std::fabs((double)join2h(x, y) - a) > std::ldexp(1.0, -22) * a) bad_err++; }
+    }
+    printf("activation range: [16384, 32768) non-finite planes %ld (must be 0); [32768, 65520): %ld values split finitely, %ld give an infinite second plane; "
+           "error bound violations %ld\n", inf_lo, fin_mid, inf_mid, bad_err);
+    if (inf_lo != 0 || bad_err != 0 || inf_mid == 0) return 1;       // inf_mid == 0 would mean the documented caveat is wrong
     printf("checked %ld conversions, %ld differ; worst error / bound: activation split %.3f, weight planes %.3f, W2 vs W0 %.3f\n", n, bad, worst_a, worst_w, worst_g);
     return (bad != 0 || worst_a > 1.0 || worst_w > 1.0 || worst_g > 1.0) ? 1 : 0;
 }

@@ -1,5 +1,5 @@
 """HNET_PREC_F16X2 (the default arithmetic: two fp16 planes per activation, three fp16 MFMAs per product, csrc/s3_format.h) has a
-range: |weight| < 16, |activation| < 65504.  Outside it the context must give the answer of HNET_PREC_BF16X3 — never a silently
+range: |weight| < 16, |activation| < 32768 (guaranteed; fp16 itself ends at 65504).  Outside it the context must give the answer of HNET_PREC_BF16X3 — never a silently
 wrong or a non-finite one — and say so through hnet_precision."""
 import numpy as np
 import pytest
@@ -89,3 +89,64 @@ def test_other_weight_sets_stay_at_fp32_level(seed, conv_gain):
         print(f"seed {seed} gain {conv_gain} precision {prec}: |hip - oracle| = {d:.2e} px, offsets up to {np.abs(ref['mean']).max():.1f} px")
         assert d < TOL_PX_VS_ORACLE
     assert float(np.abs(got[PREC_F16X2] - got[PREC_BF16X3]).max()) < 1e-4
+
+
+def test_activations_up_to_32768_are_carried_exactly_and_beyond_that_are_detected(blob, state):
+    """the proven range of the two-plane format (tests/cpp/s3_format_check.cpp: exhaustive on the host): a conv fed with |a| ~ 30 000 gives the
+    oracle's answer at the fp32 level; fed with |a| ~ 40 000 - inside fp16's 65504 but beyond the guaranteed 32768 - every output is EITHER
+    at the fp32 level OR non-finite (an infinite second plane of a near-tie value), never finite and wrong"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from oracle import pyoracle
+    layer = 4                                                  # block_2_2: 64 -> 128, 5x5 stride 2 (implicit GEMM on the matrix cores)
+    rng = np.random.default_rng(5)
+    e = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=PREC_F16X2)
+    for amp, must_be_finite in ((30000.0, True), (40000.0, False)):
+        x = (rng.uniform(0.6, 1.0, (1, 64, 28, 40)) * amp * rng.choice([-1.0, 1.0], (1, 64, 28, 40))).astype(np.float32)
+        got = e.op_conv(layer, x)
+        ref = pyoracle.conv_lrelu(x, state["model_part1.block_2_2.0.weight"], state["model_part1.block_2_2.0.bias"], 2)
+        fin = np.isfinite(got)
+        if must_be_finite:
+            assert fin.all()
+        scale = np.abs(ref).max()
+        assert np.abs(got[fin] - ref[fin]).max() / scale < 2e-5, amp
+        print(f"|a| ~ {amp:.0f}: {fin.mean() * 100:.2f} % of the outputs finite, max rel err of those {np.abs(got[fin] - ref[fin]).max() / scale:.1e}")
+    e.close()
+
+
+def test_device_entry_points_raise_the_overflow_flag(blob):
+    """the device-resident entry points cannot demote; they OR a device word that hnet_overflow_flag returns and clears"""
+    import torch
+    from cuahn_vio_amd.homography_net import PIX_F32, PIX_U8, HnetEngine
+    i1, i2 = _pair(6)
+    dev = torch.device("cuda", 0)
+    mean, cov = torch.zeros(2, 8, device=dev), torch.zeros(2, 64, device=dev)
+    e = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=2, precision=PREC_F16X2)
+    assert e.overflow_flag() == 0                              # the warm-up forward of hnet_create left it clear
+    p_ok, c_ok = torch.from_numpy(np.stack([i1, i2])).to(dev), torch.from_numpy(np.stack([i2, i1])).to(dev)
+    e.infer_batch_device(p_ok.data_ptr(), c_ok.data_ptr(), PIX_U8, None, 2, 0, mean.data_ptr(), cov.data_ptr())
+    assert e.overflow_flag() == 0 and torch.isfinite(mean).all()
+    big = lambda a: torch.from_numpy((a.astype(np.float32) / 255.0 * 3.0e6)[None]).to(dev)
+    pb, cb = big(i1), big(i2)
+    e.infer_batch_device(pb.data_ptr(), cb.data_ptr(), PIX_F32, None, 1, 0, mean.data_ptr(), cov.data_ptr())
+    assert e.overflow_flag() == 1                              # raised ...
+    assert e.overflow_flag() == 0                              # ... and cleared by the poll
+    assert e.precision() == PREC_F16X2                         # the device path never switches the mode by itself
+    # the sharded path ends in heads_fc2: same word
+    ms, lv, h1 = torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 9, device=dev)
+    e.infer_mc_partial_device(pb.data_ptr(), cb.data_ptr(), PIX_F32, None, 1, 0, ms.data_ptr(), lv.data_ptr(), h1.data_ptr())
+    assert e.overflow_flag() == 1
+    e.close()
+
+
+def test_a_nan_prior_is_not_an_overflow(blob):
+    """non-finite INPUTS (a diverged filter's NaN prior) give NaN outputs in any arithmetic; the context must keep its mode"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    i1, i2 = _pair(7)
+    e = HnetEngine(blob, variant="prior3", mc_samples=4, dropout_p=0.05, mc_seed=1, max_batch=1, precision=PREC_F16X2)
+    prior = np.full((1, 8), np.nan, np.float32)
+    mean, _cov = e.infer_batch(i1[None], i2[None], prior)
+    assert not np.isfinite(mean).all()
+    assert e.precision() == PREC_F16X2
+    m2, _ = e.infer_batch(i1[None], i2[None], np.zeros((1, 8), np.float32))
+    assert np.isfinite(m2).all() and e.precision() == PREC_F16X2
+    e.close()

@@ -35,3 +35,7 @@ def test_cpp_writer_reproduces_the_reference_file(tmp_path):
     text = "".join(" ".join(repr(x) for x in r) + "\n" for r in rows)
     subprocess.run([exe, str(out)], input=text, text=True, check=True, timeout=30)
     assert out.read_bytes() == open(GOLD, "rb").read()
+    # a fresh output directory is created like the reference does (boost::filesystem::create_directories, VioManager.cpp:92-93)
+    deep = tmp_path / "new" / "dir" / "timing.txt"
+    subprocess.run([exe, str(deep)], input=text, text=True, check=True, timeout=30)
+    assert deep.read_bytes() == open(GOLD, "rb").read()
