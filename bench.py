@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16
 PEAK_HBM_GBS = 8000.0
-TOL_PX = 2e-4                     # |HIP - oracle| gate of the self check (tests/conftest.py TOL_PX_VS_ORACLE)
+TOL_PX = 1e-4                     # |HIP - oracle| gate of the self check (tests/conftest.py TOL_PX_VS_ORACLE; north_star's figure)
 
 # precision -> (hnet_config.precision, bf16/fp32 MFMAs issued per multiply-accumulate, peak of the instruction issued, label)
 PRECISIONS = {
@@ -59,6 +59,16 @@ def parse(argv=None):
     ap.add_argument("--replay", default=None, metavar="SEQ",
                     help="with --mode stream: the pairs are rendered along the committed UZH-FPV trajectory fixture "
                          "tests/golden/replay_<SEQ>.npz (tools/make_replay_fixture.py), priors from the EKF mean propagation")
+    ap.add_argument("--pairs-total", type=int, default=None, metavar="P",
+                    help="BASELINE config 5's shape: P pairs per step ACROSS the ranks (batch per GPU = P / N, strong scaling) instead of "
+                         "--batch pairs per GPU")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="create the RCCL process group and run the per-step all-gather even with one rank (a 1-rank nccl communicator: the "
+                         "collective code path on a single MI355X)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the additional measurements of the default run (sustained window, other arithmetic modes, configs 3 / 5, "
+                         "reference launch default latency)")
+    ap.add_argument("--sustain-seconds", type=float, default=1.6, help="length of the sustained window of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
@@ -205,8 +215,16 @@ def committed_traffic(kernel_substr, batch):
                    key=lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))])
     if not files:
         return None, None
+    # the figure belongs to ONE build: the CSV carries the digest of the kernel sources that were profiled (tools/csrc_digest.py, written on
+    # the GPU box by tools/profile_round.sh).  After any change under csrc/ the committed figure is dropped, not silently re-quoted.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_digest import csrc_digest
     with open(files[-1]) as f:
-        rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+        lines = f.readlines()
+    have = [l.split(":", 1)[1].split()[0] for l in lines if l.startswith("# csrc_digest:")]
+    if not have or have[0] != csrc_digest(ROOT):
+        return None, "none: " + os.path.basename(files[-1]) + " was collected on other kernel sources (csrc digest " + (have[0] if have else "absent") + ")"
+    rows = list(csv.DictReader(l for l in lines if not l.startswith("#")))
     for r in rows:
         if kernel_substr in r["kernel"]:
             return ((2.0 * float(r["FETCH_SIZE_KiB_full_batch_launch"]) + float(r["WRITE_SIZE_KiB_full_batch_launch"])) * 1024.0,
@@ -274,18 +292,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run:
         return dry_run(args, rank, world)
-    if args.mode == "stream":
-        # the HIP runtime multiplexes its streams over GPU_MAX_HW_QUEUES (default 4) hardware queues; with 4, the copy stream of this
-        # mode regularly shared a queue with the compute stream on the pool's boxes and H2D did not overlap the forward at all
-        # (3.6 instead of 3.0 ms per step).  Read by the runtime when HIP initialises, i.e. it has to be set before torch is imported.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    import numpy as np
+    if args.pairs_total is not None:
+        if args.pairs_total % world:
+            raise SystemExit("--pairs-total must be divisible by the number of GPUs")
+        args.batch = args.pairs_total // world
+    # the HIP runtime multiplexes its streams over GPU_MAX_HW_QUEUES (default 4) hardware queues; with 4, the copy stream of the stream
+    # mode regularly shared a queue with the compute stream on the pool's boxes and H2D did not overlap the forward at all
+    # (3.6 instead of 3.0 ms per step).  Read by the runtime when HIP initialises, i.e. it has to be set before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
-
-    from cuahn_vio_amd import dist as hdist
-    from cuahn_vio_amd import synth, weights
-    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -296,12 +312,60 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = None
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
+        if world == 1 and "MASTER_ADDR" not in os.environ:      # a 1-rank communicator needs no launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         if shared:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev, "shared": shared, "collective": collective}
+    res, ok = run(args, ctx, primary=True)
+    if collective:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"bench.py: the last step's outputs do not match the oracle (max {res.get('max_px_err')} px)")
+
+
+def sub_run(base, ctx, **over):
+    """one more configuration measured in the same process (the default run's `modes` / `configs` entries): the same step, timing and oracle
+    check as the headline, nothing else.  Returns the reduced result dict."""
+    import copy
+    a = copy.copy(base)
+    a.steps, a.warmup = 20, 3
+    for k, v in over.items():
+        setattr(a, k, v)
+    r, ok = run(a, ctx, primary=False)
+    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err")
+    out = {k: r[k] for k in keep if k in r}
+    out["passed"] = bool(ok)
+    out["workload"] = r["config"]["workload"]
+    out["precision"] = r["config"]["precision"]
+    return out
+
+
+def run(args, ctx, primary):
+    """builds the engine and the inputs of one configuration, times it by the contract (W warm-up steps, K timed steps between
+    barrier + synchronize, max over ranks) and checks the last step against the oracle.  primary = the headline configuration: it also
+    carries the roofline, the stage profile, the latency figures, the CPU baseline and (default run) the extra measurements, and prints
+    the JSON line."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cuahn_vio_amd import dist as hdist
+    from cuahn_vio_amd import synth, weights
+    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
+
+    rank, local_rank, world, dev, shared, collective = (ctx[k] for k in ("rank", "local_rank", "world", "dev", "shared", "collective"))
+    backend = None
+    if collective:
         backend = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
 
     B, n_mc = args.batch, args.mc
@@ -323,7 +387,7 @@ def main():
     d_prior = prior.data_ptr() if args.variant != "full" else None
     out = torch.zeros(B, 72, device=dev)            # [mean8 | cov64] per pair
     mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
-    gathered = torch.zeros(world * B, 72, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * B, 72, device=dev) if collective else None
 
     mc_mode = args.mode == "mc"
     shard = hdist.shard_range(n_mc, world, rank) if mc_mode else None
@@ -424,7 +488,7 @@ def main():
         if mc_mode:   # trunk replicated, heads for this rank's samples, gather, finish in the reference's two-pass order
             eng.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), ms_loc.data_ptr(),
                                         lv_loc.data_ptr(), h1.data_ptr(), sp)
-            if world > 1:
+            if collective:
                 ms_all, lv_all, _ = hdist.gather_mc_samples(ms_loc, lv_loc, h1)
             else:
                 ms_all, lv_all = ms_loc, lv_loc
@@ -432,14 +496,14 @@ def main():
             return
         eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i),
                                mean.data_ptr(), cov.data_ptr(), None, sp)
-        if world > 1:
+        if collective:
             hdist.gather_outputs(mean, cov, out, gathered)
 
     def sync():
         if stream_mode and use_thread:
             up_q.join()                                                 # every queued upload has been enqueued on the copy stream
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -451,27 +515,47 @@ def main():
         step(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
     value = (1 if mc_mode else world) * B * args.steps / dt     # mc mode: every rank works on the same B pairs
+    last = args.warmup + args.steps - 1                         # index of the last executed step (the one the oracle check looks at)
+    extras = primary and not args.no_extras and not stream_mode and not mc_mode
+    sustained = None
+    if extras and args.sustain_seconds > 0:
+        # the timed region above is K = 20 steps = 34 ms: burst clocks.  The same step back to back for >= 1.5 s, outside `value`:
+        n_sus = max(args.steps, int(np.ceil(args.sustain_seconds * 1e3 / ms_per_step)))
+        t0 = time.perf_counter()
+        for i in range(n_sus):
+            step(last + 1 + i)
+        sync()
+        dts = time.perf_counter() - t0
+        if collective:
+            t = torch.tensor([dts], device="cpu" if shared else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        last += n_sus
+        sustained = {"value": round(world * B * n_sus / dts, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * dts / n_sus, 4), "steps": n_sus,
+                     "seconds": round(dts, 3), "vs_timed_region": round((world * B * n_sus / dts) / value, 4),
+                     "definition": "the same step enqueued back to back right after the timed region, barrier + synchronize on both sides, max over ranks"}
 
     res = {
         "metric": "homography preds/sec (frame pairs/s), full 4-block HomographyNet @ 320x224",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if mc_mode else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if (mc_mode or args.pairs_total is not None) else "weak", "vs_baseline": None,
         "dtype": dtype_label, "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
                                f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
                    "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision,
                    "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
                                    if mc_mode else
-                                   (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if world > 1 else "single GPU")),
+                                   (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if collective else "single GPU")),
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
-        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+        "rccl_ranks": dist.get_world_size() if collective else 1, "backend": backend,
     }
     if replay is not None:
         res["config"]["workload"] += f"; frames rendered along UZH-FPV {replay['name']} (tests/golden/replay_{args.replay}.npz), priors from the EKF mean propagation"
@@ -482,15 +566,16 @@ def main():
 
     # ---- self check, outside the timed region: pairs of the LAST step against the CPU oracle (every rank checks its own shard)
     ok = True
+    if sustained is not None:
+        res["sustained"] = sustained
     if not args.no_verify:
-        last = args.warmup + args.steps - 1
         slots = sorted({0, 1, B // 2, B - 1} & set(range(B)))
         s0 = seq0_of_step(last)
         n_v, err_px, err_cov = verify_last_step(blob, prev_h, curr_h, prior_h, args.variant, n_mc, lambda b: s0 + b,
                                                 mean.cpu().numpy(), cov.cpu().numpy(), slots)
         gated = args.precision != "bf16"        # plain bf16 is a reported mode: its error is printed, not gated
         ok = (err_px < TOL_PX and err_cov < 1e-4) or not gated
-        if world > 1:
+        if collective:
             v = torch.tensor([err_px, err_cov, 0.0 if ok else 1.0], device="cpu" if shared else dev, dtype=torch.float64)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             err_px, err_cov, ok = float(v[0]), float(v[1]), float(v[2]) == 0.0
@@ -500,9 +585,7 @@ def main():
         res["verify"] = {"against": "oracle/ (CPU restatement, double accumulation)", "slots_per_rank": slots, "step": last,
                          "gate_px": TOL_PX if gated else None, "passed": bool(ok)}
 
-    if rank == 0 and (mc_mode or stream_mode):
-        print(json.dumps(res), flush=True)
-    if rank == 0 and not mc_mode and not stream_mode:
+    if rank == 0 and primary and not mc_mode and not stream_mode:
         # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on.
         # executed FLOP = 2 x MACs x (MFMAs per MAC): three fp16 MFMAs stand behind every MAC of the default mode, six bf16 ones in split-bf16;
         # peak = dense peak of the instruction actually issued.  The fp32-equivalent rate (2 x MACs / time) is a separate field.
@@ -577,15 +660,58 @@ def main():
             res["latency_batch1_ms"]["end_to_end_p95"] = round(float(np.percentile(e2e, 95)), 4)
             res["latency_batch1_ms"]["end_to_end_definition"] = ("host wall clock of load_current_img + network_inference per frame through the "
                                                                  "HomographyNet class surface (u8 image H2D, forward, outputs D2H), 200 frames after 20")
+        if extras and world == 1 and not args.no_latency:
+            res["latency_batch1_ms"]["reference_launch_default"] = reference_launch_default_latency(blob, prev_h, curr_h, prior_h, local_rank, prec)
+        if extras and world == 1:
+            # the other arithmetic modes and BASELINE's other single-GPU configurations, 20 timed steps each, same process, same oracle gate
+            res["modes"] = {pm: sub_run(args, ctx, precision=pm, no_extras=True) for pm in ("bf16x3", "fp32", "bf16") if pm != args.precision}
+            res["configs"] = {
+                "config3_prior3_b64_n16": sub_run(args, ctx, variant="prior3", batch=64, mc=16, no_extras=True),
+                "config4_mc_n32_one_pair": sub_run(args, ctx, mode="mc", batch=1, no_extras=True),
+                "config5_replay_stream_prior3_b256": sub_run(args, ctx, mode="stream", replay="indoor_forward_7", variant="prior3", mc=16, no_extras=True),
+                "config5_shape_32_pairs_per_gpu": sub_run(args, ctx, variant="prior3", batch=32, mc=16, no_extras=True),
+            }
+            torch.cuda.set_stream(stream)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(blob, weights.synthetic_state(0), prev_h, curr_h, prior_h, args.variant, n_mc, args.cpu_seconds)
+    if rank == 0 and primary:
         print(json.dumps(res), flush=True)
+    if stream_mode and use_thread:
+        up_q.put(None)
+        up_thread.join()
     eng.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if not ok:
-        raise SystemExit(f"bench.py: the last step's outputs do not match the oracle (max {res.get('max_px_err')} px)")
+    return res, ok
+
+
+def reference_launch_default_latency(blob, prev_h, curr_h, prior_h, device_id, prec):
+    """The configuration the reference actually deploys and the only one it recorded a time for (32.8 ms mean network inference on its
+    laptop GPU, cuahn_ros/ov_data/uzh_fpv/traj_timing.txt column 4): the 3-block model with the EKF prior, N = 16, the "_showError"
+    variant with show_img = true (cuahn/launch/uzhfpv.launch:56-58,67), one pair per call - driven through the HomographyNet class
+    surface like VioManager.cpp:188,236-241: load_current_img (71 680 B H2D) + network_inference (forward, photometric error map,
+    288 B + 71 680 B D2H).  device = hnet_last_timing().device_ms of each call (events around the forward, the error map and the
+    copies back); end_to_end = host wall clock per frame."""
+    import contextlib
+    import io
+    import numpy as np
+    from cuahn_vio_amd.homography_net import HomographyNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = HomographyNet("bench_showError.hnw", use_prior=True, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=1,
+                            device_id=device_id, weights_blob=blob, precision=prec)
+        dev_ms, e2e = [], []
+        n = prev_h.shape[0]
+        for i in range(220):
+            t0 = time.perf_counter()
+            net.load_current_img(curr_h[i % n], float(i))
+            net.network_inference(prior_h[i % n].astype(np.float64), 0)
+            if i >= 20:
+                e2e.append(1e3 * (time.perf_counter() - t0))
+                dev_ms.append(net._eng.last_timing()["device_ms"])
+        assert net.last_error_map is not None and net.last_error_map.shape == (224, 320)
+    pc = lambda v, q: round(float(np.percentile(v, q)), 4)
+    return {"p50": pc(dev_ms, 50), "p95": pc(dev_ms, 95), "end_to_end_p50": pc(e2e, 50), "end_to_end_p95": pc(e2e, 95),
+            "config": "prior-3 (3 blocks + EKF prior), N=16, p=0.05, error map computed and copied back (71 680 B), batch 1, 200 frames after 20",
+            "reference_recorded_ms": 32.8,
+            "reference_recorded_note": "mean of column 4 of the reference's own traj_timing.txt (its laptop GPU, libtorch CUDA); other hardware - context only"}
 
 
 if __name__ == "__main__":

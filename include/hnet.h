@@ -128,7 +128,14 @@ int hnet_image_count(const hnet_ctx* ctx);             /* the public `img_counte
  * ring, so a raw frame goes host -> device once and never comes back.
  * PARITY UNPINNED: OpenCV is neither in this image nor vendored by the reference and the reference holds no vectors
  * for this step.  The kernel interpolates with sample positions quantised to 1/32 px like cv::remap (INTER_BITS = 5)
- * in exact integer arithmetic; against cv::remap's coefficient table it may differ by one grey level. */
+ * in exact integer arithmetic.  Deviation class against cv::remap, exactly: OpenCV blends with a 32 x 32 table of 15-bit coefficients
+ * (INTER_REMAP_COEF_BITS = 15: each 1-D weight k/32 is rounded into a pair that sums to 32768) and rounds the 2-D sum once, this
+ * kernel blends with the exact products (32 - fx)(32 - fy) ... fx fy / 1024 and rounds half up: same sample positions, same four
+ * taps, a result that can differ by ONE grey level where the exact blend sits within 2^-10 of a rounding boundary; and OpenCV's maps
+ * pass through its fixed-point convertMaps, whose rounding of positions exactly half way between two 1/32-px steps may pick the other
+ * step (again <= one grey level at a unit gradient).  What IS pinned: bit-exactness against oracle/undistort_oracle.py, four analytic
+ * map properties, and an end-to-end property independent of the restated formulas - the remap of an independently simulated fisheye
+ * photograph of an analytic scene recovers the scene to 0.34 grey levels RMS, 1.0 max (tests/test_undistort.py). */
 typedef struct hnet_camera {
     int32_t fisheye;           /* 1: equidistant model (cam0_is_fisheye, uzhfpv.launch:77), 0: radial-tangential */
     int32_t raw_rows, raw_cols;/* size of the raw image (cam0_wh, uzhfpv.launch:75: 640 x 480) */

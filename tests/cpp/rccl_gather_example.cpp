@@ -1,0 +1,116 @@
+// rccl_gather_example.cpp — the C++ side of the multi-GPU split (north_star: "host code stays C++ ... RCCL gather of the
+// per-sample homographies / covariances over xGMI").  The reference has no collective to cite: pytorch::HomographyNet picks ONE device
+// (HomographyNet.cpp:10-16).  What a C++ integrator adds around the C ABI of include/hnet.h:
+//
+//   one hnet context per GPU (weights replicated, 26 MB) -> the pairs of a batch split contiguously over the GPUs -> every GPU runs
+//   hnet_infer_batch_device on its shard, on its own stream -> the [nb, 8] means and [nb, 64] covariances are packed to [nb, 72] with two
+//   strided device copies -> ONE ncclAllGather of nb x 288 bytes per GPU (latency bound; xGMI bandwidth is irrelevant) -> every GPU
+//   holds all pairs' outputs in pair order.
+//
+// One process drives all visible GPUs here (ncclCommInitAll + group calls); a one-process-per-GPU deployment replaces ncclCommInitAll
+// by ncclGetUniqueId / ncclCommInitRank and keeps the rest.  On a 1-GPU box this is a 1-rank communicator: the same calls execute.
+//   usage: rccl_gather_example <weights.hnw> [pairs_per_gpu]
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hnet.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { std::fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); return 3; } } while (0)
+#define HNET_CHECK(x) do { int s_ = (x); if (s_ != HNET_OK) { std::fprintf(stderr, "%s: %s\n", #x, hnet_status_string(s_)); return 4; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s weights.hnw [pairs_per_gpu]\n", argv[0]); return 1; }
+    const int nb = argc > 2 ? std::atoi(argv[2]) : 8;
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (ndev < 1 || nb < 1) return 1;
+    const size_t npix = (size_t)HNET_IMG_ROWS * HNET_IMG_COLS;
+
+    std::vector<int> devs(ndev);
+    for (int d = 0; d < ndev; d++) devs[d] = d;
+    std::vector<ncclComm_t> comm(ndev);
+    NCCL_OK(ncclCommInitAll(comm.data(), ndev, devs.data()));
+
+    struct PerDev { hnet_ctx* ctx; hipStream_t s; uint8_t *prev, *curr; float *mean, *cov, *out, *all; };
+    std::vector<PerDev> g(ndev);
+    // synthetic frames: pair p of the whole batch is a smooth pattern and the same pattern shifted by (p % 5) pixels
+    std::vector<uint8_t> hp(nb * npix), hc(nb * npix);
+    for (int d = 0; d < ndev; d++) {
+        HIP_OK(hipSetDevice(d));
+        hnet_config cfg;
+        hnet_default_config(&cfg);
+        cfg.device_id = d;
+        cfg.mc_samples = 16;
+        cfg.max_batch = nb;
+        HNET_CHECK(hnet_create(&cfg, argv[1], &g[d].ctx));
+        HIP_OK(hipStreamCreateWithFlags(&g[d].s, hipStreamNonBlocking));
+        for (int b = 0; b < nb; b++) {
+            const int p = d * nb + b;                                  // global pair index: contiguous shards
+            for (int v = 0; v < HNET_IMG_ROWS; v++)
+                for (int u = 0; u < HNET_IMG_COLS; u++) {
+                    hp[b * npix + (size_t)v * HNET_IMG_COLS + u] = (uint8_t)(128 + 60 * ((u / 16 + v / 12 + p) % 2) + ((u * 7 + v * 3) % 23));
+                    const int us = u + p % 5;
+                    hc[b * npix + (size_t)v * HNET_IMG_COLS + u] = (uint8_t)(128 + 60 * ((us / 16 + v / 12 + p) % 2) + ((us * 7 + v * 3) % 23));
+                }
+        }
+        HIP_OK(hipMalloc((void**)&g[d].prev, nb * npix));
+        HIP_OK(hipMalloc((void**)&g[d].curr, nb * npix));
+        HIP_OK(hipMalloc((void**)&g[d].mean, (size_t)nb * 8 * 4));
+        HIP_OK(hipMalloc((void**)&g[d].cov, (size_t)nb * 64 * 4));
+        HIP_OK(hipMalloc((void**)&g[d].out, (size_t)nb * 72 * 4));
+        HIP_OK(hipMalloc((void**)&g[d].all, (size_t)ndev * nb * 72 * 4));
+        HIP_OK(hipMemcpy(g[d].prev, hp.data(), nb * npix, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(g[d].curr, hc.data(), nb * npix, hipMemcpyHostToDevice));
+    }
+
+    // one step: forward of every shard, pack, all-gather - everything of a GPU on its one stream
+    for (int d = 0; d < ndev; d++) {
+        HIP_OK(hipSetDevice(d));
+        HNET_CHECK(hnet_infer_batch_device(g[d].ctx, g[d].prev, g[d].curr, HNET_PIX_U8, nullptr, nb, (uint64_t)d * nb, g[d].mean, g[d].cov, nullptr, g[d].s));
+        HIP_OK(hipMemcpy2DAsync(g[d].out, 72 * 4, g[d].mean, 8 * 4, 8 * 4, nb, hipMemcpyDeviceToDevice, g[d].s));
+        HIP_OK(hipMemcpy2DAsync(g[d].out + 8, 72 * 4, g[d].cov, 64 * 4, 64 * 4, nb, hipMemcpyDeviceToDevice, g[d].s));
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int d = 0; d < ndev; d++) NCCL_OK(ncclAllGather(g[d].out, g[d].all, (size_t)nb * 72, ncclFloat, comm[d], g[d].s));
+    NCCL_OK(ncclGroupEnd());
+
+    // every GPU must hold every shard's packed outputs, in pair order, bit for bit; no output may be non-finite
+    std::vector<std::vector<float>> own(ndev, std::vector<float>((size_t)nb * 72));
+    for (int d = 0; d < ndev; d++) {
+        HIP_OK(hipSetDevice(d));
+        HIP_OK(hipStreamSynchronize(g[d].s));
+        int flags = 0;
+        HNET_CHECK(hnet_overflow_flag(g[d].ctx, g[d].s, &flags));
+        if (flags) { std::fprintf(stderr, "device %d: non-finite outputs (overflow flag %d)\n", d, flags); return 5; }
+        HIP_OK(hipMemcpy(own[d].data(), g[d].out, (size_t)nb * 72 * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<float> all((size_t)ndev * nb * 72);
+    for (int d = 0; d < ndev; d++) {
+        HIP_OK(hipSetDevice(d));
+        HIP_OK(hipMemcpy(all.data(), g[d].all, all.size() * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < ndev; r++)
+            if (std::memcmp(all.data() + (size_t)r * nb * 72, own[r].data(), (size_t)nb * 72 * 4) != 0) {
+                std::fprintf(stderr, "device %d: shard %d of the gathered outputs differs from its source\n", d, r);
+                return 6;
+            }
+    }
+    int ver = 0;
+    NCCL_OK(ncclGetVersion(&ver));
+    std::printf("RCCL_GATHER_OK ranks=%d pairs_per_gpu=%d rccl_version=%d  pair0 mean = %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n", ndev, nb, ver,
+                all[0], all[1], all[2], all[3], all[4], all[5], all[6], all[7]);
+    for (int d = 0; d < ndev; d++) {
+        HIP_OK(hipSetDevice(d));
+        hnet_destroy(g[d].ctx);
+        (void)hipFree(g[d].prev); (void)hipFree(g[d].curr); (void)hipFree(g[d].mean); (void)hipFree(g[d].cov); (void)hipFree(g[d].out); (void)hipFree(g[d].all);
+        (void)hipStreamDestroy(g[d].s);
+        ncclCommDestroy(comm[d]);
+    }
+    return 0;
+}

@@ -81,3 +81,56 @@ def test_undistort_kernel_matches_oracle(blob, fisheye):
     with pytest.raises(Exception):
         eng.push_raw_image(_raw(1, 100, 100), 9.0)          # wrong raw size
     eng.close(); e2.close()
+
+
+# ---- an end-to-end property that does not use the restated map formulas -------------------------------------------
+def _scene(x, y):
+    """an analytic grey-level pattern on the z = 1 plane of the virtual (undistorted) camera: a soft checkerboard, 8-bit range"""
+    return 128.0 + 55.0 * np.sin(9.0 * x) * np.sin(9.0 * y) + 40.0 * np.sin(2.3 * x - 1.1 * y + 0.4) + 15.0 * np.cos(5.0 * x + 3.0 * y)
+
+
+def _fisheye_photo_of_scene(k, d, rows=480, cols=640):
+    """what a fisheye camera (k, d: the equidistant model, forward direction only) records of _scene: every RAW pixel is back-projected by
+    inverting theta_d = theta (1 + d1 theta^2 + ...) with Newton's method - the opposite direction of the undistortion map, written
+    independently of include/hnet.h / oracle/undistort_oracle.py - and the scene is evaluated at that ray.  Quantised to 8 bits."""
+    v, u = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    xd, yd = (u - k[2]) / k[0], (v - k[3]) / k[1]
+    thd = np.sqrt(xd * xd + yd * yd)
+    th = thd.copy()
+    for _ in range(20):
+        t2 = th * th
+        f = th * (1 + t2 * (d[0] + t2 * (d[1] + t2 * (d[2] + t2 * d[3])))) - thd
+        fp = 1 + t2 * (3 * d[0] + t2 * (5 * d[1] + t2 * (7 * d[2] + t2 * 9 * d[3])))
+        th = th - f / fp
+    r = np.tan(np.clip(th, 0, 1.55))
+    sc = np.where(thd > 1e-12, r / np.maximum(thd, 1e-12), 1.0)
+    return np.clip(np.floor(_scene(xd * sc, yd * sc) + 0.5), 0, 255).astype(np.uint8)
+
+
+def _ideal_undistorted():
+    f = (320 - 1.0) / 2.0 / np.tan(np.pi / 4)                 # the 90-degree virtual camera of CamBase.h:166-169
+    v, u = np.mgrid[0:224, 0:320].astype(np.float64)
+    return _scene((u - (320 - 1.0) / 2.0) / f, (v - (224 - 1.0) / 2.0) / f)
+
+
+def test_undistorting_a_fisheye_photo_recovers_the_scene_cpu():
+    """numpy restatement: remap(fisheye photo) == the scene as the virtual camera sees it, to <= 1 grey level RMS (8-bit quantisation of the
+    photo 0.29 + of the output 0.29 + the 1/32-px position table + bilinear interpolation of a smooth pattern)"""
+    raw = _fisheye_photo_of_scene(K_UZH, D_UZH)
+    mx, my = uo.build_maps(K_UZH, D_UZH, fisheye=True)
+    got = uo.remap(raw, mx, my).astype(np.float64)
+    err = got - _ideal_undistorted()
+    assert np.sqrt((err ** 2).mean()) < 1.0 and np.abs(err).max() < 4.0
+
+
+@pytest.mark.gpu
+def test_undistorting_a_fisheye_photo_recovers_the_scene_gpu(blob):
+    """the same through hnet_set_camera + undistort_kernel: the GPU pre-processing inverts an independently simulated fisheye camera"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    eng = HnetEngine(blob, variant="prior1", mc_samples=4, dropout_p=0.0, max_batch=1)
+    eng.set_camera(K_UZH, D_UZH, 480, 640, fisheye=True)
+    got = eng.op_undistort(_fisheye_photo_of_scene(K_UZH, D_UZH)).astype(np.float64)
+    eng.close()
+    err = got - _ideal_undistorted()
+    print(f"undistort(fisheye photo) vs the analytic scene: RMS {np.sqrt((err ** 2).mean()):.3f}, max {np.abs(err).max():.2f} grey levels")
+    assert np.sqrt((err ** 2).mean()) < 1.0 and np.abs(err).max() < 4.0

@@ -6,6 +6,8 @@
 TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency --no-verify"
+mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/tools/csrc_digest.py > $OUT/csrc_digest.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 5 --warmup 2 > $OUT.stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $B --steps 2 --warmup 1 > $OUT.fetch.log 2>&1

@@ -55,6 +55,8 @@ def per_kernel_max(path, counter):
     return {k: (max(v), len(v)) for k, v in acc.items()}
 
 
+dg = one("csrc_digest.txt")
+digest = open(dg).read().strip() if dg else "unknown"
 fe, wr = one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collection.csv")
 if fe and wr:
     f, w = per_kernel_max(fe, "FETCH_SIZE"), per_kernel_max(wr, "WRITE_SIZE")
@@ -65,6 +67,7 @@ if fe and wr:
         out.write("# byte counts - profiles/r02_traffic_calibration.log): FETCH_SIZE reports exactly half the bytes for 16-, 8- and 4-byte-per-lane loads and for\n")
         out.write("# LDS-DMA loads; WRITE_SIZE is exact for 16- and 8-byte-per-lane stores.  traffic_MB = (2 x FETCH_SIZE + WRITE_SIZE) / 1024: bytes that leave\n")
         out.write("# the XCD's L2 (Infinity-Cache hits are included).\n")
+        out.write("# csrc_digest: " + digest + "   (tools/csrc_digest.py of the sources that were profiled; bench.py quotes this file only for the same sources)\n")
         cw = csv.writer(out)
         cw.writerow(["kernel", "launches", "FETCH_SIZE_KiB_full_batch_launch", "WRITE_SIZE_KiB_full_batch_launch", "traffic_MB_corrected"])
         for k in sorted(f):
