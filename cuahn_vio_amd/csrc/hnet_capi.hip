@@ -100,6 +100,10 @@ struct hnet_ctx {
     int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
+    bool fuse_small = true;            // batch <= 8 (latency path): block-tail FC + DLT inside the next block's prep kernel, heads_fc2 + mc_finish in one launch (HNET_FUSE_SMALL=0: the separate launches; bit-identical)
+    float* Hm2 = nullptr;              // second homography buffer of that path (a prep workgroup stores H while others still read the previous one)
+    const float* H_last = nullptr;     // where the last forward left H_part1 (Hm or Hm2)
+    bool warp_exact = false;           // HNET_WARP_EXACT=1: the prep kernels keep grid_sample's sampling positions bit for bit (kernels.hip, A/B switch); default: the fast sampler
     bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
     uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
@@ -234,7 +238,9 @@ std::vector<float> permute_fc(const float* w, int n_out) {
     return out;
 }
 
-void build_stages(hnet_ctx* c) {
+// the launches of one forward of `batch` pairs, in order (what the STAGE macro of forward_chunk records events for): the latency path
+// (batch <= 8) has fewer of them
+void build_stages(hnet_ctx* c, int batch) {
     c->stages.clear();
     const hnet_config& g = c->cfg;
     auto conv_flops = [&](int l, int h, int w) {
@@ -242,10 +248,19 @@ void build_stages(hnet_ctx* c) {
         return 2.0 * d.cout * d.cin * d.ks * d.ks * conv_out_dim(h, d.ks, d.stride) * conv_out_dim(w, d.ks, d.stride);
     };
     static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
-    if (g.use_prior) c->stages.push_back({"prior_dlt", 0});
+    const bool small = c->fuse_small && batch <= 8;
+    bool pend = false;
+    if (g.use_prior) {
+        if (small) pend = true;
+        else c->stages.push_back({"prior_dlt", 0});
+    }
     const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
     for (int blk = fb; blk < 4; blk++) {
-        c->stages.push_back({"prep_b" + std::to_string(blk + 1), 0});
+        const bool fused_prep = pend && (blk < 3 || c->x16_b4 != nullptr);
+        if (pend && !fused_prep) c->stages.push_back({blk == fb && g.use_prior ? "prior_dlt" : "fc_dlt_b" + std::to_string(blk), blk == fb && g.use_prior ? 0.0 : 2.0 * 8 * 5120});
+        c->stages.push_back({std::string(fused_prep ? (blk == fb && g.use_prior ? "prior_dlt+" : "fc_dlt+") : "") + "prep_b" + std::to_string(blk + 1),
+                             fused_prep && !(blk == fb && g.use_prior) ? 2.0 * 8 * 5120 : 0.0});
+        pend = false;
         int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
         for (int l = first[blk]; l <= last[blk]; l++) {
             double fl = conv_flops(l, h, w);
@@ -261,11 +276,17 @@ void build_stages(hnet_ctx* c) {
             }
             c->stages.push_back({nm, fl});
         }
-        if (blk < 3) c->stages.push_back({"fc_dlt_b" + std::to_string(blk + 1), 2.0 * 8 * 5120});
+        if (blk < 3) {
+            if (small) pend = true;
+            else c->stages.push_back({"fc_dlt_b" + std::to_string(blk + 1), 2.0 * 8 * 5120});
+        }
     }
     c->stages.push_back({"heads_fc1", 2.0 * 512 * 5120 * c->n_local});
-    c->stages.push_back({"heads_fc2", 2.0 * 16 * 256 * c->n_local});
-    c->stages.push_back({"mc_finish", 0});
+    if (small && c->n_local <= HEADS_FC2_FINISH_MAX_N) c->stages.push_back({"heads_fc2+mc_finish", 2.0 * 16 * 256 * c->n_local});
+    else {
+        c->stages.push_back({"heads_fc2", 2.0 * 16 * 256 * c->n_local});
+        c->stages.push_back({"mc_finish", 0});
+    }
     if (g.emit_error_map) c->stages.push_back({"errmap", 0});
 }
 
@@ -307,7 +328,19 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // split-K workspace: only for a launch that covers the whole batch on one stream (small batches)
     float* ws = a.use_ws ? c->ws : nullptr;
     const size_t wsn = a.use_ws ? c->ws_floats : 0;
-    if (g.use_prior) STAGE(launch_prior_dlt(a.prior, Hm, B, s));                    // :129-130
+    // Latency path (batch <= 8): the homography of a block is not produced by a launch of its own (prior DLT / FC + DLT + composition) but
+    // recomputed inside the next block's prep kernel by every workgroup (kernels.h FcArgs): 3-4 launches fewer in the dependent chain.
+    // `pend` holds what the next prep has to evaluate; the homographies alternate between Hm and Hm2 (a workgroup stores the new one while
+    // others still read the old one).
+    const bool small = c->fuse_small && B <= 8;
+    FcArgs pend = {};
+    bool have_pend = false;
+    float* Hcur = Hm;                              // buffer holding the homography so far
+    float* Hnext = c->Hm2 + P0 * 9;
+    if (g.use_prior) {
+        if (small) { pend = FcArgs{nullptr, nullptr, nullptr, nullptr, a.prior, nullptr}; have_pend = true; }
+        else STAGE(launch_prior_dlt(a.prior, Hm, B, s));                               // :129-130
+    }
     const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
     for (int blk = fb; blk < 4; blk++) {
         const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
@@ -315,7 +348,20 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         float* x = c->x_in[blk] + P0 * h * w * 2;
         const bool b4_dma = blk == 3 && c->x16_b4 != nullptr;      // block 4 always warps (:261): the prep kernel writes the padded planes
         uint32_t* x16 = b4_dma ? c->x16_b4 + P0 * B4_HP * B4_WP : nullptr;
-        STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hm : nullptr, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes));
+        if (have_pend) {
+            if (prep_fc_supported(a.prev, a.curr, 8 >> blk, x16 != nullptr)) {
+                pend.H_out = pend.feat ? Hnext : Hcur;                                // the prior's DLT has no input homography: it may land in Hcur
+                STAGE(launch_prep_fc(a.prev, a.curr, a.pix_fmt, pend, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
+                if (pend.feat) std::swap(Hcur, Hnext);
+            } else {                                                                  // (unaligned images / K = 8: the separate launches)
+                if (pend.feat) STAGE(launch_block_fc_dlt(pend.feat, pend.wfc, pend.bfc, pend.H_in, Hcur, B, s));
+                else STAGE(launch_prior_dlt(pend.prior, Hcur, B, s));
+                STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, Hcur, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
+            }
+            have_pend = false;
+        } else {
+            STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hcur : nullptr, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
+        }
         const float* in = x;
         const uint16_t* in16 = nullptr;
         size_t in_plane = 0;
@@ -353,9 +399,13 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             h = c->act_h[l];
             w = c->act_w[l];
         }
-        if (blk < 3)                                                                  // :143-150, :163-168, :183-188
-            STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? Hm : nullptr, Hm, B, s));
+        if (blk < 3) {                                                                // :143-150, :163-168, :183-188
+            if (small) { pend = FcArgs{in, c->fc_w[blk], c->fc_b[blk], warp ? Hcur : nullptr, nullptr, nullptr}; have_pend = true; }
+            else STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? Hcur : nullptr, Hcur, B, s));
+        }
     }
+    Hm = Hcur;                                     // H_part1 of this forward
+    c->H_last = Hcur - P0 * 9;
     // block 4 heads (:272-282) and output assembly (:310-317)
     const float* feat = c->act[19] + P0 * 5120;
     float* hidden = c->hidden + P0 * c->n_local * 512;
@@ -375,8 +425,13 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     }
     float* ms = c->mean_s + P0 * c->n_local * 8;
     float* lv = c->logvar_s + P0 * c->n_local * 8;
-    STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s, a.seq_dev));
-    STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag));
+    if (small && c->n_local <= HEADS_FC2_FINISH_MAX_N) {
+        STAGE(launch_heads_fc2_finish(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, Hm, a.mean, a.cov, Htot, s,
+                                      a.seq_dev, c->d_flag));
+    } else {
+        STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s, a.seq_dev));
+        STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag));
+    }
     if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
         STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, Htot, a.err, a.err_u8, B, s));
     return HNET_OK;
@@ -678,6 +733,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
     c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
+    c->warp_exact = getenv("HNET_WARP_EXACT") && atoi(getenv("HNET_WARP_EXACT")) != 0;
+    c->fuse_small = !(getenv("HNET_FUSE_SMALL") && atoi(getenv("HNET_FUSE_SMALL")) == 0);
     c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
     c->patch_rb5 = getenv("HNET_PATCH_RB5") ? atoi(getenv("HNET_PATCH_RB5")) : 5;     // measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
@@ -752,6 +809,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipMalloc((void**)&c->head_mask, MB * c->n_local * 2 * 640));
     }
     CK(dalloc(&c->Hm, MB * 9));
+    CK(dalloc(&c->Hm2, MB * 9));
     CK(dalloc(&c->Htot, MB * 9));
     CK(dalloc(&c->mean_s, MB * c->n_local * 8));
     CK(dalloc(&c->logvar_s, MB * c->n_local * 8));
@@ -766,7 +824,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     }
     CK(dalloc(&c->ring[0], (size_t)NPIX));
     CK(dalloc(&c->ring[1], (size_t)NPIX));
-    build_stages(c);
+    build_stages(c, g.max_batch);
 
     // ---- warm-up forward on the reference's constant inputs (HomographyNet.cpp:28-45): 0.2 / 0.5 / prior 1.0
     {
@@ -846,7 +904,7 @@ void hnet_destroy(hnet_ctx* c) {
     fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
-    fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
+    fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1227,6 +1285,7 @@ int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_cur
                               uint64_t pair_seq0, float* d_mean, float* d_cov, int iters, float* stage_ms_avg) {
     if (!c || iters < 1 || !stage_ms_avg) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    build_stages(c, batch);               // the launches of a forward of THIS batch (the latency path has fewer): hnet_stage_name follows
     const size_t ns = c->stages.size();
     std::vector<double> acc(ns, 0.0);
     // the per-stage events live in the context only for the duration of this call: whatever happens, they are destroyed
@@ -1372,7 +1431,7 @@ static int op_prep_impl(hnet_ctx* c, const void* img1, const void* img2, int pix
     HIPCHK(c, hipMemcpy(d_1, img1, NPIX * px, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_2, img2, NPIX * px, hipMemcpyHostToDevice));
     if (H) HIPCHK(c, hipMemcpy(d_h, H, 36, hipMemcpyHostToDevice));
-    HIPCHK(c, launch_prep(d_1, d_2, pix_fmt, H ? d_h : nullptr, k, d_o, 1, c->stream));
+    HIPCHK(c, launch_prep(d_1, d_2, pix_fmt, H ? d_h : nullptr, k, d_o, 1, c->stream, nullptr, 0, 3, c->warp_exact));
     HIPCHK(c, launch_nhwc_to_nchw(d_o, d_t, 1, 2, ho, wo, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_t, (size_t)2 * ho * wo * 4, hipMemcpyDeviceToHost));
@@ -1425,7 +1484,7 @@ int hnet_debug_h_part1(hnet_ctx* c, int pair, float* out9) {
     if (!c || !out9 || pair < 0 || pair >= c->cfg.max_batch) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out9, c->Hm + (size_t)pair * 9, 36, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out9, (c->H_last ? c->H_last : c->Hm) + (size_t)pair * 9, 36, hipMemcpyDeviceToHost));
     return HNET_OK;
 }
 

@@ -74,8 +74,24 @@ constexpr int B4_PADX = 5, B4_PADY = 5, B4_WP = 336, B4_HP = 235;
 
 // cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
 // out_s3 != nullptr (k = 1 only): write the padded bf16 planes above instead (s3_plane = dwords per plane)
+//   exact = true: sampling positions bit-identical to grid_sample (IEEE divisions, the normalise / un-normalise round trip of warp.py:70);
+//   false (the library default, HNET_WARP_EXACT=0): shared reciprocal + Newton step, no round trip (positions within 6e-5 px; kernels.hip)
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
-                       int batch, hipStream_t s, uint32_t* out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3);
+                       int batch, hipStream_t s, uint32_t* out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3, bool exact = true);
+// Small-batch form of launch_prep (latency path, batch <= 8): the block-tail launch (Linear(5120,8) + DLT + composition, launch_block_fc_dlt)
+// or the prior's DLT (launch_prior_dlt) disappears from the dependent chain - every workgroup of the tiled warp kernel recomputes its
+// pair's homography with the same instructions in the same order (bit-identical), the first workgroup of a pair stores it to H_out.
+struct FcArgs {
+    const float* feat;      // [B][5120] NHWC-flattened trunk output of the previous block, or nullptr
+    const float* wfc;       // [8][5120], same order
+    const float* bfc;       // [8]
+    const float* H_in;      // [B][9] homography so far (nullptr: identity)
+    const float* prior;     // [B][8] corner-offset prior: H = DLT(p4 + prior); used when feat == nullptr
+    float* H_out;           // [B][9]: written by the first workgroup of each pair (a buffer other than H_in)
+};
+bool prep_fc_supported(const void* img1, const void* img2, int k, bool has_out_s3);
+hipError_t launch_prep_fc(const void* img1, const void* img2, int pix_fmt, const FcArgs& fc, int k, float* out, int batch, hipStream_t s,
+                          uint32_t* out_s3, size_t s3_plane, int n_planes, bool exact);
 hipError_t launch_f32_nhwc_to_s3pad(const float* x, uint32_t* out, size_t s3_plane, int batch, int n_planes, hipStream_t s);
 hipError_t launch_s3pad_to_f32_nhwc(const uint32_t* in, size_t s3_plane, float* x, int batch, int n_planes, hipStream_t s);
 
@@ -106,6 +122,12 @@ hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_b
 // ensemble/transfer from gathered per-sample outputs [B][n][8]
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
                             float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag = nullptr);
+
+// latency path (n_local <= 64): both launches above in one, one 1024-thread workgroup per pair; bit-identical results
+constexpr int HEADS_FC2_FINISH_MAX_N = 64;
+hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed, uint64_t pair_seq0, const float* w2,
+                                   const float* b2, const float* H1, float* mean, float* cov, float* Htot, hipStream_t s,
+                                   const uint64_t* seq_dev = nullptr, uint32_t* flag = nullptr);
 
 // layout helpers for the operator-level entry points
 hipError_t launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s);

@@ -18,14 +18,26 @@ namespace hnet {
 // pixel access: u8 -> float exactly as `toType(kFloat) / 255.0` (HomographyNet.cpp:141,146) through a
 // 256-entry table in LDS (one IEEE division per entry per workgroup instead of one per tap)
 // ---------------------------------------------------------------------------------------------
+// (float)b / 255.0f without the divide or a table: q = b * (1/255) is off by at most one ulp, one Newton step on the
+// remainder lands on the correctly rounded quotient — verified for all 256 bytes (test_u8_scaling_is_exact)
+__device__ __forceinline__ float u8_to_unit(float f) {
+    constexpr float r = 1.0f / 255.0f;
+    const float q = f * r;
+    return fmaf(fmaf(-255.0f, q, f), r, q);
+}
 template <typename PIX> struct PixRead;
 template <> struct PixRead<uint8_t> {
     static constexpr bool kNeedLut = true;
     __device__ static inline float get(const uint8_t* img, int idx, const float* lut) { return lut[img[idx]]; }
+    // the same value without the table (the tiled kernel's rare per-pixel fallback)
+    __device__ static inline float get_direct(const uint8_t* img, int idx) { return u8_to_unit((float)img[idx]); }
+    __device__ static inline float cvt(uint8_t v) { return u8_to_unit((float)v); }
 };
 template <> struct PixRead<float> {
     static constexpr bool kNeedLut = false;
     __device__ static inline float get(const float* img, int idx, const float*) { return img[idx]; }
+    __device__ static inline float get_direct(const float* img, int idx) { return img[idx]; }
+    __device__ static inline float cvt(float v) { return v; }
 };
 
 __device__ inline void fill_lut(float* lut) {
@@ -78,7 +90,7 @@ __device__ inline void warp_coords(const float* h, int u, int v, float& ix, floa
 }
 
 // bilinear blend of the four taps around (ix, iy) read from global memory; out-of-image taps contribute 0
-template <typename PIX>
+template <typename PIX, bool LUT = true>
 __device__ inline float warp_taps_global(const PIX* img, float ix, float iy, const float* lut) {
     const float x0f = floorf(ix), y0f = floorf(iy);
     // NaN / far-out coordinates: all taps out of range -> 0 (comparisons with NaN are false)
@@ -88,10 +100,10 @@ __device__ inline float warp_taps_global(const PIX* img, float ix, float iy, con
     const bool xin0 = x0 >= 0 && x0 < IMG_W, xin1 = x0 + 1 >= 0 && x0 + 1 < IMG_W;
     const bool yin0 = y0 >= 0 && y0 < IMG_H, yin1 = y0 + 1 >= 0 && y0 + 1 < IMG_H;
     float s = 0.0f;
-    if (yin0 && xin0) s = fmaf(PixRead<PIX>::get(img, y0 * IMG_W + x0, lut), wx0 * wy0, s);
-    if (yin0 && xin1) s = fmaf(PixRead<PIX>::get(img, y0 * IMG_W + x0 + 1, lut), wx1 * wy0, s);
-    if (yin1 && xin0) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0, lut), wx0 * wy1, s);
-    if (yin1 && xin1) s = fmaf(PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0 + 1, lut), wx1 * wy1, s);
+    if (yin0 && xin0) s = fmaf((LUT ? PixRead<PIX>::get(img, y0 * IMG_W + x0, lut) : PixRead<PIX>::get_direct(img, y0 * IMG_W + x0)), wx0 * wy0, s);
+    if (yin0 && xin1) s = fmaf((LUT ? PixRead<PIX>::get(img, y0 * IMG_W + x0 + 1, lut) : PixRead<PIX>::get_direct(img, y0 * IMG_W + x0 + 1)), wx1 * wy0, s);
+    if (yin1 && xin0) s = fmaf((LUT ? PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0, lut) : PixRead<PIX>::get_direct(img, (y0 + 1) * IMG_W + x0)), wx0 * wy1, s);
+    if (yin1 && xin1) s = fmaf((LUT ? PixRead<PIX>::get(img, (y0 + 1) * IMG_W + x0 + 1, lut) : PixRead<PIX>::get_direct(img, (y0 + 1) * IMG_W + x0 + 1)), wx1 * wy1, s);
     return s;
 }
 
@@ -120,13 +132,6 @@ __device__ inline float warp_sample(const PIX* img, const float* h, int u, int v
 constexpr int WT_W = 64, WT_H = 32;          // output tile
 constexpr int WT_CAP = 7168;                 // staged floats (28 KB): e.g. 112 x 64
 
-// (float)b / 255.0f without the divide or a table: q = b * (1/255) is off by at most one ulp, one Newton step on the
-// remainder lands on the correctly rounded quotient — verified for all 256 bytes (test_u8_scaling_is_exact)
-__device__ __forceinline__ float u8_to_unit(float f) {
-    constexpr float r = 1.0f / 255.0f;
-    const float q = f * r;
-    return fmaf(fmaf(-255.0f, q, f), r, q);
-}
 template <typename PIX> __device__ __forceinline__ float4 load_px4(const PIX* p);
 template <> __device__ __forceinline__ float4 load_px4<uint8_t>(const uint8_t* p) {
     const uint32_t q = *reinterpret_cast<const uint32_t*>(p);
@@ -204,20 +209,110 @@ __device__ __forceinline__ float warp_sample_box(const float* h, int u, int v, c
     return near && inbox ? s : 0.0f;
 }
 
+// The FAST sampler (round 3, the default; HNET_WARP_EXACT=1 selects the bit-faithful one above).  The contract of the path is 1e-4 px on the
+// network's outputs, not bit-identical sampling positions: warp.py:60-79 normalises the coordinates to [-1, 1] and grid_sample un-normalises
+// them again (two roundings that are not the identity in fp32), and X / Z, Y / Z are IEEE divisions.  Here
+//   * one v_rcp_f32 + one Newton step is shared by both quotients (relative error < 1.5 ulp: 4e-5 px at 320 px) and the normalise /
+//     un-normalise round trip is skipped (it moves a position by < 3e-5 px),
+//   * X, Y, Z advance down the thread's column with one FMA each (the column part is formed once per thread),
+//   * the tile's bounding box holds every tap (a projective map with Z of one sign takes the tile to a convex quadrilateral), so instead of
+//     testing each pixel the POSITION is clamped to the box: where the box was clipped to the frame [-1, W] x [-1, H] the clamp gives the
+//     zero padding exactly (position -1 or W: the only tap with a non-zero weight is a stored zero), elsewhere it never acts,
+//   * weights come from v_fract_f32, the LDS address from one FMA + one conversion.
+// ~30 vector instructions per pixel instead of ~85.  Used only for tiles with a staged box and Z safely away from 0 (the others take the
+// exact path).  Measured position difference to the exact path: < 6e-5 px; outputs: same golden gates (tests/test_gpu_parity.py).
+struct WarpFast { float bx_lo, bx_hi, by_lo, by_hi, fpitch, fbase; };
+__device__ __forceinline__ WarpFast warp_fast_setup(const WarpBox& bx) {
+    WarpFast f;
+    f.bx_lo = (float)max(bx.gx0, -1);
+    f.bx_hi = (float)min(bx.gx0 + bx.pitch - 2, IMG_W);
+    f.by_lo = (float)max(bx.ry0, -1);
+    f.by_hi = (float)min(bx.ry0 + bx.rows - 2, IMG_H);
+    f.fpitch = (float)bx.pitch;
+    f.fbase = -((float)bx.ry0 * (float)bx.pitch + (float)bx.gx0);      // |values| < 2^15: exact in fp32
+    return f;
+}
+__device__ __forceinline__ float warp_sample_box_fast(float X, float Y, float Z, const WarpFast& f, int pitch, const float* reg) {
+    const float r0 = __builtin_amdgcn_rcpf(Z);
+    const float r1 = fmaf(fmaf(-Z, r0, 1.0f), r0, r0);
+    const float ix = __builtin_amdgcn_fmed3f(X * r1, f.bx_lo, f.bx_hi);   // NaN -> one of the bounds (a zero-weight corner case, never a fault)
+    const float iy = __builtin_amdgcn_fmed3f(Y * r1, f.by_lo, f.by_hi);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const int e = (int)fmaf(y0f, f.fpitch, x0f + f.fbase);             // exact: integers below 2^24
+    const float* t = reg + e;
+    float s = t[0] * (wx0 * wy0);
+    s = fmaf(t[1], wx1 * wy0, s);
+    s = fmaf(t[pitch], wx0 * wy1, s);
+    s = fmaf(t[pitch + 1], wx1 * wy1, s);
+    return s;
+}
+
+// Linear(5120, 8) of one pair + corner update + DLT + composition (model_to_trace.py:143-150, :163-168, :183-188), by one 256-thread
+// workgroup: the 8 dot products in a fixed order (thread t takes elements t + 256 i, wave shuffle tree, 4 partials summed by thread 0),
+// geometry in double.  Shared by block_fc_dlt_kernel (one workgroup per pair) and by the small-batch prep kernels, every workgroup of
+// which recomputes its pair's homography instead of waiting for a launch of its own (FcArgs below): the same instructions in the same
+// order, so the two paths agree bit for bit.  Result: hout[9] (fp32, in LDS); prior != nullptr: H = DLT(p4 + prior) (the :129-130 case).
+__device__ __forceinline__ void fc_dlt_block(const float* __restrict__ f, const float* __restrict__ wfc, const float* __restrict__ bfc,
+                                             const float* __restrict__ H_in_b, float (*part)[8], float* hout) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < 20; i++) {
+        const int k = tid + 256 * i;
+        const float x = f[k];
+#pragma unroll
+        for (int o = 0; o < 8; o++) acc[o] = fmaf(x, wfc[o * 5120 + k], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        float v = acc[o];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) part[wave][o] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double dst[8], hb[9], hin[9], ho[9];
+        for (int o = 0; o < 8; o++) {
+            const float fc = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + bfc[o];
+            dst[o] = (double)(float)(p4(o) + (double)fc);
+        }
+        dlt_solve(dst, hb);
+        if (H_in_b) {
+            for (int i = 0; i < 9; i++) hin[i] = (double)H_in_b[i];
+            mat3_mul(hin, hb, ho);
+        } else {
+            for (int i = 0; i < 9; i++) ho[i] = hb[i];
+        }
+        for (int i = 0; i < 9; i++) hout[i] = (float)ho[i];
+    }
+}
+__device__ __forceinline__ void prior_dlt_block(const float* __restrict__ prior_b, float* hout) {     // dlt_kernel with add_corners
+    if (threadIdx.x == 0) {
+        double d[8], hb[9];
+        for (int k = 0; k < 8; k++) d[k] = (double)(float)(p4(k) + (double)prior_b[k]);
+        dlt_solve(d, hb);
+        for (int k = 0; k < 9; k++) hout[k] = (float)hb[k];
+    }
+}
+
 // prep with warp, LDS-tiled: AvgPool_K(cat(img1, warp(img2, H))) -> NHWC [B][224/K][320/K][2].
 // Lane = column of the tile, wave w = rows 8w .. 8w+7, eight pixels of one column per thread: the taps of a wave are
 // (nearly) consecutive LDS words, the K = 1 stores are 512 contiguous bytes per wave and row.  Pooling: the rows of a
 // window are summed in the thread, its columns across lanes (xor 1, 2, 4); lane % K == 0 stores.
 // OUTS3 (K = 1 only): the block-4 input is written as bf16 planes with a zero border, [plane][B][B4_HP][B4_WP] dwords
 // (lo = img1, hi = warped img2 of one pixel), the layout the fused block-4 kernel stages by LDS-DMA (kernels.h B4_*)
-template <typename PIX, int K, bool OUTS3 = false>
+// FC (small batches only): H is not read from memory but recomputed by every workgroup from the previous block's trunk output (fc_dlt_block,
+// FcArgs) - the block-tail launch disappears from the dependent chain of a batch-1 forward; the first workgroup of a pair stores it.
+template <typename PIX, int K, bool OUTS3 = false, bool EXACT = true, bool FC = false>
 __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restrict__ img1, const PIX* __restrict__ img2,
                                                               const float* __restrict__ H, float* __restrict__ out,
-                                                              uint32_t* __restrict__ out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3) {
-    __shared__ float lut[256];                                          // only the per-pixel fallback path reads it
+                                                              uint32_t* __restrict__ out_s3 = nullptr, size_t s3_plane = 0, int n_planes = 3,
+                                                              FcArgs fc = FcArgs{}) {
     __shared__ __attribute__((aligned(16))) float reg[WT_CAP];
-    __shared__ __attribute__((aligned(16))) float a1[WT_H][WT_W];
-    if (PixRead<PIX>::kNeedLut) fill_lut(lut);
     constexpr int TX = IMG_W / WT_W, TY = IMG_H / WT_H, HO = IMG_H / K, WO = IMG_W / K;
     // XCD-aware tile order: consecutive workgroup ids run on different XCDs (private L2s) and the staged boxes of neighbouring tiles
     // overlap: with tile = workgroup id the warped image was fetched 2.4 times (FETCH_SIZE x 2: 89 MB for 37 MB of images)
@@ -228,25 +323,48 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     const int u0 = tx * WT_W, v0 = ty * WT_H;
     const PIX* i1 = img1 + (size_t)b * NPIX;
     const PIX* i2 = img2 + (size_t)b * NPIX;
-    float h[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
-#pragma unroll
-    for (int g = threadIdx.x; g < WT_H * WT_W / 4; g += 256) {          // img1 tile: 512 groups of 4 pixels
-        const int r = g >> 4, c = (g & 15) * 4;
-        *reinterpret_cast<float4*>(&a1[r][c]) = load_px4<PIX>(i1 + (v0 + r) * IMG_W + u0 + c);
-    }
-    const WarpBox bx = warp_stage_box<PIX>(i2, h, u0, v0, reg);
-    __syncthreads();
     const int lane = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
     const int u = u0 + lane;
+    float h[9];
+    if constexpr (FC) {
+        __shared__ float fc_part[4][8];
+        __shared__ float fc_h[9];
+        if (fc.feat) fc_dlt_block(fc.feat + (size_t)b * 5120, fc.wfc, fc.bfc, fc.H_in ? fc.H_in + b * 9 : nullptr, fc_part, fc_h);
+        else prior_dlt_block(fc.prior + b * 8, fc_h);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; i++) h[i] = fc_h[i];
+        if (tx == 0 && ty == 0 && threadIdx.x < 9) fc.H_out[b * 9 + threadIdx.x] = h[threadIdx.x];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
+    }
+    // round 3: the kernel was bound by its own dependent latencies (img1 tile -> LDS, then H -> box -> img2 box -> LDS, barrier: two global
+    // round trips in sequence at four workgroups per CU).  A thread's eight img1 pixels (one column of the tile: 64 consecutive bytes per
+    // wave and row) are now loaded straight into registers BEFORE the box is staged and are consumed after the barrier: one round trip,
+    // no LDS tile for img1 (28 instead of 37 KB per workgroup), no u8 -> f32 table.
+    PIX araw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) araw[i] = i1[(v0 + r0 + i) * IMG_W + u];
+    const WarpBox bx = warp_stage_box<PIX>(i2, h, u0, v0, reg);
+    __syncthreads();
     float a[8], w[8], fx[8], fy[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = PixRead<PIX>::cvt(araw[i]);
     uint32_t fb = 0;
-    if (bx.zsafe) {                                                     // workgroup-uniform: the shared-reciprocal division without its range test
+    if (!EXACT && bx.zsafe && bx.ok && bx.rows >= 2 && bx.pitch >= 2) {   // workgroup-uniform: the fast sampler (see warp_sample_box_fast)
+        const WarpFast wf = warp_fast_setup(bx);
+        const float fu = (float)u;
+        const float Xc = fmaf(h[0], fu, h[2]), Yc = fmaf(h[3], fu, h[5]), Zc = fmaf(h[6], fu, h[8]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float fv = (float)(v0 + r0 + i);
+            w[i] = warp_sample_box_fast(fmaf(h[1], fv, Xc), fmaf(h[4], fv, Yc), fmaf(h[7], fv, Zc), wf, bx.pitch, reg);
+        }
+    } else if (bx.zsafe) {                                              // workgroup-uniform: the shared-reciprocal division without its range test
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             bool f;
-            a[i] = a1[r0 + i][lane];
             w[i] = warp_sample_box<true>(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
             fb |= (uint32_t)f << i;
         }
@@ -254,7 +372,6 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             bool f;
-            a[i] = a1[r0 + i][lane];
             w[i] = warp_sample_box<false>(h, u, v0 + r0 + i, bx, reg, f, fx[i], fy[i]);
             fb |= (uint32_t)f << i;
         }
@@ -262,7 +379,7 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     if (__builtin_expect(__any(fb != 0), 0)) {                          // rare: taps outside the staged box -> direct gathers
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            if (fb & (1u << i)) w[i] = warp_taps_global<PIX>(i2, fx[i], fy[i], lut);
+            if (fb & (1u << i)) w[i] = warp_taps_global<PIX, false>(i2, fx[i], fy[i], nullptr);
     }
     if constexpr (K == 1 && OUTS3) {
 #pragma unroll
@@ -428,12 +545,13 @@ hipError_t launch_s3pad_to_f32_nhwc(const uint32_t* in, size_t s3_plane, float* 
 
 template <typename PIX>
 static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, int k, float* out, int batch, hipStream_t s,
-                                uint32_t* out_s3, size_t s3_plane, int n_planes) {
+                                uint32_t* out_s3, size_t s3_plane, int n_planes, bool exact) {
     if (out_s3) {     // block-4 input as padded bf16 planes (k = 1, with warp): the tiled kernel writes them directly
         if (k != 1 || !H) return hipErrorInvalidValue;
         if ((((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {
             const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
-            hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, out_s3, s3_plane, n_planes);
+            if (exact) hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1, true, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, out_s3, s3_plane, n_planes);
+            else hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1, true, false>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out, out_s3, s3_plane, n_planes);
             return hipGetLastError();
         }
         // unaligned images: direct-gather kernel into the fp32 buffer, then convert
@@ -441,19 +559,25 @@ static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, in
         hipLaunchKernelGGL(prep_k1_kernel<PIX>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, i1, i2, H, out, batch);
         return launch_f32_nhwc_to_s3pad(out, out_s3, s3_plane, batch, n_planes, s);
     }
-    static const bool tiled = !(std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 0);   // 0: direct-gather kernels
+    const bool tiled = !(std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 0);   // 0: direct-gather kernels
     // measured at batch 256 (ms, tiled vs direct): K=1 0.085 / 0.094, K=2 0.076 / 0.080, K=4 0.068 / 0.062 -> tiled for K <= 2
     // (HNET_PREP_TILED=2 forces it for every K: the parity tests run both)
-    static const bool tiled_all = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 2;
-    if (H && tiled && (k <= 2 || tiled_all) && (((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {   // 4-pixel groups: u8 4 B, f32 16 B loads
+    const bool tiled_all = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 2;
+    // the fast sampler exists in the tiled kernel only: with it the tiled kernel serves every K (HNET_PREP_TILED=1 keeps K >= 4 on the direct kernel)
+    const bool tiled_k2 = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 1;
+    if (H && tiled && (k <= 2 || tiled_all || (!exact && !tiled_k2)) && (((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {   // 4-pixel groups: u8 4 B, f32 16 B loads
         const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
+#define HNET_TILED(KK)                                                                                                                 \
+    if (exact) hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, false, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out);       \
+    else hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, false, false>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out);
         switch (k) {
-            case 1: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 1>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
-            case 2: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 2>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
-            case 4: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 4>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
-            case 8: hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, 8>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out); break;
+            case 1: HNET_TILED(1); break;
+            case 2: HNET_TILED(2); break;
+            case 4: HNET_TILED(4); break;
+            case 8: HNET_TILED(8); break;
             default: return hipErrorInvalidValue;
         }
+#undef HNET_TILED
         return hipGetLastError();
     }
     if (k == 1 && H) {
@@ -479,9 +603,37 @@ static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, in
 }
 
 hipError_t launch_prep(const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out,
-                       int batch, hipStream_t s, uint32_t* out_s3, size_t s3_plane, int n_planes) {
-    if (pix_fmt == HNET_PIX_U8) return prep_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes);
-    return prep_dispatch<float>((const float*)img1, (const float*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes);
+                       int batch, hipStream_t s, uint32_t* out_s3, size_t s3_plane, int n_planes, bool exact) {
+    if (pix_fmt == HNET_PIX_U8) return prep_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes, exact);
+    return prep_dispatch<float>((const float*)img1, (const float*)img2, H, k, out, batch, s, out_s3, s3_plane, n_planes, exact);
+}
+
+// small-batch form: the homography of each pair is recomputed by every workgroup of the tiled kernel from the previous block's trunk
+// output (or from the prior), see FcArgs / fc_dlt_block.  Tiled kernel only: needs 16-byte aligned images and K in {1 (padded planes), 2, 4}.
+bool prep_fc_supported(const void* img1, const void* img2, int k, bool has_out_s3) {
+    return ((((uintptr_t)img1 | (uintptr_t)img2) & 15) == 0) && ((k == 1 && has_out_s3) || k == 2 || k == 4);
+}
+template <typename PIX>
+static hipError_t prep_fc_dispatch(const PIX* i1, const PIX* i2, const FcArgs& fc, int k, float* out, int batch, hipStream_t s, uint32_t* out_s3,
+                                   size_t s3_plane, int n_planes, bool exact) {
+    const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
+#define HNET_TILED_FC(KK, S3)                                                                                                                        \
+    if (exact) hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, S3, true, true>), dim3(blocks), dim3(256), 0, s, i1, i2, (const float*)nullptr, out, out_s3, s3_plane, n_planes, fc); \
+    else hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, S3, false, true>), dim3(blocks), dim3(256), 0, s, i1, i2, (const float*)nullptr, out, out_s3, s3_plane, n_planes, fc);
+    switch (k) {
+        case 1: HNET_TILED_FC(1, true); break;
+        case 2: HNET_TILED_FC(2, false); break;
+        case 4: HNET_TILED_FC(4, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef HNET_TILED_FC
+    return hipGetLastError();
+}
+hipError_t launch_prep_fc(const void* img1, const void* img2, int pix_fmt, const FcArgs& fc, int k, float* out, int batch, hipStream_t s,
+                          uint32_t* out_s3, size_t s3_plane, int n_planes, bool exact) {
+    if (!prep_fc_supported(img1, img2, k, out_s3 != nullptr) || !fc.H_out || (!fc.feat && !fc.prior)) return hipErrorInvalidValue;
+    if (pix_fmt == HNET_PIX_U8) return prep_fc_dispatch<uint8_t>((const uint8_t*)img1, (const uint8_t*)img2, fc, k, out, batch, s, out_s3, s3_plane, n_planes, exact);
+    return prep_fc_dispatch<float>((const float*)img1, (const float*)img2, fc, k, out, batch, s, out_s3, s3_plane, n_planes, exact);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -596,41 +748,11 @@ __global__ __launch_bounds__(256) void block_fc_dlt_kernel(const float* __restri
                                                            const float* __restrict__ bfc, const float* __restrict__ H_in,
                                                            float* __restrict__ H_out) {
     __shared__ float part[4][8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* f = feat + (size_t)b * 5120;
-    float acc[8];
-#pragma unroll
-    for (int o = 0; o < 8; o++) acc[o] = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < 20; i++) {
-        const int k = tid + 256 * i;
-        const float x = f[k];
-#pragma unroll
-        for (int o = 0; o < 8; o++) acc[o] = fmaf(x, wfc[o * 5120 + k], acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < 8; o++) {
-        float v = acc[o];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        if (lane == 0) part[wave][o] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double dst[8], hb[9], hin[9], ho[9];
-        for (int o = 0; o < 8; o++) {
-            const float fc = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + bfc[o];
-            dst[o] = (double)(float)(p4(o) + (double)fc);
-        }
-        dlt_solve(dst, hb);
-        if (H_in) {
-            for (int i = 0; i < 9; i++) hin[i] = (double)H_in[b * 9 + i];
-            mat3_mul(hin, hb, ho);
-        } else {
-            for (int i = 0; i < 9; i++) ho[i] = hb[i];
-        }
-        for (int i = 0; i < 9; i++) H_out[b * 9 + i] = (float)ho[i];
-    }
+    __shared__ float hout[9];
+    const int b = blockIdx.x;
+    fc_dlt_block(feat + (size_t)b * 5120, wfc, bfc, H_in ? H_in + b * 9 : nullptr, part, hout);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 9; i++) H_out[b * 9 + i] = hout[i];
 }
 
 hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float* bfc, const float* H_in,
@@ -649,36 +771,27 @@ hipError_t launch_block_fc_dlt(const float* feat, const float* wfc, const float*
 // ---------------------------------------------------------------------------------------------
 constexpr int FC2_CHUNK = 4;
 
-__global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
-                                                        uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
-                                                        const uint64_t* __restrict__ seq_dev, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        float* __restrict__ mean_s, float* __restrict__ logvar_s, uint32_t* __restrict__ flag) {
-    __shared__ float w2s[4096];                  // [2][8][256]
-    __shared__ float hid[FC2_CHUNK * 512];       // after dropout
-    const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
-    const int b = blockIdx.x / n_chunks, c0 = (blockIdx.x % n_chunks) * FC2_CHUNK;
-    const int nc = min(FC2_CHUNK, n_local - c0);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
+// one chunk (up to FC2_CHUNK samples) of one pair by 256 threads (t = 0..255 inside the chunk's thread group); w2s [2][8][256] already staged;
+// hid / pre_row: this group's LDS slices.  Every thread of the workgroup must call it (workgroup barriers inside); nc <= 0: nothing stored.
+// The per-sample results go to mean_o / logvar_o [n_local][8] of the pair (global memory, or LDS in the merged kernel).
+__device__ __forceinline__ void heads_fc2_chunk(const float* __restrict__ hidden_b, int n_local, int s_begin, int c0, int nc, int t, uint32_t thr,
+                                                float scale, uint64_t key, const float* w2s, const float* __restrict__ b2, float* hid,
+                                                uint32_t* pre_row, float* mean_o, float* logvar_o, uint32_t* __restrict__ flag) {
     // the hash prefix of a (sample, head) row - four hnet_mix32 - once per row, not once per element
-    __shared__ uint32_t pre_row[FC2_CHUNK * 2];
-    if (tid < FC2_CHUNK * 2) {
-        const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
-        pre_row[tid] = hnet_mask_prefix(key, (uint32_t)(2 * (tid & 1) + 1), (uint32_t)(s_begin + c0 + (tid >> 1)));
-    }
+    if (t < FC2_CHUNK * 2) pre_row[t] = hnet_mask_prefix(key, (uint32_t)(2 * (t & 1) + 1), (uint32_t)(s_begin + c0 + (t >> 1)));
     __syncthreads();
-    for (int i = tid; i < FC2_CHUNK * 512; i += 256) {
+    for (int i = t; i < FC2_CHUNK * 512; i += 256) {
         const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
         float v = 0.0f;
         if (sl < nc) {
             const uint32_t pre = pre_row[sl * 2 + head];
-            const float x = hidden[((size_t)b * n_local + c0 + sl) * 512 + col];
+            const float x = hidden_b[(size_t)(c0 + sl) * 512 + col];
             v = hnet_mask_keep(pre, (uint32_t)j, thr) ? x * scale : 0.0f;
         }
         hid[i] = v;
     }
     __syncthreads();
-    const int d = tid >> 2, part = tid & 3;      // dot index (sample, output), quarter of the dot
+    const int d = t >> 2, part = t & 3;      // dot index (sample, output), quarter of the dot
     const int sl = d >> 4, o = d & 15, head = o >> 3, oi = o & 7;
     const float* hrow = hid + sl * 512 + head * 256 + part * 64;
     const float* wrow = w2s + (head * 8 + oi) * 256 + part * 64;
@@ -693,11 +806,28 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
     acc += __shfl_xor(acc, 2);
     if (part == 0 && sl < nc) {
         float v = acc + b2[head * 8 + oi];
-        float* dst = head == 0 ? mean_s : logvar_s;
+        float* dst = head == 0 ? mean_o : logvar_o;
         if (head == 1) v *= 1e-3f;
-        dst[((size_t)b * n_local + c0 + sl) * 8 + oi] = v;
+        dst[(size_t)(c0 + sl) * 8 + oi] = v;
         if (flag && !(fabsf(v) <= 3.0e38f)) atomicOr(flag, 1u);       // hnet_overflow_flag: a non-finite per-sample output (the *_partial path ends here)
     }
+}
+
+__global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict__ hidden, int n_local, int s_begin,
+                                                        uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
+                                                        const uint64_t* __restrict__ seq_dev, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ mean_s, float* __restrict__ logvar_s, uint32_t* __restrict__ flag) {
+    __shared__ float w2s[4096];                  // [2][8][256]
+    __shared__ float hid[FC2_CHUNK * 512];       // after dropout
+    __shared__ uint32_t pre_row[FC2_CHUNK * 2];
+    const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
+    const int b = blockIdx.x / n_chunks, c0 = (blockIdx.x % n_chunks) * FC2_CHUNK;
+    const int nc = min(FC2_CHUNK, n_local - c0);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) w2s[i] = w2[i];
+    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
+    heads_fc2_chunk(hidden + (size_t)b * n_local * 512, n_local, s_begin, c0, nc, tid, thr, scale, key, w2s, b2, hid, pre_row,
+                    mean_s + (size_t)b * n_local * 8, logvar_s + (size_t)b * n_local * 8, flag);
 }
 
 hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
@@ -721,13 +851,10 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     hi = __shfl_xor(hi, m);
     return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
-                                                       const float* __restrict__ H1, int batch, float* __restrict__ mean,
-                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag) {
-    const int t = threadIdx.x, i = t & 7, c = t >> 3;
-    const int b = blockIdx.x;
-    const float* ms = mean_s + (size_t)b * n * 8;
-    const float* lv = logvar_s + (size_t)b * n * 8;
+// the ensemble + transfer of ONE pair by one wave (t = lane); ms / lv: the pair's per-sample outputs [n][8] (global memory or LDS)
+__device__ __forceinline__ void mc_finish_wave(const float* ms, const float* lv, int n, const float* __restrict__ H1_b, float* __restrict__ mean_b,
+                                               float* __restrict__ cov_b, float* __restrict__ Htot_b, uint32_t* __restrict__ flag, int t) {
+    const int i = t & 7, c = t >> 3;
     double sm = 0, sv = 0;
     for (int s = c; s < n; s += 8) {
         sm += (double)ms[s * 8 + i];
@@ -742,21 +869,84 @@ __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__
     for (int m = 8; m < 64; m <<= 1) se += shfl_xor_f64(se, m);
     const double en = (double)(float)((double)(float)(se / n) + (double)vb);
     const double pb = (double)(float)(p4(i) + (double)mb);
-    double pbar[8], ens[8];
+    auto bcast = [](double v, int src) { return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src)); };
+    double pbar[8];                                // every lane: the eight corner coordinates (lane 4 solves the DLT with them)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        pbar[k] = __hiloint2double(__shfl(__double2hiint(pb), k), __shfl(__double2loint(pb), k));
-        ens[k] = __hiloint2double(__shfl(__double2hiint(en), k), __shfl(__double2loint(en), k));
+    for (int k = 0; k < 8; k++) pbar[k] = bcast(pb, k);
+    // lane c < 4 works on corner c: its coordinates and ensemble variances come from lanes 2c, 2c + 1 (no lane-indexed arrays)
+    const int cs = 2 * (t & 3);
+    const double pu = bcast(pb, cs), pv = bcast(pb, cs + 1), vu = bcast(en, cs), vv = bcast(en, cs + 1);
+    // transfer + assembly (geom.h transfer_pair), spread over the wave: lane c < 4 takes corner c (its two means and its 2 x 2 covariance
+    // block), lane 4 the total homography, all 64 lanes the zero fill of the block-diagonal 8 x 8 matrix.  Same formulas per entry as the
+    // one-thread form (the CPU restatement of the tests evaluates that one).
+    double H1[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) H1[k] = (double)H1_b[k];
+    const bool diag = ((t >> 3) >> 1) == ((t & 7) >> 1);           // entry (row t >> 3, column t & 7) lies in a 2 x 2 diagonal block
+    if (!diag) cov_b[t] = 0.0f;
+    bool bad = false;
+    if (t < 4) {
+        const int c = t;
+        const double X = H1[0] * pu + H1[1] * pv + H1[2];
+        const double Y = H1[3] * pu + H1[4] * pv + H1[5];
+        const double S = H1[6] * pu + H1[7] * pv + H1[8];
+        const float m0 = (float)(X / S - p4(2 * c)), m1 = (float)(Y / S - p4(2 * c + 1));
+        const double g00 = H1[0] / S, g01 = H1[1] / S, g10 = H1[3] / S, g11 = H1[4] / S;
+        const float c00 = (float)(g00 * vu * g00 + g01 * vv * g01), c01 = (float)(g00 * vu * g10 + g01 * vv * g11);
+        const float c10 = (float)(g10 * vu * g00 + g11 * vv * g01), c11 = (float)(g10 * vu * g10 + g11 * vv * g11);
+        mean_b[2 * c] = m0; mean_b[2 * c + 1] = m1;
+        cov_b[(2 * c) * 8 + 2 * c] = c00; cov_b[(2 * c) * 8 + 2 * c + 1] = c01;
+        cov_b[(2 * c + 1) * 8 + 2 * c] = c10; cov_b[(2 * c + 1) * 8 + 2 * c + 1] = c11;
+        bad = !(fabsf(m0) <= 3.0e38f && fabsf(m1) <= 3.0e38f && fabsf(c00) <= 3.0e38f && fabsf(c01) <= 3.0e38f && fabsf(c10) <= 3.0e38f &&
+                fabsf(c11) <= 3.0e38f);
+    } else if (t == 4 && Htot_b) {
+        double Hb[9], Ht[9];
+        dlt_solve(pbar, Hb);
+        mat3_mul(H1, Hb, Ht);
+        for (int k = 0; k < 9; k++) Htot_b[k] = (float)Ht[k];
     }
-    if (t == 0) {
-        transfer_pair(pbar, ens, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr);
-        if (flag) {                                  // hnet_overflow_flag: any non-finite output of this pair (the 8 x 8 covariance is block diagonal:
-            bool bad = false;                        // its 2 x 2 blocks hold every non-zero entry)
-            for (int k = 0; k < 8; k++) bad = bad || !(fabsf(mean[b * 8 + k]) <= 3.0e38f);
-            for (int k = 0; k < 64; k++) bad = bad || !(fabsf(cov[b * 64 + k]) <= 3.0e38f);
-            if (bad) atomicOr(flag, 1u);
-        }
+    if (flag && bad) atomicOr(flag, 1u);           // hnet_overflow_flag: a non-finite output of this pair
+}
+__global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
+                                                       const float* __restrict__ H1, int batch, float* __restrict__ mean,
+                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag) {
+    const int b = blockIdx.x;
+    mc_finish_wave(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + b * 8, cov + b * 64,
+                   Htot ? Htot + b * 9 : nullptr, flag, threadIdx.x);
+}
+
+// Small batches (latency path): second FC of the heads for ALL samples of a pair and the ensemble in ONE launch, one 1024-thread workgroup
+// per pair: four 256-thread groups each take a chunk of FC2_CHUNK samples per round (heads_fc2_chunk, same arithmetic as heads_fc2_kernel),
+// the per-sample outputs stay in LDS, wave 0 finishes the pair (mc_finish_wave): bit-identical to the two launches it replaces.
+constexpr int FC2M_MAX_N = 64;
+__global__ __launch_bounds__(1024) void heads_fc2_finish_kernel(const float* __restrict__ hidden, int n_local, int s_begin, uint32_t thr, float scale,
+                                                                uint64_t mc_seed, uint64_t pair_seq0, const uint64_t* __restrict__ seq_dev,
+                                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                const float* __restrict__ H1, float* __restrict__ mean, float* __restrict__ cov,
+                                                                float* __restrict__ Htot, uint32_t* __restrict__ flag) {
+    __shared__ float w2s[4096];
+    __shared__ float hid[4][FC2_CHUNK * 512];
+    __shared__ uint32_t pre_row[4][FC2_CHUNK * 2];
+    __shared__ float ms_l[FC2M_MAX_N * 8], lv_l[FC2M_MAX_N * 8];
+    const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
+    for (int i = tid; i < 4096; i += 1024) w2s[i] = w2[i];
+    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
+    const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
+    for (int r = 0; r * 4 < n_chunks; r++) {                       // (the first barrier inside heads_fc2_chunk also covers the w2s fill)
+        const int c0 = (r * 4 + grp) * FC2_CHUNK;
+        heads_fc2_chunk(hidden + (size_t)b * n_local * 512, n_local, s_begin, c0, min(FC2_CHUNK, n_local - c0), t, thr, scale, key, w2s, b2, hid[grp],
+                        pre_row[grp], ms_l, lv_l, nullptr);
     }
+    __syncthreads();
+    if (tid < 64) mc_finish_wave(ms_l, lv_l, n_local, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr, flag, tid);
+}
+hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed, uint64_t pair_seq0, const float* w2,
+                                   const float* b2, const float* H1, float* mean, float* cov, float* Htot, hipStream_t s, const uint64_t* seq_dev,
+                                   uint32_t* flag) {
+    if (n_local < 1 || n_local > FC2M_MAX_N) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(heads_fc2_finish_kernel, dim3((unsigned)batch), dim3(1024), 0, s, hidden, n_local, s_begin, hnet_drop_threshold(p), 1.0f / (1.0f - p),
+                       mc_seed, pair_seq0, seq_dev, w2, b2, H1, mean, cov, Htot, flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,

@@ -133,7 +133,7 @@ int hnet_image_count(const hnet_ctx* ctx);             /* the public `img_counte
  * kernel blends with the exact products (32 - fx)(32 - fy) ... fx fy / 1024 and rounds half up: same sample positions, same four
  * taps, a result that can differ by ONE grey level where the exact blend sits within 2^-10 of a rounding boundary; and OpenCV's maps
  * pass through its fixed-point convertMaps, whose rounding of positions exactly half way between two 1/32-px steps may pick the other
- * step (again <= one grey level at a unit gradient).  What IS pinned: bit-exactness against oracle/undistort_oracle.py, four analytic
+ * step (again <= one grey level at a unit gradient).  What IS pinned: bit-exactness against the numpy restatement under tests (see tests/test_undistort.py), four analytic
  * map properties, and an end-to-end property independent of the restated formulas - the remap of an independently simulated fisheye
  * photograph of an analytic scene recovers the scene to 0.34 grey levels RMS, 1.0 max (tests/test_undistort.py). */
 typedef struct hnet_camera {
@@ -198,7 +198,9 @@ int hnet_time_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr
 
 /* Per-stage device timing: a "stage" is one kernel launch of the forward (prep / conv layer / fc+DLT / heads).
  * hnet_profile_batch_device runs `iters` forwards with a HIP event after every launch on the context's stream
- * and returns the average milliseconds per stage ([hnet_stage_count] floats).  flops_per_pair = 2 x MACs. */
+ * and returns the average milliseconds per stage ([hnet_stage_count] floats).  flops_per_pair = 2 x MACs.  The stage list is that of a
+ * forward of max_batch pairs until a profile call names another batch: batches <= 8 take the latency path, which has fewer launches
+ * (never more than the max_batch list), and hnet_stage_count / _name then describe the batch last profiled. */
 int hnet_stage_count(const hnet_ctx* ctx);
 const char* hnet_stage_name(const hnet_ctx* ctx, int i);
 double hnet_stage_flops_per_pair(const hnet_ctx* ctx, int i);

@@ -103,7 +103,7 @@ def test_activations_up_to_32768_are_carried_exactly_and_beyond_that_are_detecte
     for amp, must_be_finite in ((30000.0, True), (40000.0, False)):
         x = (rng.uniform(0.6, 1.0, (1, 64, 28, 40)) * amp * rng.choice([-1.0, 1.0], (1, 64, 28, 40))).astype(np.float32)
         got = e.op_conv(layer, x)
-        ref = pyoracle.conv_lrelu(x, state["model_part1.block_2_2.0.weight"], state["model_part1.block_2_2.0.bias"], 2)
+        ref = pyoracle.conv_lrelu(x[0], state["model_part1.block_2_2.0.weight"], state["model_part1.block_2_2.0.bias"], 2)[None]
         fin = np.isfinite(got)
         if must_be_finite:
             assert fin.all()

@@ -1,0 +1,81 @@
+"""The latency path (batch <= 8): the block-tail launch (FC 5120 -> 8 + DLT + composition) and the prior's DLT are recomputed inside the next
+block's prep kernel, heads_fc2 + mc_finish run as one launch (csrc/hnet_capi.hip forward_chunk, kernels.h FcArgs).  Same instructions in the
+same order: the outputs must be BITWISE those of the multi-launch path (HNET_FUSE_SMALL=0), in every arithmetic mode and variant."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(blob, fuse, **kw):
+    from cuahn_vio_amd.homography_net import HnetEngine
+    old = os.environ.get("HNET_FUSE_SMALL")
+    os.environ["HNET_FUSE_SMALL"] = "1" if fuse else "0"
+    try:
+        return HnetEngine(blob, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("HNET_FUSE_SMALL", None)
+        else:
+            os.environ["HNET_FUSE_SMALL"] = old
+
+
+@pytest.mark.parametrize("precision", [pytest.param(3, id="f16x2"), pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")])
+@pytest.mark.parametrize("variant,n_mc,batch", [("full", 32, 1), ("prior3", 16, 1), ("prior2", 16, 3), ("prior1", 64, 2), ("full", 16, 8), ("prior3", 5, 7)])
+def test_latency_path_is_bitwise_the_multi_launch_path(blob, oracle, variant, n_mc, batch, precision):
+    from conftest import TOL_PX_VS_ORACLE
+    from cuahn_vio_amd import synth
+    prev, curr, prior, _ = synth.make_batch(500 + batch, batch)
+    pr = None if variant == "full" else prior
+    kw = dict(variant=variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=11, max_batch=8, emit_error_map=True, precision=precision)
+    outs = []
+    for fuse in (True, False):
+        e = _engine(blob, fuse, **kw)
+        mean, cov, err = e.infer_batch(prev, curr, pr, pair_seq0=77, want_err=True)
+        h1 = np.stack([e.debug_h_part1(b) for b in range(batch)])
+        names = [n for n, _f in e.stages()]
+        e.close()
+        outs.append((mean, cov, err, h1, names))
+    (m1, c1, e1, h1, n1), (m0, c0, e0, h0, n0) = outs
+    assert np.array_equal(m1, m0) and np.array_equal(c1, c0) and np.array_equal(e1, e0) and np.array_equal(h1, h0)
+    # and it is the right answer
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    o = oracle.forward(prev[0], curr[0], None if pr is None else pr[0], btr, n_mc, 0.05, 11, 77)
+    assert np.abs(m1[0] - o["mean"]).max() < TOL_PX_VS_ORACLE
+    # fewer launches: no block-tail / prior-DLT stage of its own, one heads tail
+    # (exact-fp32 mode: block 4's prep does not write the padded planes the fused form needs, so its block-tail launch stays)
+    own = [n for n in n1 if n.startswith("fc_dlt_b") or n == "prior_dlt"]
+    assert (own == [] or (precision == 0 and own in (["fc_dlt_b3"], ["prior_dlt"]))) and "heads_fc2+mc_finish" in n1
+    assert len(n1) < len(n0)
+
+
+def test_streaming_class_uses_the_latency_path_and_matches(blob):
+    """hnet_infer (graph replay of the batch-1 forward) through the class surface: fused and unfused contexts give the same bits"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HomographyNet
+    import contextlib
+    import io
+    frames = [synth.make_pair(900 + i)[0] for i in range(4)]
+    res = []
+    for fuse in ("1", "0"):
+        old = os.environ.get("HNET_FUSE_SMALL")
+        os.environ["HNET_FUSE_SMALL"] = fuse
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                net = HomographyNet("x_showError.hnw", use_prior=True, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=3, weights_blob=blob)
+                got = []
+                for i, f in enumerate(frames):
+                    net.load_current_img(f, float(i))
+                    net.network_inference(np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.25, 2.0, -0.75]), 0)
+                    if i:
+                        got.append((net._pred_mean.copy(), net._pred_Cov.copy(), net.last_error_map.copy()))
+        finally:
+            if old is None:
+                os.environ.pop("HNET_FUSE_SMALL", None)
+            else:
+                os.environ["HNET_FUSE_SMALL"] = old
+        res.append(got)
+    for (m1, c1, e1), (m0, c0, e0) in zip(*res):
+        assert np.array_equal(m1, m0) and np.array_equal(c1, c0) and np.array_equal(e1, e0)
