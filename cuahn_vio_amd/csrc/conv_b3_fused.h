@@ -1,0 +1,252 @@
+// conv_b3_fused.h — block_3_0 (7x7 s1, 2 -> 16 @112x160) and block_3_1 (5x5 s2, 16 -> 32 -> 56x80) in ONE kernel
+// (reference model_to_trace.py:108-109, :171-178 via conv() :7-15).  Round 3; fp16-plane arithmetic (HNET_PREC_F16X2) only.
+//
+// Unfused, block_3_0 writes its 16-channel map (294 MB per 256 pairs as two fp16 planes) and block_3_1 reads it straight back:
+// 0.086 + 0.129 ms per step, both at 3.4 TB/s.  Here a workgroup owns an 8 x 16 tile of block_3_1 outputs:
+//   phase 0  the (2*8 + 9) x 41-pixel input patch of the tile (fp32 NHWC [B][112][160][2] from the block's prep kernel) is split into
+//            fp16 planes and staged in LDS (zero outside the image = block_3_0's zero padding); the NEXT tile's patch is prefetched
+//            into registers while this one computes
+//   phase 1  block_3_0 on the 19 x 35 region the tile needs: the pixel-pair GEMM of conv_first.h (M = 2 region rows x 16 pairs of
+//            adjacent pixels, N = (pixel-in-pair, cout) = 32, one v_mfma_f32_32x32x16_f16 group per kernel row: K = 8 taps x 2 ch),
+//            bias + LeakyReLU, zero outside the 112 x 160 image (= block_3_1's zero padding), split into planes and written to LDS
+//            as 32-byte pixels [plane][row][column parity][column / 2][16 ch]
+//   phase 2  block_3_1 straight from that LDS image: transposed 16x16x32 tiles (weights as the A operand, held in VGPRs): an M-tile
+//            is one output row of the tile (16 pixels), a 32-deep K step is two filter taps x 16 channels (13 steps for the 25 taps);
+//            wave w owns output channels 16 (w & 1) .. +15 and the four rows (w >> 1) + 2 j, which it advances TOGETHER through the K
+//            loop (the weight fragment of a step is used four times); output as fp16 planes, 8 bytes per lane and plane.
+// The 16-channel intermediate never touches HBM.  Workgroups are persistent (the 160 weight registers of a lane are loaded once).
+//
+// Arithmetic: the two-plane / two-accumulator form of the implicit-GEMM kernels (igemm_s3.h): w = W0 + W1 / 4096, a = A0 + A1 / 4096,
+// hi += W0 A0, lo += W1 A0 + W0 A1, result = hi + lo / 4096 (three fp16 MFMAs per product, fp32 accumulation; the weights of both
+// layers fit the register file in two planes, not in three).
+//
+// LDS reads of phase 2 are conflict free by layout: a ds_read_b128 is served in four passes of 16 lanes - pixels {0-3, 12-15} of lane
+// group g with pixels {4-11} of group g + 1 - and with 32-byte pixels group g reads even 16-byte slots, group g + 1 (the other channel
+// half, or the next tap: an even number of slots away, plus one) odd ones.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "igemm_s3.h"
+#include "kernels.h"
+
+namespace hnet {
+
+struct B3Cfg {
+    static constexpr int TH = 8, TW = 16, THREADS = 256;
+    static constexpr int H0 = 112, W0 = 160, H1 = 56, W1 = 80, C0 = 16, C1 = 32;
+    static constexpr int RH = 2 * TH + 3, RW = 2 * TW + 3;       // block_3_0 region of a tile: 19 x 35
+    static constexpr int PH = 26, PW = 44;                       // input patch rows (RH + 6 = 25, + 1: the M-tiles cover row pairs) x pixels
+    static constexpr int PROWB = PW * 4;                         // bytes per patch row and plane (one dword = both channels of a pixel)
+    static constexpr int PPLANEB = PH * PROWB;
+    static constexpr int XH = 18;                                // pixels per (row, parity): ceil(35 / 2)
+    static constexpr int IROWB = 2 * XH * 32;                    // bytes per image row and plane
+    static constexpr int IPLANEB = RH * IROWB;
+    static constexpr int NP = 2;
+    static constexpr int LDS_BYTES = NP * (PPLANEB + IPLANEB);
+    static constexpr int TILES_X = W1 / TW, TILES_Y = H1 / TH;   // 5 x 7 tiles per pair
+    static constexpr int N_MT0 = 12;                             // phase-1 M-tiles: 10 row pairs + 2 tiles for the pairs of columns 32..34
+    static constexpr int NSTEP1 = 13;                            // phase-2 K steps (two taps each; the 26th tap has zero weights)
+    static_assert(W1 % TW == 0 && H1 % TH == 0, "tiles cover the 56 x 80 output exactly");
+};
+
+// w0frag: [7 kernel rows][2 planes][64 lanes] x 16 B: lane (n = l & 31 = (dx, co), hh = l >> 5) holds kk = 8 hh .. 8 hh + 7 of
+//         W'[kh][kk = 2 kw' + ci][n] = W[co][ci][kh][kw' - dx]   (conv_first.h; planes of the activation split, s3_format.h split2h)
+// w1frag: [2 n-tiles][13 steps][2 planes][64 lanes] x 16 B: lane (i = l & 15, g = l >> 4) holds output channel 16 nt + i, tap 2 st + (g >> 1),
+//         input channels 8 (g & 1) .. + 7
+template <int NP>
+__global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
+                                                              const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
+                                                              const float* __restrict__ bias1, uint16_t* __restrict__ out16, size_t o_plane,
+                                                              int n_tiles) {
+    static_assert(NP == 2, "two fp16 planes (HNET_PREC_F16X2): the other modes run the two layers unfused");
+    typedef B3Cfg C;
+    constexpr int H0 = C::H0, W0 = C::W0, H1 = C::H1, W1 = C::W1, TH = C::TH, TW = C::TW, RH = C::RH, PH = C::PH, PW = C::PW;
+    constexpr int PROWB = C::PROWB, PPLANEB = C::PPLANEB, XH = C::XH, IROWB = C::IROWB, IPLANEB = C::IPLANEB;
+    typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char* const patch = lds_raw;                               // [2 planes][PH][PW] dwords
+    unsigned char* const img = lds_raw + 2 * PPLANEB;                   // [2 planes][RH][2 parities][XH][16 ch] fp16
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weights -> registers, once per (persistent) workgroup
+    f16x8 w0[7][2], w1[C::NSTEP1][2];
+#pragma unroll
+    for (int kh = 0; kh < 7; kh++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) w0[kh][pl] = __builtin_bit_cast(f16x8, w0frag[(kh * 2 + pl) * 64 + lane]);
+    const int nt = wave & 1;                                            // phase 2: this wave's half of the 32 output channels
+#pragma unroll
+    for (int st = 0; st < C::NSTEP1; st++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) w1[st][pl] = __builtin_bit_cast(f16x8, w1frag[((nt * C::NSTEP1 + st) * 2 + pl) * 64 + lane]);
+
+    // phase-1 lane roles (32x32x16, weights as A operand: D row = n = (dx, co), D column = pixel pair of the M-tile)
+    const int pcol = lane & 31, hh = lane >> 5, prow = pcol >> 4, pair = pcol & 15;
+    float bv0[4][4];                                                    // D row (r & 3) + 8 (r >> 2) + 4 hh = n: group q = r >> 2, n = 8 q + 4 hh + i
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) bv0[q][i] = bias0[(8 * q + 4 * hh + i) & 15];
+    // phase-2 lane roles (16x16x32 transposed: D row 4 g + r = output channel, D column m = pixel of the output row)
+    const int m = lane & 15, g = lane >> 4;
+    float bv1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv1[r] = bias1[16 * nt + 4 * g + r];
+    // lane part of the phase-2 read addresses: step st, tap t = 2 st + (g >> 1) = (kh, kw): pixel (2 oy + kh, 2 m + kw) of the image,
+    // channel half g & 1;  (t = 25 has zero weights: any valid address)
+    uint32_t p2off[C::NSTEP1];
+#pragma unroll
+    for (int st = 0; st < C::NSTEP1; st++) {
+        const int t = min(2 * st + (g >> 1), 24);
+        const int kh = t / 5, kw = t - 5 * kh;
+        p2off[st] = (uint32_t)(kh * IROWB + ((kw & 1) * XH + m + (kw >> 1)) * 32 + 16 * (g & 1));
+    }
+    int hi4 = 8;                                                        // opaque byte offset: two ds_read_b64 instead of one ds_read2_b64 (conv_first.h)
+    asm volatile("" : "+v"(hi4));
+
+    // ---- patch prefetch (registers): unconditional float2 loads from a clamped address, zero selected when consumed
+    constexpr int PPT = (PH * PW + 255) / 256;
+    float2 px[PPT];
+    uint32_t okbits = 0;
+    auto tile_origin = [&](int t, int& b, int& ty, int& tx) {
+        int bid = s3p::xcd_tile(t, n_tiles, gridDim.x);
+        tx = bid % C::TILES_X; bid /= C::TILES_X;
+        ty = bid % C::TILES_Y;
+        b = bid / C::TILES_Y;
+    };
+    auto patch_load = [&](int t) {
+        int b, ty, tx;
+        tile_origin(t, b, ty, tx);
+        const int Py0 = 2 * ty * TH - 5, Px0 = 2 * tx * TW - 5;         // input pixel of patch (0, 0): region origin (2 ty0 - 2, 2 tx0 - 2) minus the 7x7 halo
+        const float* inb = x_in + (size_t)b * H0 * W0 * 2;
+        okbits = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = min(tid + q * 256, PH * PW - 1);
+            const int pr = i / PW, pc = i - pr * PW;
+            const int iy = Py0 + pr, ix = Px0 + pc;
+            const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
+            px[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W0 + ix) * 2 : 0));
+            okbits |= ok ? (1u << q) : 0u;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        const int Ry0 = 2 * ty0 - 2, Rx0 = 2 * tx0 - 2;                 // image coordinates of region pixel (0, 0)
+
+        // ---- phase 0: the prefetched patch -> fp16 planes in LDS
+        __syncthreads();                                                // the previous tile is done with the patch and the image
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = tid + q * 256;
+            if (i < PH * PW) {
+                const bool ok = (okbits >> q) & 1u;
+                uint32_t pk[3];
+                s3p::split_pair<2>(ok ? px[q].x : 0.f, ok ? px[q].y : 0.f, pk);
+                *reinterpret_cast<uint32_t*>(patch + i * 4) = pk[0];
+                *reinterpret_cast<uint32_t*>(patch + PPLANEB + i * 4) = pk[1];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
+
+        // ---- phase 1: block_3_0 over the region -> LDS image.  M-tile mt < 10: region rows 2 mt, 2 mt + 1, pixel pairs 0..15;
+        //      mt = 10, 11: the pairs 16, 17 (columns 32..35) of all rows, 32 (row, pair) combinations each
+#pragma unroll 1
+        for (int j = 0; j < C::N_MT0 / 4; j++) {
+            const int mt = wave + 4 * j;                                // wave-uniform
+            int row, pr2;                                               // this lane's region row and pixel pair
+            if (mt < 10) { row = 2 * mt + prow; pr2 = pair; }
+            else { const int idx = (mt - 10) * 32 + pcol; row = idx >> 1; pr2 = 16 + (idx & 1); }
+            const bool row_ok = row < RH;
+            const int rrow = row_ok ? row : RH - 1;                     // (rows beyond the region: reads stay inside the patch, nothing is stored)
+            f32x16 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { hi[r] = bv0[r >> 2][r & 3]; lo[r] = 0.f; }
+            const unsigned char* abase = patch + rrow * PROWB + pr2 * 8 + 16 * hh;
+#pragma unroll
+            for (int kh = 0; kh < 7; kh++) {
+                f16x8 a[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {                        // 8 fp16 = 4 taps x 2 ch, 8-byte aligned
+                    const unsigned char* src = abase + pl * PPLANEB + kh * PROWB;
+                    const bf16x4_t l4 = *reinterpret_cast<const bf16x4_t*>(src);
+                    const bf16x4_t h4 = *reinterpret_cast<const bf16x4_t*>(src + hi4);
+                    a[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][0], a[1], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][1], a[0], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][0], a[0], hi, 0, 0, 0);
+            }
+            // D row 8 q + 4 hh + i = (dx = q >> 1, co = 8 (q & 1) + 4 hh + i): a lane holds four consecutive channels of pixel 2 pr2 + dx
+            const int iy = Ry0 + row;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int dx = q >> 1, col = 2 * pr2 + dx;
+                const bool ok = (unsigned)iy < (unsigned)H0 && (unsigned)(Rx0 + col) < (unsigned)W0;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float s = fmaf(lo[4 * q + i], S3_F16_INV, hi[4 * q + i]);
+                    v[i] = ok ? s3p::lrelu(s) : 0.f;
+                }
+                uint32_t pa[3], pb[3];
+                s3p::split_pair<2>(v[0], v[1], pa);
+                s3p::split_pair<2>(v[2], v[3], pb);
+                if (row_ok && pr2 < XH) {
+                    unsigned char* dst = img + ((row * 2 + dx) * XH + pr2) * 32 + (8 * (q & 1) + 4 * hh) * 2;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);
+                    *reinterpret_cast<uint2*>(dst + IPLANEB) = make_uint2(pa[1], pb[1]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: block_3_1 from the LDS image.  This wave: channels 16 nt .. + 15, output rows (wave >> 1) + 2 j (j = 0..3) together
+        {
+            f32x4_m16 hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                hi[j] = f32x4_m16{bv1[0], bv1[1], bv1[2], bv1[3]};
+                lo[j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+            }
+            const unsigned char* ibase = img + (2 * (wave >> 1)) * IROWB;    // image row 2 oy of the first output row of this wave
+#pragma unroll
+            for (int st = 0; st < C::NSTEP1; st++) {
+                f16x8 a[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int pl = 0; pl < 2; pl++)
+                        a[j][pl] = *reinterpret_cast<const f16x8*>(ibase + p2off[st] + j * 4 * IROWB + pl * IPLANEB);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    lo[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a[j][1], lo[j], 0, 0, 0);
+                    lo[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][1], a[j][0], lo[j], 0, 0, 0);
+                    hi[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a[j][0], hi[j], 0, 0, 0);
+                }
+            }
+            // D (transposed): row 4 g + r = output channel 16 nt + 4 g + r, column m = pixel: 8 bytes (4 channels) per lane and plane
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int oy = (wave >> 1) + 2 * j;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = s3p::lrelu(fmaf(lo[j][r], S3_F16_INV, hi[j][r]));
+                uint32_t pa[3], pb[3];
+                s3p::split_pair<2>(v[0], v[1], pa);
+                s3p::split_pair<2>(v[2], v[3], pb);
+                uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
+                *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
+                *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);
+            }
+        }
+    }   // persistent tile loop
+}
+
+}  // namespace hnet

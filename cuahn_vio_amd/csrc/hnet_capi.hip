@@ -100,6 +100,9 @@ struct hnet_ctx {
     int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
+    bool fuse_b3 = false;              // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h): fp16-plane mode, HNET_FUSE_B3=0 switches back
+    uint16_t* b3f_w0 = nullptr;        // its weights: block_3_0 as [7][2][64] x 16 B fragments (two planes), block_3_1 as [2][13][2][64] x 16 B
+    uint16_t* b3f_w1 = nullptr;
     bool fuse_small = true;            // batch <= 8 (latency path): block-tail FC + DLT inside the next block's prep kernel, heads_fc2 + mc_finish in one launch (HNET_FUSE_SMALL=0: the separate launches; bit-identical)
     float* Hm2 = nullptr;              // second homography buffer of that path (a prep workgroup stores H while others still read the previous one)
     const float* H_last = nullptr;     // where the last forward left H_part1 (Hm or Hm2)
@@ -267,6 +270,13 @@ void build_stages(hnet_ctx* c, int batch) {
             std::string nm = kConvs[l].name;
             h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
             w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
+            if (c->fuse_b3 && l == 7) {        // one launch for block_3_0 + block_3_1
+                fl += conv_flops(8, h, w);
+                nm = "block_3_0+3_1";
+                h = conv_out_dim(h, kConvs[8].ks, kConvs[8].stride);
+                w = conv_out_dim(w, kConvs[8].ks, kConvs[8].stride);
+                l = 8;
+            }
             if (c->fuse_b4 && l == 13) {       // one launch for block_4_0 + block_4_1
                 fl += conv_flops(14, h, w);
                 nm = "block_4_0+4_1";
@@ -377,6 +387,15 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 l = 14;
                 continue;
             }
+            if (c->fuse_b3 && l == 7 && c->n_planes == 2 && c->b3f_w0 && c->b3f_w1 && h == 112 && w == 160) {   // block_3_0 + block_3_1 in one launch
+                const size_t cnt1 = c->act_count[8];
+                uint16_t* o16b = c->act16[8] + P0 * cnt1;
+                STAGE(launch_block3_fused(in, c->b3f_w0, c->conv_b[7], c->b3f_w1, c->conv_b[8], o16b, MB * cnt1, B, s, c->n_planes));
+                in = nullptr; in16 = o16b; in_plane = MB * cnt1;
+                h = c->act_h[8]; w = c->act_w[8];
+                l = 8;
+                continue;
+            }
             const size_t cnt = c->act_count[l];
             float* o = c->act[l] ? c->act[l] + P0 * cnt : nullptr;
             uint16_t* o16 = c->act16[l] ? c->act16[l] + P0 * cnt : nullptr;
@@ -485,7 +504,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
         auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
         for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); }
         for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
-        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16);
+        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1);
         fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
     }
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
@@ -538,8 +557,44 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                 }
             CK(hipMalloc((void**)&c->b30_frag, fr.size() * 2));
             CK(hipMemcpy(c->b30_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            if (c->n_planes == 2) {   // the same fragments in the two-plane form (w = W0 + W1 / 4096) of the fused block_3_0 + block_3_1 kernel
+                std::vector<uint16_t> f2((size_t)7 * 2 * 64 * 8, 0);
+                for (int kh = 0; kh < 7; kh++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int n = ln & 31, hh = ln >> 5, dx = n >> 4, co = n & 15;
+                        for (int j = 0; j < 8; j++) {
+                            const int kk = 8 * hh + j, kw = (kk >> 1) - dx, ci = kk & 1;
+                            if (kw < 0 || kw >= 7) continue;
+                            uint16_t a0, a1;
+                            split2h(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], a0, a1);
+                            f2[(((size_t)kh * 2 + 0) * 64 + ln) * 8 + j] = a0;
+                            f2[(((size_t)kh * 2 + 1) * 64 + ln) * 8 + j] = a1;
+                        }
+                    }
+                CK(hipMalloc((void**)&c->b3f_w0, f2.size() * 2));
+                CK(hipMemcpy(c->b3f_w0, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
+            }
             const char* e30 = getenv("HNET_B30_S3");
             c->b30_s3 = !(e30 && atoi(e30) == 0) || c->n_planes == 2;     // (the fp32-MFMA fallback writes bf16 planes: not in the fp16 mode)
+        }
+        if (c->s3 && l == 8 && c->n_planes == 2) {   // block_3_1 for the fused kernel: lane (i, g) of n-tile nt, step st: channel 16 nt + i, tap 2 st + (g >> 1), ci 8 (g & 1) + j
+            std::vector<uint16_t> f2((size_t)2 * 13 * 2 * 64 * 8, 0);
+            for (int nt = 0; nt < 2; nt++)
+                for (int st = 0; st < 13; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int co = 16 * nt + (ln & 15), gg = ln >> 4, t = 2 * st + (gg >> 1);
+                        if (t >= 25) continue;
+                        const int kh = t / 5, kw = t % 5;
+                        for (int j = 0; j < 8; j++) {
+                            const int ci = 8 * (gg & 1) + j;
+                            uint16_t a0, a1;
+                            split2h(w->data[(((size_t)co * 16 + ci) * 5 + kh) * 5 + kw], a0, a1);
+                            f2[((((size_t)nt * 13 + st) * 2 + 0) * 64 + ln) * 8 + j] = a0;
+                            f2[((((size_t)nt * 13 + st) * 2 + 1) * 64 + ln) * 8 + j] = a1;
+                        }
+                    }
+            CK(hipMalloc((void**)&c->b3f_w1, f2.size() * 2));
+            CK(hipMemcpy(c->b3f_w1, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
         }
         if (c->s3 && conv_is_first_s2(l)) {   // lane (i = channel of the n-tile, g): kernel row 2 st + (g>>1), taps 4 (g&1) + (j>>1), ci = j&1
             const int nt_n = d.cout / 16;
@@ -735,6 +790,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
     c->warp_exact = getenv("HNET_WARP_EXACT") && atoi(getenv("HNET_WARP_EXACT")) != 0;
     c->fuse_small = !(getenv("HNET_FUSE_SMALL") && atoi(getenv("HNET_FUSE_SMALL")) == 0);
+    c->fuse_b3 = c->n_planes == 2 && !(getenv("HNET_FUSE_B3") && atoi(getenv("HNET_FUSE_B3")) == 0);
     c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
     c->patch_rb5 = getenv("HNET_PATCH_RB5") ? atoi(getenv("HNET_PATCH_RB5")) : 5;     // measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
@@ -903,7 +959,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->feat16); fr(c->head_mask);
+    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1048,6 +1104,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     Blob b;
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;
+    c->fuse_b3 = false;                  // the fused block-3 kernel exists for the fp16 planes only (its layers' buffers stay allocated)
     c->cfg.precision = HNET_PREC_BF16X3;
     const int rc = upload_weights(c, b);
     if (rc != HNET_OK) return fail(c, rc, "re-packing the weights for HNET_PREC_BF16X3");
@@ -1419,6 +1476,25 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
     return HNET_OK;
 }
 
+int hnet_op_block3_fused(hnet_ctx* c, const float* in, int batch, float* out) {
+    if (!c || !in || !out || batch < 1) return HNET_ERR_INVALID_ARG;
+    if (!c->fuse_b3 || !c->b3f_w0 || !c->b3f_w1) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_3_0 + block_3_1 kernel exists in the fp16-plane mode only");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int h0 = IMG_H / 2, w0 = IMG_W / 2;
+    const size_t n_in = (size_t)batch * 2 * h0 * w0, n_out = (size_t)batch * 32 * (h0 / 2) * (w0 / 2);
+    DevTemps t;
+    float *d_a = nullptr, *d_b = nullptr, *d_d = nullptr;
+    uint16_t* p_out = nullptr;
+    HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
+    HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, h0, w0, c->stream));
+    HIPCHK(c, launch_block3_fused(d_b, c->b3f_w0, c->conv_b[7], c->b3f_w1, c->conv_b[8], p_out, n_out, batch, c->stream, c->n_planes));
+    HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 32, h0 / 2, w0 / 2, c->stream, c->n_planes));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
+    return HNET_OK;
+}
+
 static int op_prep_impl(hnet_ctx* c, const void* img1, const void* img2, int pix_fmt, const float* H, int k, float* out) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int ho = IMG_H / k, wo = IMG_W / k;
@@ -1469,6 +1545,11 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, launch_conv(13, xin, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
                               nullptr, 0, tmp, n));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));   // three planes: written by the fp32-MFMA kernel
+    } else if (c->fuse_b3 && layer == 7) {   // the fused block-3 kernel keeps block_3_0's output in LDS: recompute it unfused for inspection
+        uint16_t* tmp = nullptr;
+        HIPCHK(c, t.alloc(&tmp, 3 * n));
+        HIPCHK(c, launch_conv_first_s3(c->x_in[2] + (size_t)pair * (NPIX / 4) * 2, c->b30_frag, c->conv_b[7], tmp, n, 1, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[7], c->act_h[7], c->act_w[7], c->stream, c->n_planes));
     } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
                                              c->act_h[layer], c->act_w[layer], c->stream,

@@ -52,6 +52,10 @@ inline bool b4_cfg_is_dma(int cfg) { return cfg >= 4 && cfg <= 6; }
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */,
                                int cfg = 1, int n_planes = 3);
+// block_3_0 + block_3_1 in one launch (conv_b3_fused.h), fp16-plane mode (n_planes == 2) only: x_in fp32 NHWC [B][112][160][2] (the block's prep output),
+// w0frag [7][2][64] x 16 B, w1frag [2][13][2][64] x 16 B (packed by hnet_create), out16 [2][B][56][80][32]
+hipError_t launch_block3_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
+                               size_t o_plane, int batch, hipStream_t s, int n_planes);
 // dynamic-LDS limits of the kernels that use more than 64 KB; once per device (hnet_create)
 hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,

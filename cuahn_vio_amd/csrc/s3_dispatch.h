@@ -6,6 +6,7 @@
 #include "conv_first.h"
 #include "igemm_s3.h"
 #include "conv_b4_fused.h"
+#include "conv_b3_fused.h"
 #include "conv_patch_s2.h"
 #include "conv5_region.h"
 #include "kernels.h"
@@ -202,6 +203,19 @@ hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* 
     return run_b4<7, 256, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
+// block_3_0 + block_3_1 in one kernel (conv_b3_fused.h; fp16-plane mode only): x_in fp32 [B][112][160][2] -> out16 fp16 planes [2][B][56][80][32]
+template <int NP>
+hipError_t launch_block3_fused_np(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
+                                  size_t o_plane, int batch, hipStream_t s) {
+    if constexpr (NP != 2) return hipErrorInvalidValue;
+    else {
+        const int n_tiles = batch * B3Cfg::TILES_X * B3Cfg::TILES_Y;
+        hipLaunchKernelGGL(block3_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B3Cfg::LDS_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
+                           (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles);
+        return hipGetLastError();
+    }
+}
+
 // block_3_0 on the bf16 matrix cores (conv_first.h): x_in fp32 [B][h][w][2] -> out16 S3 planes [3][B][h][w][16]
 template <int NP>
 hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
@@ -378,6 +392,9 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     }
+    if constexpr (NP == 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES);
+    }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
@@ -396,6 +413,7 @@ hipError_t conv_kernels_init_device_np() {
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
                                                       uint16_t*, size_t, int, hipStream_t, int, int);                                    \
+    KW template hipError_t launch_block3_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv5_region_np<NP>(int, const uint16_t*, size_t, int, const void*, const float*, uint16_t*, size_t, hipStream_t); \

@@ -177,6 +177,15 @@ class HnetEngine:
         check(self._h, self._L.hnet_op_block4_fused(self._h, _fp(x), b, int(bool(reverse)), _fp(out)))
         return out
 
+    def op_block3_fused(self, x):
+        """the fused block_3_0 + block_3_1 kernel alone (fp16-plane mode): x [B,2,112,160] -> [B,32,56,80]"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        b = x.shape[0]
+        assert x.shape[1:] == (2, IMG_H // 2, IMG_W // 2)
+        out = np.zeros((b, 32, IMG_H // 4, IMG_W // 4), np.float32)
+        check(self._h, self._L.hnet_op_block3_fused(self._h, _fp(x), b, _fp(out)))
+        return out
+
     def op_prep(self, img1, img2, h, k):
         i1 = np.ascontiguousarray(img1, dtype=np.float32).reshape(IMG_H, IMG_W)
         i2 = np.ascontiguousarray(img2, dtype=np.float32).reshape(IMG_H, IMG_W)

@@ -196,3 +196,64 @@ def test_conv5_region_kernel_opt_in(blob, state, layer, batch, monkeypatch):
         err = float(np.abs(got[b] - ref).max())
         assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- the fused block-3 kernel, element by element
+def _conv2_b3(state, x):
+    from oracle import pyoracle
+    pre = "model_part1."
+    y = pyoracle.conv_lrelu(x, state[pre + "block_3_0.0.weight"], state[pre + "block_3_0.0.bias"], 1)
+    return pyoracle.conv_lrelu(y, state[pre + "block_3_1.0.weight"], state[pre + "block_3_1.0.bias"], 2)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 16])
+def test_block3_fused_kernel_elementwise(blob, state, batch):
+    """block3_fused_kernel (block_3_0 + block_3_1 in one launch, the 16-channel map never leaves LDS; csrc/conv_b3_fused.h) against
+    conv_lrelu(conv_lrelu(.)) of the oracle: every element of every pair, random inputs that are non-zero up to the image border (the zero
+    padding of BOTH layers matters), batches that give the persistent workgroups one tile each (35, 105) and more than one (560 tiles over
+    512 workgroups)"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=3)
+    rng = np.random.default_rng(300 + batch)
+    x = rng.standard_normal((batch, 2, 112, 160)).astype(np.float32)
+    x[:, :, :3, :] += 2.0
+    x[:, :, :, -3:] -= 2.0
+    got = eng.op_block3_fused(x)
+    eng.close()
+    for b in range(min(batch, 5)):
+        ref = _conv2_b3(state, x[b])
+        assert got[b].shape == ref.shape
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (b, err, np.unravel_index(np.abs(got[b] - ref).argmax(), ref.shape))
+    if batch == 16:        # pairs 5..15 against pair-wise reruns of the same kernel (slot invariance), not the slow oracle
+        for b in (7, 15):
+            e1 = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=3)
+            assert np.array_equal(e1.op_block3_fused(x[b:b + 1])[0], got[b])
+            e1.close()
+
+
+def test_block3_fused_forward_equals_the_unfused_layers_to_rounding(blob, oracle):
+    """the whole forward with and without the fusion (HNET_FUSE_B3=0): different but equally accurate arithmetic (two-accumulator form in
+    the fused kernel) - both inside the oracle gate and within 2e-5 px of each other"""
+    from conftest import TOL_PX_VS_ORACLE
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, _p, _ = synth.make_batch(640, 3)
+    res = []
+    for fuse in ("1", "0"):
+        old = os.environ.get("HNET_FUSE_B3")
+        os.environ["HNET_FUSE_B3"] = fuse
+        try:
+            e = HnetEngine(blob, variant="full", mc_samples=8, dropout_p=0.05, mc_seed=2, max_batch=3, precision=3)
+        finally:
+            if old is None:
+                os.environ.pop("HNET_FUSE_B3", None)
+            else:
+                os.environ["HNET_FUSE_B3"] = old
+        names = [n for n, _ in e.stages()]
+        assert ("block_3_0+3_1" in names) == (fuse == "1")
+        res.append(e.infer_batch(prev, curr, None, pair_seq0=5)[0])
+        e.close()
+    o = oracle.forward(prev[1], curr[1], None, 3, 8, 0.05, 2, 6)
+    assert np.abs(res[0][1] - o["mean"]).max() < TOL_PX_VS_ORACLE and np.abs(res[1][1] - o["mean"]).max() < TOL_PX_VS_ORACLE
+    assert np.abs(res[0] - res[1]).max() < 2e-5

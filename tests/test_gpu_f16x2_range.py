@@ -101,7 +101,11 @@ def test_activations_up_to_32768_are_carried_exactly_and_beyond_that_are_detecte
     rng = np.random.default_rng(5)
     e = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=PREC_F16X2)
     for amp, must_be_finite in ((30000.0, True), (40000.0, False)):
-        x = (rng.uniform(0.6, 1.0, (1, 64, 28, 40)) * amp * rng.choice([-1.0, 1.0], (1, 64, 28, 40))).astype(np.float32)
+        # ordinary activations with 2 % of the elements at +-(0.6 .. 1.0) x amp: the INPUT planes are what is probed, the outputs (sums over
+        # 1600 products, ~32 of them large) stay far inside the range
+        x = rng.standard_normal((1, 64, 28, 40)).astype(np.float32)
+        big = rng.random(x.shape) < 0.02
+        x[big] = (rng.uniform(0.6, 1.0, int(big.sum())) * amp * rng.choice([-1.0, 1.0], int(big.sum()))).astype(np.float32)
         got = e.op_conv(layer, x)
         ref = pyoracle.conv_lrelu(x[0], state["model_part1.block_2_2.0.weight"], state["model_part1.block_2_2.0.bias"], 2)[None]
         fin = np.isfinite(got)
