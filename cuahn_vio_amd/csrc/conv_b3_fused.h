@@ -41,7 +41,8 @@ struct B3Cfg {
     static constexpr int IROWB = 2 * XH * 32;                    // bytes per image row and plane
     static constexpr int IPLANEB = RH * IROWB;
     static constexpr int NP = 2;
-    static constexpr int LDS_BYTES = NP * (PPLANEB + IPLANEB);
+    static constexpr int LDS_BYTES = NP * (PPLANEB + IPLANEB);   // patch + image (the kernel adds W0_BYTES of weight fragments behind them)
+    static constexpr int W0_BYTES = 7 * 2 * 64 * 16;
     static constexpr int TILES_X = W1 / TW, TILES_Y = H1 / TH;   // 5 x 7 tiles per pair
     static constexpr int N_MT0 = 12;                             // phase-1 M-tiles: 10 row pairs + 2 tiles for the pairs of columns 32..34
     static constexpr int NSTEP1 = 13;                            // phase-2 K steps (two taps each; the 26th tap has zero weights)
@@ -70,11 +71,11 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- weights -> registers, once per (persistent) workgroup
-    f16x8 w0[7][2], w1[C::NSTEP1][2];
-#pragma unroll
-    for (int kh = 0; kh < 7; kh++)
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++) w0[kh][pl] = __builtin_bit_cast(f16x8, w0frag[(kh * 2 + pl) * 64 + lane]);
+    // block_3_1's 104 registers stay; block_3_0's fragments (14 x 1 KiB) live in LDS and are read per kernel row (the two sets together
+    // with both phases' accumulators do not fit 256 registers: 33 dwords of scratch in the first version)
+    f16x8 w1[C::NSTEP1][2];
+    u32x4* const w0s = reinterpret_cast<u32x4*>(lds_raw + C::LDS_BYTES);     // [7][2][64] x 16 B, lane-linear
+    for (int i = tid; i < 7 * 2 * 64; i += 256) w0s[i] = w0frag[i];
     const int nt = wave & 1;                                            // phase 2: this wave's half of the 32 output channels
 #pragma unroll
     for (int st = 0; st < C::NSTEP1; st++)
@@ -83,25 +84,19 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
 
     // phase-1 lane roles (32x32x16, weights as A operand: D row = n = (dx, co), D column = pixel pair of the M-tile)
     const int pcol = lane & 31, hh = lane >> 5, prow = pcol >> 4, pair = pcol & 15;
-    float bv0[4][4];                                                    // D row (r & 3) + 8 (r >> 2) + 4 hh = n: group q = r >> 2, n = 8 q + 4 hh + i
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) bv0[q][i] = bias0[(8 * q + 4 * hh + i) & 15];
+    // D row (r & 3) + 8 (r >> 2) + 4 hh = n: group q = r >> 2 holds channels 8 (q & 1) + 4 hh + i: its four biases = one 16-byte LDS read
+    __shared__ __attribute__((aligned(16))) float bias0s[16];
+    if (tid < 16) bias0s[tid] = bias0[tid];
     // phase-2 lane roles (16x16x32 transposed: D row 4 g + r = output channel, D column m = pixel of the output row)
     const int m = lane & 15, g = lane >> 4;
     float bv1[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) bv1[r] = bias1[16 * nt + 4 * g + r];
-    // lane part of the phase-2 read addresses: step st, tap t = 2 st + (g >> 1) = (kh, kw): pixel (2 oy + kh, 2 m + kw) of the image,
-    // channel half g & 1;  (t = 25 has zero weights: any valid address)
-    uint32_t p2off[C::NSTEP1];
-#pragma unroll
-    for (int st = 0; st < C::NSTEP1; st++) {
-        const int t = min(2 * st + (g >> 1), 24);
-        const int kh = t / 5, kw = t - 5 * kh;
-        p2off[st] = (uint32_t)(kh * IROWB + ((kw & 1) * XH + m + (kw >> 1)) * 32 + 16 * (g & 1));
-    }
+    // lane part of the phase-2 read addresses: pixel column 2 m (+ kw), channel half g & 1; the tap of step st is t = 2 st + (g >> 1) = (kh, kw):
+    // its offset is one of two compile-time constants per step (p2tap), selected by g >> 1  (t = 25 has zero weights: any valid address)
+    const uint32_t p2lane = (uint32_t)(m * 32 + 16 * (g & 1));
+    const bool ghi = (g >> 1) != 0;
+    auto p2tap = [](int t) constexpr { const int tt = t < 24 ? t : 24; const int kh = tt / 5, kw = tt - 5 * kh; return kh * C::IROWB + ((kw & 1) * C::XH + (kw >> 1)) * 32; };
     int hi4 = 8;                                                        // opaque byte offset: two ds_read_b64 instead of one ds_read2_b64 (conv_first.h)
     asm volatile("" : "+v"(hi4));
 
@@ -167,7 +162,11 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
             const int rrow = row_ok ? row : RH - 1;                     // (rows beyond the region: reads stay inside the patch, nothing is stored)
             f32x16 hi, lo;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { hi[r] = bv0[r >> 2][r & 3]; lo[r] = 0.f; }
+            for (int q = 0; q < 4; q++) {
+                const f32x4_m16 bq = *reinterpret_cast<const f32x4_m16*>(&bias0s[8 * (q & 1) + 4 * hh]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { hi[4 * q + i] = bq[i]; lo[4 * q + i] = 0.f; }
+            }
             const unsigned char* abase = patch + rrow * PROWB + pr2 * 8 + 16 * hh;
 #pragma unroll
             for (int kh = 0; kh < 7; kh++) {
@@ -179,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
                     const bf16x4_t h4 = *reinterpret_cast<const bf16x4_t*>(src + hi4);
                     a[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][0], a[1], lo, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][1], a[0], lo, 0, 0, 0);
-                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kh][0], a[0], hi, 0, 0, 0);
+                const f16x8 wk0 = __builtin_bit_cast(f16x8, w0s[(kh * 2 + 0) * 64 + lane]), wk1 = __builtin_bit_cast(f16x8, w0s[(kh * 2 + 1) * 64 + lane]);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk0, a[1], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk1, a[0], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk0, a[0], hi, 0, 0, 0);
             }
             // D row 8 q + 4 hh + i = (dx = q >> 1, co = 8 (q & 1) + 4 hh + i): a lane holds four consecutive channels of pixel 2 pr2 + dx
             const int iy = Ry0 + row;
@@ -207,44 +207,32 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
         }
         __syncthreads();
 
-        // ---- phase 2: block_3_1 from the LDS image.  This wave: channels 16 nt .. + 15, output rows (wave >> 1) + 2 j (j = 0..3) together
-        {
-            f32x4_m16 hi[4], lo[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                hi[j] = f32x4_m16{bv1[0], bv1[1], bv1[2], bv1[3]};
-                lo[j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
-            }
-            const unsigned char* ibase = img + (2 * (wave >> 1)) * IROWB;    // image row 2 oy of the first output row of this wave
+        // ---- phase 2: block_3_1 from the LDS image.  This wave: channels 16 nt .. + 15, output rows (wave >> 1) + 2 j (j = 0..3), one row
+        //      (M-tile) at a time: the weights of all 13 steps sit in registers
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            const int oy = (wave >> 1) + 2 * j;
+            f32x4_m16 hi = f32x4_m16{bv1[0], bv1[1], bv1[2], bv1[3]}, lo = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* ibase = img + (2 * oy) * IROWB + p2lane;    // image row 2 oy, this lane's pixel column and channel half
 #pragma unroll
             for (int st = 0; st < C::NSTEP1; st++) {
-                f16x8 a[4][2];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int pl = 0; pl < 2; pl++)
-                        a[j][pl] = *reinterpret_cast<const f16x8*>(ibase + p2off[st] + j * 4 * IROWB + pl * IPLANEB);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    lo[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a[j][1], lo[j], 0, 0, 0);
-                    lo[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][1], a[j][0], lo[j], 0, 0, 0);
-                    hi[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a[j][0], hi[j], 0, 0, 0);
-                }
+                const uint32_t off = ghi ? (uint32_t)p2tap(2 * st + 1) : (uint32_t)p2tap(2 * st);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(ibase + off);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(ibase + off + IPLANEB);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a1, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][1], a0, lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a0, hi, 0, 0, 0);
             }
             // D (transposed): row 4 g + r = output channel 16 nt + 4 g + r, column m = pixel: 8 bytes (4 channels) per lane and plane
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int oy = (wave >> 1) + 2 * j;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = s3p::lrelu(fmaf(lo[j][r], S3_F16_INV, hi[j][r]));
-                uint32_t pa[3], pb[3];
-                s3p::split_pair<2>(v[0], v[1], pa);
-                s3p::split_pair<2>(v[2], v[3], pb);
-                uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
-                *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
-                *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);
-            }
+            for (int r = 0; r < 4; r++) v[r] = s3p::lrelu(fmaf(lo[r], S3_F16_INV, hi[r]));
+            uint32_t pa[3], pb[3];
+            s3p::split_pair<2>(v[0], v[1], pa);
+            s3p::split_pair<2>(v[2], v[3], pb);
+            uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
+            *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
+            *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);
         }
     }   // persistent tile loop
 }

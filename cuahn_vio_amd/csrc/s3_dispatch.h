@@ -210,7 +210,7 @@ hipError_t launch_block3_fused_np(const float* x_in, const void* w0frag, const f
     if constexpr (NP != 2) return hipErrorInvalidValue;
     else {
         const int n_tiles = batch * B3Cfg::TILES_X * B3Cfg::TILES_Y;
-        hipLaunchKernelGGL(block3_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B3Cfg::LDS_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
+        hipLaunchKernelGGL(block3_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
                            (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles);
         return hipGetLastError();
     }
@@ -393,7 +393,7 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     }
     if constexpr (NP == 2) {
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
