@@ -34,8 +34,11 @@ struct B3Cfg {
     static constexpr int TH = 8, TW = 16, THREADS = 256;
     static constexpr int H0 = 112, W0 = 160, H1 = 56, W1 = 80, C0 = 16, C1 = 32;
     static constexpr int RH = 2 * TH + 3, RW = 2 * TW + 3;       // block_3_0 region of a tile: 19 x 35
-    static constexpr int PH = 26, PW = 44;                       // input patch rows (RH + 6 = 25, + 1: the M-tiles cover row pairs) x pixels
-    static constexpr int PROWB = PW * 4;                         // bytes per patch row and plane (one dword = both channels of a pixel)
+    static constexpr int PH = 26, PW = 44;                       // input patch rows (RH + 6 = 25, + 1: the last M-tile's second row) x pixels
+    // bytes per patch row and plane (one dword = both channels of a pixel).  A phase-1 M-tile pairs region rows r and r + 8: 8 x 176 = 128 mod 256,
+    // so the two 128-byte windows a ds_read_b64 touches lie in disjoint bank halves (rows r, r + 1 overlapped in 12 of 32 banks; a pitch of
+    // 384 fixes that too but puts the 16 rows of the leftover M-tiles on two bank offsets: measured conflict share 0.23 -> 0.34)
+    static constexpr int PROWB = PW * 4;
     static constexpr int PPLANEB = PH * PROWB;
     static constexpr int XH = 18;                                // pixels per (row, parity): ceil(35 / 2)
     static constexpr int IROWB = 2 * XH * 32;                    // bytes per image row and plane
@@ -44,7 +47,7 @@ struct B3Cfg {
     static constexpr int LDS_BYTES = NP * (PPLANEB + IPLANEB);   // patch + image (the kernel adds W0_BYTES of weight fragments behind them)
     static constexpr int W0_BYTES = 7 * 2 * 64 * 16;
     static constexpr int TILES_X = W1 / TW, TILES_Y = H1 / TH;   // 5 x 7 tiles per pair
-    static constexpr int N_MT0 = 12;                             // phase-1 M-tiles: 10 row pairs + 2 tiles for the pairs of columns 32..34
+    static constexpr int N_MT0 = 12;                             // phase-1 M-tiles: 10 pairs of rows + 2 tiles for the pixel pairs of columns 32..34
     static constexpr int NSTEP1 = 13;                            // phase-2 K steps (two taps each; the 26th tap has zero weights)
     static_assert(W1 % TW == 0 && H1 % TH == 0, "tiles cover the 56 x 80 output exactly");
 };
@@ -143,20 +146,21 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
                 const bool ok = (okbits >> q) & 1u;
                 uint32_t pk[3];
                 s3p::split_pair<2>(ok ? px[q].x : 0.f, ok ? px[q].y : 0.f, pk);
-                *reinterpret_cast<uint32_t*>(patch + i * 4) = pk[0];
-                *reinterpret_cast<uint32_t*>(patch + PPLANEB + i * 4) = pk[1];
+                const int pr = i / PW, pc = i - pr * PW;
+                *reinterpret_cast<uint32_t*>(patch + pr * PROWB + pc * 4) = pk[0];
+                *reinterpret_cast<uint32_t*>(patch + PPLANEB + pr * PROWB + pc * 4) = pk[1];
             }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
 
-        // ---- phase 1: block_3_0 over the region -> LDS image.  M-tile mt < 10: region rows 2 mt, 2 mt + 1, pixel pairs 0..15;
-        //      mt = 10, 11: the pairs 16, 17 (columns 32..35) of all rows, 32 (row, pair) combinations each
+        // ---- phase 1: block_3_0 over the region -> LDS image.  M-tile mt < 8: region rows mt, mt + 8, pixel pairs 0..15; mt = 8: rows 16, 17;
+        //      mt = 9: row 18 (+ an unused one); mt = 10, 11: the pairs 16, 17 (columns 32..35) of all rows, 32 (row, pair) combinations each
 #pragma unroll 1
         for (int j = 0; j < C::N_MT0 / 4; j++) {
             const int mt = wave + 4 * j;                                // wave-uniform
             int row, pr2;                                               // this lane's region row and pixel pair
-            if (mt < 10) { row = 2 * mt + prow; pr2 = pair; }
+            if (mt < 10) { row = mt < 8 ? mt + 8 * prow : 2 * mt + prow; pr2 = pair; }
             else { const int idx = (mt - 10) * 32 + pcol; row = idx >> 1; pr2 = 16 + (idx & 1); }
             const bool row_ok = row < RH;
             const int rrow = row_ok ? row : RH - 1;                     // (rows beyond the region: reads stay inside the patch, nothing is stored)
@@ -189,15 +193,10 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
             for (int q = 0; q < 4; q++) {
                 const int dx = q >> 1, col = 2 * pr2 + dx;
                 const bool ok = (unsigned)iy < (unsigned)H0 && (unsigned)(Rx0 + col) < (unsigned)W0;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float s = fmaf(lo[4 * q + i], S3_F16_INV, hi[4 * q + i]);
-                    v[i] = ok ? s3p::lrelu(s) : 0.f;
-                }
+                // u = 4096 hi + lo is the accumulator of the one-accumulator form (4096 x the sum): the packed LeakyReLU + split of s3p::act_split
                 uint32_t pa[3], pb[3];
-                s3p::split_pair<2>(v[0], v[1], pa);
-                s3p::split_pair<2>(v[2], v[3], pb);
+                s3p::act_split<2>(fmaf(hi[4 * q], S3_F16_SCALE, lo[4 * q]), fmaf(hi[4 * q + 1], S3_F16_SCALE, lo[4 * q + 1]), pa, ok);
+                s3p::act_split<2>(fmaf(hi[4 * q + 2], S3_F16_SCALE, lo[4 * q + 2]), fmaf(hi[4 * q + 3], S3_F16_SCALE, lo[4 * q + 3]), pb, ok);
                 if (row_ok && pr2 < XH) {
                     unsigned char* dst = img + ((row * 2 + dx) * XH + pr2) * 32 + (8 * (q & 1) + 4 * hh) * 2;
                     *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);
@@ -224,12 +223,9 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
                 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a0, hi, 0, 0, 0);
             }
             // D (transposed): row 4 g + r = output channel 16 nt + 4 g + r, column m = pixel: 8 bytes (4 channels) per lane and plane
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = s3p::lrelu(fmaf(lo[r], S3_F16_INV, hi[r]));
             uint32_t pa[3], pb[3];
-            s3p::split_pair<2>(v[0], v[1], pa);
-            s3p::split_pair<2>(v[2], v[3], pb);
+            s3p::act_split<2>(fmaf(hi[0], S3_F16_SCALE, lo[0]), fmaf(hi[1], S3_F16_SCALE, lo[1]), pa);
+            s3p::act_split<2>(fmaf(hi[2], S3_F16_SCALE, lo[2]), fmaf(hi[3], S3_F16_SCALE, lo[3]), pb);
             uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
             *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
             *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);

@@ -5,7 +5,7 @@
 #   mfma  : SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT + instruction counts
 TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency --no-verify"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency --no-verify --no-extras"
 mkdir -p $OUT
 python3 $GRAFT_REPO_ROOT/tools/csrc_digest.py > $OUT/csrc_digest.txt
 cd /tmp && export TMPDIR=/tmp
