@@ -48,8 +48,8 @@ def main():
     for r in range(world):
         a, b = hdist.shard_range(B, world, r)
         pm, pc = torch.zeros(b - a, 8, device=dev), torch.zeros(b - a, 64, device=dev)
-        eng.infer_batch_device(torch.from_numpy(prev_h[a:b]).to(dev).data_ptr(), torch.from_numpy(curr_h[a:b]).to(dev).data_ptr(), PIX_U8,
-                               torch.from_numpy(prior_h[a:b]).to(dev).data_ptr(), b - a, 40 + a, pm.data_ptr(), pc.data_ptr(), None, stream)
+        tp, tc, tr = torch.from_numpy(prev_h[a:b]).to(dev), torch.from_numpy(curr_h[a:b]).to(dev), torch.from_numpy(prior_h[a:b]).to(dev)   # kept alive until the sync
+        eng.infer_batch_device(tp.data_ptr(), tc.data_ptr(), PIX_U8, tr.data_ptr(), b - a, 40 + a, pm.data_ptr(), pc.data_ptr(), None, stream)
         torch.cuda.synchronize(dev)
         ok_all = ok_all and np.array_equal(g[a:b, :8], pm.cpu().numpy()) and np.array_equal(g[a:b, 8:], pc.cpu().numpy())
     res["all_shards_bitwise"] = bool(ok_all)
