@@ -25,7 +25,7 @@ SYMBOLS = [
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
-    "hnet_op_block4_fused", "hnet_op_block3_fused", "hnet_precision", "hnet_overflow_flag",
+    "hnet_op_block4_fused", "hnet_op_block3_fused", "hnet_op_block42_fused", "hnet_precision", "hnet_overflow_flag",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.hnet_op_conv.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp]
     L.hnet_op_block4_fused.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.hnet_op_block3_fused.argtypes = [vp, fp, C.c_int, fp]
+    L.hnet_op_block42_fused.argtypes = [vp, fp, C.c_int, fp]
     L.hnet_op_prep.argtypes = [vp, fp, fp, fp, C.c_int, fp]
     L.hnet_op_prep_u8.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp, C.c_int, fp]
     L.hnet_debug_layer_output.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t]

@@ -103,6 +103,9 @@ struct hnet_ctx {
     bool fuse_b3 = false;              // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h): fp16-plane mode, HNET_FUSE_B3=0 switches back
     uint16_t* b3f_w0 = nullptr;        // its weights: block_3_0 as [7][2][64] x 16 B fragments (two planes), block_3_1 as [2][13][2][64] x 16 B
     uint16_t* b3f_w1 = nullptr;
+    bool fuse_b42 = false;             // block_4_2 + block_4_3 in one kernel (conv_b42_fused.h): fp16-plane mode, HNET_FUSE_B42=0 switches back
+    uint16_t* b42_w2 = nullptr;        // its weights: [2][5][2][64] x 16 B and [4][9][2][64] x 16 B fragments
+    uint16_t* b42_w3 = nullptr;
     bool fuse_small = true;            // batch <= 8 (latency path): block-tail FC + DLT inside the next block's prep kernel, heads_fc2 + mc_finish in one launch (HNET_FUSE_SMALL=0: the separate launches; bit-identical)
     float* Hm2 = nullptr;              // second homography buffer of that path (a prep workgroup stores H while others still read the previous one)
     const float* H_last = nullptr;     // where the last forward left H_part1 (Hm or Hm2)
@@ -270,6 +273,13 @@ void build_stages(hnet_ctx* c, int batch) {
             std::string nm = kConvs[l].name;
             h = conv_out_dim(h, kConvs[l].ks, kConvs[l].stride);
             w = conv_out_dim(w, kConvs[l].ks, kConvs[l].stride);
+            if (c->fuse_b42 && l == 15) {      // one launch for block_4_2 + block_4_3
+                fl += conv_flops(16, h, w);
+                nm = "block_4_2+4_3";
+                h = conv_out_dim(h, kConvs[16].ks, kConvs[16].stride);
+                w = conv_out_dim(w, kConvs[16].ks, kConvs[16].stride);
+                l = 16;
+            }
             if (c->fuse_b3 && l == 7) {        // one launch for block_3_0 + block_3_1
                 fl += conv_flops(8, h, w);
                 nm = "block_3_0+3_1";
@@ -385,6 +395,15 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
+                continue;
+            }
+            if (c->fuse_b42 && l == 15 && c->n_planes == 2 && c->b42_w2 && c->b42_w3 && in16 && h == 112 && w == 160) {   // block_4_2 + block_4_3 in one launch
+                const size_t cnt1 = c->act_count[16];
+                uint16_t* o16b = c->act16[16] + P0 * cnt1;
+                STAGE(launch_block42_fused(in16, in_plane, c->b42_w2, c->conv_b[15], c->b42_w3, c->conv_b[16], o16b, MB * cnt1, B, s, c->n_planes));
+                in = nullptr; in16 = o16b; in_plane = MB * cnt1;
+                h = c->act_h[16]; w = c->act_w[16];
+                l = 16;
                 continue;
             }
             if (c->fuse_b3 && l == 7 && c->n_planes == 2 && c->b3f_w0 && c->b3f_w1 && h == 112 && w == 160) {   // block_3_0 + block_3_1 in one launch
@@ -504,7 +523,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
         auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
         for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); }
         for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
-        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1);
+        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3);
         fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
     }
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
@@ -595,6 +614,28 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                     }
             CK(hipMalloc((void**)&c->b3f_w1, f2.size() * 2));
             CK(hipMemcpy(c->b3f_w1, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
+        }
+        if (c->s3 && (l == 15 || l == 16) && c->n_planes == 2) {   // block_4_2 / block_4_3 for the fused kernel (conv_b42_fused.h), two weight planes
+            const int nnt = d.cout / 16, nst = l == 15 ? 5 : 9;
+            std::vector<uint16_t> f2((size_t)nnt * nst * 2 * 64 * 8, 0);
+            for (int nt = 0; nt < nnt; nt++)
+                for (int st = 0; st < nst; st++)
+                    for (int ln = 0; ln < 64; ln++) {
+                        const int co = 16 * nt + (ln & 15), gg = ln >> 4;
+                        const int t = l == 15 ? 2 * st + (gg >> 1) : st;           // 16 -> 32: two taps per 32-deep step; 32 -> 64: one
+                        if (t >= 9) continue;
+                        const int kh = t / 3, kw = t % 3;
+                        for (int j = 0; j < 8; j++) {
+                            const int ci = l == 15 ? 8 * (gg & 1) + j : 8 * gg + j;
+                            uint16_t a0, a1;
+                            split2h(w->data[(((size_t)co * d.cin + ci) * 3 + kh) * 3 + kw], a0, a1);
+                            f2[((((size_t)nt * nst + st) * 2 + 0) * 64 + ln) * 8 + j] = a0;
+                            f2[((((size_t)nt * nst + st) * 2 + 1) * 64 + ln) * 8 + j] = a1;
+                        }
+                    }
+            uint16_t*& dstp = l == 15 ? c->b42_w2 : c->b42_w3;
+            CK(hipMalloc((void**)&dstp, f2.size() * 2));
+            CK(hipMemcpy(dstp, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
         }
         if (c->s3 && conv_is_first_s2(l)) {   // lane (i = channel of the n-tile, g): kernel row 2 st + (g>>1), taps 4 (g&1) + (j>>1), ci = j&1
             const int nt_n = d.cout / 16;
@@ -791,6 +832,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->warp_exact = getenv("HNET_WARP_EXACT") && atoi(getenv("HNET_WARP_EXACT")) != 0;
     c->fuse_small = !(getenv("HNET_FUSE_SMALL") && atoi(getenv("HNET_FUSE_SMALL")) == 0);
     c->fuse_b3 = c->n_planes == 2 && !(getenv("HNET_FUSE_B3") && atoi(getenv("HNET_FUSE_B3")) == 0);
+    c->fuse_b42 = c->n_planes == 2 && !(getenv("HNET_FUSE_B42") && atoi(getenv("HNET_FUSE_B42")) == 0);
     c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
     c->patch_rb5 = getenv("HNET_PATCH_RB5") ? atoi(getenv("HNET_PATCH_RB5")) : 5;     // measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
@@ -959,7 +1001,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->feat16); fr(c->head_mask);
+    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1104,7 +1146,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     Blob b;
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;
-    c->fuse_b3 = false;                  // the fused block-3 kernel exists for the fp16 planes only (its layers' buffers stay allocated)
+    c->fuse_b3 = c->fuse_b42 = false;    // the fused block-3 / block_4_2+4_3 kernels exist for the fp16 planes only (their layers' buffers stay allocated)
     c->cfg.precision = HNET_PREC_BF16X3;
     const int rc = upload_weights(c, b);
     if (rc != HNET_OK) return fail(c, rc, "re-packing the weights for HNET_PREC_BF16X3");
@@ -1476,6 +1518,25 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
     return HNET_OK;
 }
 
+int hnet_op_block42_fused(hnet_ctx* c, const float* in, int batch, float* out) {
+    if (!c || !in || !out || batch < 1) return HNET_ERR_INVALID_ARG;
+    if (!c->fuse_b42 || !c->b42_w2 || !c->b42_w3) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_4_2 + block_4_3 kernel exists in the fp16-plane mode only");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int h1 = IMG_H / 2, w1 = IMG_W / 2;
+    const size_t n_in = (size_t)batch * 16 * h1 * w1, n_out = (size_t)batch * 64 * (h1 / 4) * (w1 / 4);
+    DevTemps t;
+    float *d_a = nullptr, *d_d = nullptr;
+    uint16_t *p_in = nullptr, *p_out = nullptr;
+    HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
+    HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, 16, h1, w1, c->stream, c->n_planes));
+    HIPCHK(c, launch_block42_fused(p_in, n_in, c->b42_w2, c->conv_b[15], c->b42_w3, c->conv_b[16], p_out, n_out, batch, c->stream, c->n_planes));
+    HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 64, h1 / 4, w1 / 4, c->stream, c->n_planes));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
+    return HNET_OK;
+}
+
 int hnet_op_block3_fused(hnet_ctx* c, const float* in, int batch, float* out) {
     if (!c || !in || !out || batch < 1) return HNET_ERR_INVALID_ARG;
     if (!c->fuse_b3 || !c->b3f_w0 || !c->b3f_w1) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_3_0 + block_3_1 kernel exists in the fp16-plane mode only");
@@ -1545,6 +1606,13 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, launch_conv(13, xin, 1, IMG_H, IMG_W, c->conv_w[13], c->conv_b[13], nullptr, c->stream,
                               nullptr, 0, tmp, n));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[13], c->act_h[13], c->act_w[13], c->stream));   // three planes: written by the fp32-MFMA kernel
+    } else if (c->fuse_b42 && layer == 15) {   // block_4_2's output lives in LDS only: recompute it with the stand-alone patch kernel for inspection
+        uint16_t* tmp = nullptr;
+        HIPCHK(c, t.alloc(&tmp, 3 * n));
+        const size_t n14 = c->act_count[14];
+        HIPCHK(c, launch_conv_patch(15, c->act16[14] + (size_t)pair * n14, (size_t)c->cfg.max_batch * n14, 1, c->act_h[14], c->act_w[14], c->patch_frag[15],
+                                    c->conv_b[15], tmp, n, c->stream, c->n_planes, c->patch_b128, c->patch_rb5));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[15], c->act_h[15], c->act_w[15], c->stream, c->n_planes));
     } else if (c->fuse_b3 && layer == 7) {   // the fused block-3 kernel keeps block_3_0's output in LDS: recompute it unfused for inspection
         uint16_t* tmp = nullptr;
         HIPCHK(c, t.alloc(&tmp, 3 * n));

@@ -56,6 +56,10 @@ hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0f
 // w0frag [7][2][64] x 16 B, w1frag [2][13][2][64] x 16 B (packed by hnet_create), out16 [2][B][56][80][32]
 hipError_t launch_block3_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
                                size_t o_plane, int batch, hipStream_t s, int n_planes);
+// block_4_2 + block_4_3 in one launch (conv_b42_fused.h), fp16-plane mode only: in16 = block_4_1's planes [2][B][112][160][16],
+// w2frag [2][5][2][64] x 16 B, w3frag [4][9][2][64] x 16 B (packed by hnet_create), out16 [2][B][28][40][64]
+hipError_t launch_block42_fused(const uint16_t* in16, size_t i_plane, const void* w2frag, const float* bias2, const void* w3frag, const float* bias3,
+                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int n_planes);
 // dynamic-LDS limits of the kernels that use more than 64 KB; once per device (hnet_create)
 hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,

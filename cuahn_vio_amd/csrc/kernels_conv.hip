@@ -152,6 +152,11 @@ hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0f
     return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
 }
 
+hipError_t launch_block42_fused(const uint16_t* in16, size_t i_plane, const void* w2frag, const float* bias2, const void* w3frag, const float* bias3,
+                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int n_planes) {
+    return HNET_NP(launch_block42_fused_np, in16, i_plane, w2frag, bias2, w3frag, bias3, out16, o_plane, batch, s);
+}
+
 hipError_t launch_block3_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,
                                size_t o_plane, int batch, hipStream_t s, int n_planes) {
     return HNET_NP(launch_block3_fused_np, x_in, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s);

@@ -7,6 +7,7 @@
 #include "igemm_s3.h"
 #include "conv_b4_fused.h"
 #include "conv_b3_fused.h"
+#include "conv_b42_fused.h"
 #include "conv_patch_s2.h"
 #include "conv5_region.h"
 #include "kernels.h"
@@ -216,6 +217,19 @@ hipError_t launch_block3_fused_np(const float* x_in, const void* w0frag, const f
     }
 }
 
+// block_4_2 + block_4_3 in one kernel (conv_b42_fused.h; fp16-plane mode only): in16 [2][B][112][160][16] -> out16 [2][B][28][40][64]
+template <int NP>
+hipError_t launch_block42_fused_np(const uint16_t* in16, size_t i_plane, const void* w2frag, const float* bias2, const void* w3frag, const float* bias3,
+                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s) {
+    if constexpr (NP != 2) return hipErrorInvalidValue;
+    else {
+        const int n_tiles = batch * B42Cfg::TILES_X * B42Cfg::TILES_Y;
+        hipLaunchKernelGGL(block42_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B42Cfg::LDS_BYTES, s, in16, i_plane,
+                           (const u32x4*)w2frag, bias2, (const u32x4*)w3frag, bias3, out16, o_plane, n_tiles);
+        return hipGetLastError();
+    }
+}
+
 // block_3_0 on the bf16 matrix cores (conv_first.h): x_in fp32 [B][h][w][2] -> out16 S3 planes [3][B][h][w][16]
 template <int NP>
 hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
@@ -393,6 +407,7 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     }
     if constexpr (NP == 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
@@ -413,6 +428,7 @@ hipError_t conv_kernels_init_device_np() {
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
                                                       uint16_t*, size_t, int, hipStream_t, int, int);                                    \
+    KW template hipError_t launch_block42_fused_np<NP>(const uint16_t*, size_t, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_block3_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \

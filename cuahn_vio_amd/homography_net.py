@@ -186,6 +186,15 @@ class HnetEngine:
         check(self._h, self._L.hnet_op_block3_fused(self._h, _fp(x), b, _fp(out)))
         return out
 
+    def op_block42_fused(self, x):
+        """the fused block_4_2 + block_4_3 kernel alone (fp16-plane mode): x [B,16,112,160] -> [B,64,28,40]"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        b = x.shape[0]
+        assert x.shape[1:] == (16, IMG_H // 2, IMG_W // 2)
+        out = np.zeros((b, 64, IMG_H // 8, IMG_W // 8), np.float32)
+        check(self._h, self._L.hnet_op_block42_fused(self._h, _fp(x), b, _fp(out)))
+        return out
+
     def op_prep(self, img1, img2, h, k):
         i1 = np.ascontiguousarray(img1, dtype=np.float32).reshape(IMG_H, IMG_W)
         i2 = np.ascontiguousarray(img2, dtype=np.float32).reshape(IMG_H, IMG_W)

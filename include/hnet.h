@@ -224,6 +224,8 @@ int hnet_op_block4_fused(hnet_ctx* ctx, const float* in, int batch, int reverse,
 /* the fused block_3_0 + block_3_1 kernel alone (fp16-plane mode): in [B][2][112][160] (NCHW fp32) -> out [B][32][56][80] = conv(conv(in)) with
  * the reference's conv() (model_to_trace.py:7-15, layers :108-109) */
 int hnet_op_block3_fused(hnet_ctx* ctx, const float* in, int batch, float* out);
+/* the fused block_4_2 + block_4_3 kernel alone (fp16-plane mode): in [B][16][112][160] -> out [B][64][28][40] (model_to_trace.py:212-213) */
+int hnet_op_block42_fused(hnet_ctx* ctx, const float* in, int batch, float* out);
 /* cat(img1, warp(img2,H)) -> AvgPool(k): img1,img2 [224][320] f32, H[9] or NULL (no warp), k in {1,2,4,8}
  * -> out [2][224/k][320/k]   (model_to_trace.py:153-157) */
 int hnet_op_prep(hnet_ctx* ctx, const float* img1, const float* img2, const float* H, int k, float* out);

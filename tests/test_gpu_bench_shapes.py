@@ -257,3 +257,32 @@ def test_block3_fused_forward_equals_the_unfused_layers_to_rounding(blob, oracle
     o = oracle.forward(prev[1], curr[1], None, 3, 8, 0.05, 2, 6)
     assert np.abs(res[0][1] - o["mean"]).max() < TOL_PX_VS_ORACLE and np.abs(res[1][1] - o["mean"]).max() < TOL_PX_VS_ORACLE
     assert np.abs(res[0] - res[1]).max() < 2e-5
+
+
+def _conv2_b42(state, x):
+    from oracle import pyoracle
+    pre = "model_last_block_list.0."
+    y = pyoracle.conv_lrelu(x, state[pre + "block_4_2.0.weight"], state[pre + "block_4_2.0.bias"], 2)
+    return pyoracle.conv_lrelu(y, state[pre + "block_4_3.0.weight"], state[pre + "block_4_3.0.bias"], 2)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 16])
+def test_block42_fused_kernel_elementwise(blob, state, batch):
+    """block42_fused_kernel (block_4_2 + block_4_3 in one launch, the 32-channel map never leaves LDS; csrc/conv_b42_fused.h) against
+    conv_lrelu(conv_lrelu(.)) of the oracle: every element, inputs non-zero up to the border, 35 / 105 / 560 tiles over 512 workgroups"""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=3)
+    rng = np.random.default_rng(400 + batch)
+    x = rng.standard_normal((batch, 16, 112, 160)).astype(np.float32)
+    x[:, :, :2, :] += 2.0
+    x[:, :, :, -2:] -= 2.0
+    got = eng.op_block42_fused(x)
+    for b in range(min(batch, 4)):
+        ref = _conv2_b42(state, x[b])
+        assert got[b].shape == ref.shape
+        err = float(np.abs(got[b] - ref).max())
+        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (b, err, np.unravel_index(np.abs(got[b] - ref).argmax(), ref.shape))
+    if batch == 16:
+        for b in (9, 15):
+            assert np.array_equal(eng.op_block42_fused(x[b:b + 1])[0], got[b])
+    eng.close()
