@@ -816,6 +816,9 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
                 *reinterpret_cast<u32x4*>(&As[pl * TILE_A + a_lds[i]]) = v;
             }
         }
+#ifdef HNET_S3_ABLATE
+        if (p.tile == 91 || p.tile == 92) return;      // ablation (wrong results): no LDS stores of the weight tile
+#endif
 #pragma unroll
         for (int i = 0; i < B_ROWS; i++)
 #pragma unroll
@@ -843,6 +846,13 @@ __global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
 #pragma unroll
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
+#ifdef HNET_S3_ABLATE
+                if (p.tile == 92) {                     // ablation (wrong results): no LDS reads of the weight fragments either
+#pragma unroll
+                    for (int pl = 0; pl < NW; pl++) bf[j][pl] = __builtin_bit_cast(bf16x8, breg[j % B_ROWS][pl]);
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int pl = 0; pl < NW; pl++)
                     bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
