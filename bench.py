@@ -234,7 +234,7 @@ def committed_traffic(kernel_substr, batch):
 
 # stage name -> substring of the HIP kernel name in the rocprof tables
 KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "HeadLoaderS3, 128", "block_3_1": "conv_patch_s2_kernel<5",
-                   "block_2_2": "ConvLoaderS3<64, 5, 2, 32>"}
+                   "block_2_2": "ConvLoaderS3<64, 5, 2, 32>", "block_3_0+3_1": "block3_fused_kernel", "block_4_2+4_3": "block42_fused_kernel"}
 # stages whose contraction does not run on the bf16 matrix cores in the split-bf16 mode: the small FCs (fp32 FMAs).  (Round 1 also ran
 # the Cin = 2 first layers of blocks 1 and 2 on the fp32 MFMA; they are bf16x3 kernels since r02_v2, conv_first.h conv7_c2_s2_s3_kernel.)
 FP32_STAGES = ("fc_dlt_b1", "fc_dlt_b2", "fc_dlt_b3", "heads_fc2")
@@ -617,8 +617,8 @@ def run(args, ctx, primary):
                            "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
                            "mfma_per_mac": mfma_per_mac if pk == peak_tf else 1,
                            "fp32_equivalent_tflops": round(alg / (ms[k] * 1e-3) / 1e12, 2),
-                           "note": ("three fp16 MFMAs per multiply-accumulate (two fp16 planes per value); the same kernel issues six bf16 MFMAs per MAC in "
-                                    "--precision bf16x3 and reaches 0.39-0.40 of the peak there at 0.72x the throughput (profiles/r02_v15_bench_bf16x3.json)"
+                           "note": ("three fp16 MFMAs per multiply-accumulate (two fp16 planes per value): achieved / peak counts the MFMAs issued; counting "
+                                    "useful FLOP only (fp32_equivalent_tflops) the fraction is a third of frac"
                                     if args.precision == "f16x2" else None),
                            "peak_of": ("dense fp16 MFMA (v_mfma_f32_16x16x32_f16; same rate as bf16)" if args.precision == "f16x2" else
                                        "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)") if pk == PEAK_BF16_MFMA_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
