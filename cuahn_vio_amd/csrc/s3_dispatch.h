@@ -153,6 +153,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         if constexpr (NP != 1) {
             if (tile == 1) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn);
             if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+            if constexpr (COUT >= 128 && NP == 2) { if (tile == 8 && big_m) return run_s3<L, 64, 128, 2, OUT32, NP>(p, s, ws, wsn); }   // experiment: all (or half) of N per workgroup: the im2col tile is staged once
             if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         }
         if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
@@ -354,7 +355,10 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     p.out32 = hidden;
     p.M = batch * n_local; p.N = 512; p.Kp = 5120;
     p.mask = mask; p.n_local = n_local; p.tile = tile;
-    if constexpr (NP == 2) { if (tile == 2 && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn); }
+    if constexpr (NP == 2) {
+        if (tile == 2 && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn);
+        if (tile == 3) return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, nullptr, 0);       // experiment: 64 x 64 tiles (four workgroups per CU) at large M
+    }
     // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
     if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn);
     return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, ws, wsn);
