@@ -156,7 +156,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
             if constexpr (COUT >= 128 && NP == 2) { if (tile == 8 && big_m) return run_s3<L, 64, 128, 2, OUT32, NP>(p, s, ws, wsn); }   // experiment: all (or half) of N per workgroup: the im2col tile is staged once
             if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         }
-        if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
+        if constexpr (CIN == 256) { if (big_m && tile != 9) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }   // (tile 9: experiment, 64 x 64 + split-K policy of run_s3)
         // (fp16 mode: two accumulators per tile - the 128x128 tile would need 128 accumulator registers: 0.091 ms against 0.080 ms with 64x64)
         if constexpr (CIN == 128 && KS == 5 && NP != 2) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
