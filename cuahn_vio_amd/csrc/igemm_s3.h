@@ -915,7 +915,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     for (int i = 0; i < A_INST; i++) {
         const int r = (wave + 4 * i) * 16 + lrow;
         rows[i] = L::make_row(p, m0 + r, n0);
-        akp[i] = (lphys ^ ((r >> 2) & 3)) * 8;
+        akp[i] = (MF == 16 ? (lphys ^ (((r >> 3) & 1) * 3)) : (lphys ^ ((r >> 2) & 3))) * 8;   // 16x16x32 reads: the conflict-free 64-byte-row swizzle of s3_swz_m16
     }
     const uint16_t* wsrc[B_INST];
     bool wvalid[B_INST];
@@ -923,7 +923,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
     for (int i = 0; i < B_INST; i++) {
         const int r = (wave + 4 * i) * 16 + lrow;
         wvalid[i] = n0 + r < p.N;
-        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n0 + r : 0) * p.Kp + (lphys ^ ((r >> 2) & 3)) * 8;
+        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n0 + r : 0) * p.Kp + (MF == 16 ? (lphys ^ (((r >> 3) & 1) * 3)) : (lphys ^ ((r >> 2) & 3))) * 8;
     }
 
     f32x16 acc[TM][TN];
@@ -986,13 +986,13 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
             for (int i = 0; i < TM16; i++) {
                 const int r = wm * WM + i * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, g16)]);
+                for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz_m16<4>(r, g16)]);
             }
 #pragma unroll
             for (int j = 0; j < TN16; j++) {
                 const int r = wn * WN + j * 16 + r16;
 #pragma unroll
-                for (int pl = 0; pl < NW; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, g16)]);
+                for (int pl = 0; pl < NW; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<4>(r, g16)]);
             }
 #pragma unroll
             for (int i = 0; i < TM16; i++)

@@ -65,6 +65,13 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
                 return hipGetLastError();
             }
         }
+        if constexpr (!L::HAS_MASK && BM == 64 && BN == 64) {        // experiments: the LDS-DMA ring (no register staging, no ds_write, two K-tiles in flight) on every conv layer
+            if ((p.tile == 10 || p.tile == 11) && split == 1 && p.zeros) {
+                if (p.tile == 10) hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, NP>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4, 16, NP>), grid, dim3(256), 0, s, p);
+                return hipGetLastError();
+            }
+        }
         if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
             if constexpr (L::template lean_ok<64>()) {
                 hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
