@@ -382,6 +382,21 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
             if (fb & (1u << i)) w[i] = warp_taps_global<PIX, false>(i2, fx[i], fy[i], nullptr);
     }
     if constexpr (K == 1 && OUTS3) {
+        if (n_planes == 2) {                                            // fp16 planes (the default mode): both channels of a pixel split as ONE packed pair
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            uint32_t* o0 = out_s3 + ((size_t)b * B4_HP + (v0 + r0 + B4_PADY)) * B4_WP + u + B4_PADX;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                               // = split2h(a), split2h(w) of s3_format.h: A0 = f16(v), A1 = f16((v - A0) 4096)
+                const f2 v = {a[i], w[i]};
+                const h2 hi = {(_Float16)v[0], (_Float16)v[1]};
+                const f2 back = {(float)hi[0], (float)hi[1]};
+                const f2 r = (v - back) * S3_F16_SCALE;
+                const h2 lo = {(_Float16)r[0], (_Float16)r[1]};
+                o0[(size_t)i * B4_WP] = __builtin_bit_cast(uint32_t, hi);
+                o0[s3_plane + (size_t)i * B4_WP] = __builtin_bit_cast(uint32_t, lo);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint16_t a0, a1, a2, w0, w1, w2;
