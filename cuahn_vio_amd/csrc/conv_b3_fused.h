@@ -20,6 +20,8 @@
 // hi += W0 A0, lo += W1 A0 + W0 A1, result = hi + lo / 4096 (three fp16 MFMAs per product, fp32 accumulation; the weights of both
 // layers fit the register file in two planes, not in three).
 //
+// (Round-3 addendum: the two 16-byte chunks of a pixel are swapped where (column / 2 >> 2) & 1 - the phase-1 stores, 16 lanes at 32-byte stride, go from
+// 4-way to 2-way bank conflicts, conflict share of the kernel 0.22 -> 0.12; the reads below stay conflict free.)
 // LDS reads of phase 2 are conflict free by layout: a ds_read_b128 is served in four passes of 16 lanes - pixels {0-3, 12-15} of lane
 // group g with pixels {4-11} of group g + 1 - and with 32-byte pixels group g reads even 16-byte slots, group g + 1 (the other channel
 // half, or the next tap: an even number of slots away, plus one) odd ones.
@@ -97,7 +99,11 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
     for (int r = 0; r < 4; r++) bv1[r] = bias1[16 * nt + 4 * g + r];
     // lane part of the phase-2 read addresses: pixel column 2 m (+ kw), channel half g & 1; the tap of step st is t = 2 st + (g >> 1) = (kh, kw):
     // its offset is one of two compile-time constants per step (p2tap), selected by g >> 1  (t = 25 has zero weights: any valid address)
-    const uint32_t p2lane = (uint32_t)(m * 32 + 16 * (g & 1));
+    // the two 16-byte chunks of a pixel are SWAPPED where (x / 2 >> 2) & 1 (bank model, tools/lds_bank_model.py: the 16 lanes of a phase-1 store group
+    // then hit 2 instead of 4 addresses per bank, the phase-2 reads stay conflict free): the lane offset depends on the tap's kw >> 1 = 0, 1, 2
+    const uint32_t p2l0 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ ((m >> 2) & 1)));
+    const uint32_t p2l1 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ (((m + 1) >> 2) & 1)));
+    const uint32_t p2l2 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ (((m + 2) >> 2) & 1)));
     const bool ghi = (g >> 1) != 0;
     auto p2tap = [](int t) constexpr { const int tt = t < 24 ? t : 24; const int kh = tt / 5, kw = tt - 5 * kh; return kh * C::IROWB + ((kw & 1) * C::XH + (kw >> 1)) * 32; };
     int hi4 = 8;                                                        // opaque byte offset: two ds_read_b64 instead of one ds_read2_b64 (conv_first.h)
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
                 s3p::act_split<2>(fmaf(hi[4 * q], S3_F16_SCALE, lo[4 * q]), fmaf(hi[4 * q + 1], S3_F16_SCALE, lo[4 * q + 1]), pa, ok);
                 s3p::act_split<2>(fmaf(hi[4 * q + 2], S3_F16_SCALE, lo[4 * q + 2]), fmaf(hi[4 * q + 3], S3_F16_SCALE, lo[4 * q + 3]), pb, ok);
                 if (row_ok && pr2 < XH) {
-                    unsigned char* dst = img + ((row * 2 + dx) * XH + pr2) * 32 + (8 * (q & 1) + 4 * hh) * 2;
+                    unsigned char* dst = img + ((row * 2 + dx) * XH + pr2) * 32 + 16 * ((q & 1) ^ ((pr2 >> 2) & 1)) + 8 * hh;
                     *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);
                     *reinterpret_cast<uint2*>(dst + IPLANEB) = make_uint2(pa[1], pb[1]);
                 }
@@ -212,10 +218,12 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
         for (int j = 0; j < 4; j++) {
             const int oy = (wave >> 1) + 2 * j;
             f32x4_m16 hi = f32x4_m16{bv1[0], bv1[1], bv1[2], bv1[3]}, lo = f32x4_m16{0.f, 0.f, 0.f, 0.f};
-            const unsigned char* ibase = img + (2 * oy) * IROWB + p2lane;    // image row 2 oy, this lane's pixel column and channel half
+            const unsigned char* ibase = img + (2 * oy) * IROWB;             // image row 2 oy; the lane's pixel column and (swapped) channel half: p2l*
 #pragma unroll
             for (int st = 0; st < C::NSTEP1; st++) {
-                const uint32_t off = ghi ? (uint32_t)p2tap(2 * st + 1) : (uint32_t)p2tap(2 * st);
+                const int tA = 2 * st < 24 ? 2 * st : 24, tB = 2 * st + 1 < 24 ? 2 * st + 1 : 24;   // (compile-time after unrolling)
+                const int kA = (tA % 5) >> 1, kB = (tB % 5) >> 1;
+                const uint32_t off = ghi ? (uint32_t)p2tap(tB) + (kB == 0 ? p2l0 : kB == 1 ? p2l1 : p2l2) : (uint32_t)p2tap(tA) + (kA == 0 ? p2l0 : kA == 1 ? p2l1 : p2l2);
                 const f16x8 a0 = *reinterpret_cast<const f16x8*>(ibase + off);
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(ibase + off + IPLANEB);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a1, lo, 0, 0, 0);
