@@ -1154,6 +1154,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     if (c->g_batch) { (void)hipGraphExecDestroy(c->g_batch); c->g_batch = nullptr; }
     c->blob_copy.clear();
     c->blob_copy.shrink_to_fit();
+    build_stages(c, c->cfg.max_batch);     // the fused fp16-plane kernels are gone from the launch list
     fprintf(stderr, "hnet: activation beyond the fp16 range in HNET_PREC_F16X2: context demoted to HNET_PREC_BF16X3\n");
     return HNET_OK;
 }
