@@ -132,32 +132,51 @@ __device__ inline float warp_sample(const PIX* img, const float* h, int u, int v
 constexpr int WT_W = 64, WT_H = 32;          // output tile
 constexpr int WT_CAP = 7168;                 // staged floats (28 KB): e.g. 112 x 64
 
-template <typename PIX> __device__ __forceinline__ float4 load_px4(const PIX* p);
-template <> __device__ __forceinline__ float4 load_px4<uint8_t>(const uint8_t* p) {
-    const uint32_t q = *reinterpret_cast<const uint32_t*>(p);
-    return make_float4(u8_to_unit((float)(q & 255u)), u8_to_unit((float)((q >> 8) & 255u)), u8_to_unit((float)((q >> 16) & 255u)),
-                       u8_to_unit((float)(q >> 24)));
-}
-template <> __device__ __forceinline__ float4 load_px4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// four consecutive pixels: the raw load and its conversion to float are separate steps so that several loads can be in flight
+template <typename PIX> struct PxRaw;
+template <> struct PxRaw<uint8_t> {
+    typedef uint32_t type;
+    __device__ static __forceinline__ type zero() { return 0u; }
+    __device__ static __forceinline__ type load(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+    __device__ static __forceinline__ float4 cvt(type q) {
+        return make_float4(u8_to_unit((float)(q & 255u)), u8_to_unit((float)((q >> 8) & 255u)), u8_to_unit((float)((q >> 16) & 255u)),
+                           u8_to_unit((float)(q >> 24)));
+    }
+};
+template <> struct PxRaw<float> {
+    typedef float4 type;
+    __device__ static __forceinline__ type zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    __device__ static __forceinline__ type load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ float4 cvt(type q) { return q; }
+};
 
 struct WarpBox { int gx0, ry0, pitch, rows; bool ok; bool zsafe; };
+
+// minimum / maximum over the four lanes of a quad (DPP quad_perm: no LDS crossbar, no wait)
+template <int CTRL> __device__ __forceinline__ float quad_perm_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_min(float v) { v = fminf(v, quad_perm_f<0xB1>(v)); return fminf(v, quad_perm_f<0x4E>(v)); }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, quad_perm_f<0xB1>(v)); return fmaxf(v, quad_perm_f<0x4E>(v)); }
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 template <typename PIX>
 __device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const float* h, int u0, int v0, float* __restrict__ reg) {
     WarpBox bx;
-    float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
-    bool pos = true, neg = true, finite = true, zs = true;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float ix, iy, Z;
-        warp_coords(h, u0 + (c & 1) * (WT_W - 1), v0 + (c >> 1) * (WT_H - 1), ix, iy, Z);
-        pos = pos && Z > 0.0f;
-        neg = neg && Z < 0.0f;
-        zs = zs && warp_z_safe(Z);
-        finite = finite && fabsf(ix) < 1.0e6f && fabsf(iy) < 1.0e6f;      // false for NaN
-        lo_x = fminf(lo_x, ix); hi_x = fmaxf(hi_x, ix);
-        lo_y = fminf(lo_y, iy); hi_y = fmaxf(hi_y, iy);
-    }
+    // The four warped corners: lane c of every quad evaluates corner c (ONE pass through warp_coords per wave instead of four - the corner
+    // arithmetic with its range test and division was a quarter of the kernel's vector instructions), minimum / maximum across the quad,
+    // the sign / range / finiteness flags by ballot; everything after that is wave-uniform and lives in SGPRs.  Same values as the
+    // sequential form: min / max of non-NaN floats do not depend on the order, and any NaN clears `finite`, which discards the box.
+    const int c = (int)(threadIdx.x & 3u);
+    float ix, iy, Z;
+    warp_coords(h, u0 + (c & 1) * (WT_W - 1), v0 + (c >> 1) * (WT_H - 1), ix, iy, Z);
+    const unsigned quad0 = 0xFu;                                            // lanes 0..3 of the wave: one of each corner
+    const bool pos = ((unsigned)__ballot(Z > 0.0f) & quad0) == quad0;
+    const bool neg = ((unsigned)__ballot(Z < 0.0f) & quad0) == quad0;
+    const bool zs = ((unsigned)__ballot(warp_z_safe(Z)) & quad0) == quad0;
+    const bool finite = ((unsigned)__ballot(fabsf(ix) < 1.0e6f && fabsf(iy) < 1.0e6f) & quad0) == quad0;      // false for NaN
+    const float lo_x = uniform_f(quad_min(ix)), hi_x = uniform_f(quad_max(ix));
+    const float lo_y = uniform_f(quad_min(iy)), hi_y = uniform_f(quad_max(iy));
     bx.ok = (pos || neg) && finite;
     bx.zsafe = (pos || neg) && zs;        // Z is affine in (u, v) and keeps its sign over the tile: |Z| inside the tile lies between the corners' values
     // taps of pixels that survive the far-out test lie in [-1, W] x [-1, H] (+1): clip the box to that frame
@@ -169,15 +188,26 @@ __device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const floa
     bx.rows = ry1 >= ry0 ? ry1 - ry0 + 1 : 0;
     if (bx.pitch * bx.rows > WT_CAP) bx.ok = false;
     if (!bx.ok) return bx;
+    // four rows per thread and pass: the loads of a pass are all issued before the first conversion (with one row per pass every thread
+    // walked its ~5 rows as five dependent global round trips - hidden by other workgroups at large batches, exposed at batch 1)
     const int groups = bx.pitch >> 2;
-    for (int r = threadIdx.x >> 5; r < bx.rows; r += 8) {
-        const int y = ry0 + r;
-        const bool yin = y >= 0 && y < IMG_H;
-        for (int c = threadIdx.x & 31; c < groups; c += 32) {
+    const int rl = (int)(threadIdx.x >> 5);
+    for (int rb = 0; rb < bx.rows; rb += 32) {
+        for (int c = (int)(threadIdx.x & 31); c < groups; c += 32) {
             const int x = bx.gx0 + 4 * c;                                // multiple of 4: the group is all in or all out
-            float4 f = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (yin && x >= 0 && x < IMG_W) f = load_px4<PIX>(img + y * IMG_W + x);
-            *reinterpret_cast<float4*>(&reg[r * bx.pitch + 4 * c]) = f;
+            const bool xin = x >= 0 && x < IMG_W;
+            typename PxRaw<PIX>::type raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = rb + rl + 8 * k, y = ry0 + r;
+                raw[k] = PxRaw<PIX>::zero();
+                if (r < bx.rows && xin && y >= 0 && y < IMG_H) raw[k] = PxRaw<PIX>::load(img + y * IMG_W + x);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = rb + rl + 8 * k;
+                if (r < bx.rows) *reinterpret_cast<float4*>(&reg[r * bx.pitch + 4 * c]) = PxRaw<PIX>::cvt(raw[k]);   // raw zero -> 0.0f
+            }
         }
     }
     return bx;
@@ -344,8 +374,9 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     // wave and row) are now loaded straight into registers BEFORE the box is staged and are consumed after the barrier: one round trip,
     // no LDS tile for img1 (28 instead of 37 KB per workgroup), no u8 -> f32 table.
     PIX araw[8];
+    const PIX* p1 = i1 + (v0 + r0) * IMG_W + u;                          // one address, the rows as instruction offsets
 #pragma unroll
-    for (int i = 0; i < 8; i++) araw[i] = i1[(v0 + r0 + i) * IMG_W + u];
+    for (int i = 0; i < 8; i++) araw[i] = p1[i * IMG_W];
     const WarpBox bx = warp_stage_box<PIX>(i2, h, u0, v0, reg);
     __syncthreads();
     float a[8], w[8], fx[8], fy[8];
