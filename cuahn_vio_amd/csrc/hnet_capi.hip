@@ -792,7 +792,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
-    if ((size_t)g.max_batch * (size_t)g.mc_samples * 1280 + 256 >= ((size_t)1 << 32)) return HNET_ERR_CAPACITY;   // 32-bit indices of the keep-bit kernel (s3_dispatch.h)
+    if ((size_t)g.max_batch * std::max((size_t)g.mc_samples * 1280, (size_t)4 * 5120) + 1024 >= ((size_t)1 << 32)) return HNET_ERR_CAPACITY;   // 32-bit indices of the keep-bit kernel (s3_dispatch.h)
     if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
         return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;

@@ -1098,34 +1098,37 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
         feat16[i] = a; feat16[f_plane + i] = b;
         if (np != 2) feat16[2 * f_plane + i] = c;
     }
-    // keep bits: one byte per thread.  A workgroup's 256 bytes span at most two rows (b, sample, head) of 640 bytes: the row's hash prefix
-    // (four hnet_mix32 and, with a run-time n_local, an integer division) is formed by two threads and shared through LDS, and all index
-    // arithmetic is 32-bit - the 64-bit i % 640, i / 640, t % n_local per thread of the first version cost more than the hashing itself
-    __shared__ uint32_t pre_row[2];
-    const uint32_t i0 = blockIdx.x * 256u, row0 = i0 / 640u, rem0 = i0 - row0 * 640u;
-    if (threadIdx.x < 2) {
+    // keep bits: FOUR bytes (32 draws of one row) per thread, one 32-bit store.  A workgroup's 1024 bytes span at most three rows (b, sample,
+    // head) of 640 bytes: the row's hash prefix (four hnet_mix32 and, with a run-time n_local, an integer division) is formed by three threads
+    // and shared through LDS, and all index arithmetic is 32-bit - the 64-bit i % 640, i / 640, t % n_local per thread of the first version
+    // cost more than the hashing itself; with one byte per thread (round 2) the per-thread overhead was still half of the instructions
+    __shared__ uint32_t pre_row[3];
+    const uint32_t i0 = blockIdx.x * 1024u, row0 = i0 / 640u, rem0 = i0 - row0 * 640u;
+    if (threadIdx.x < 3) {
         const uint32_t row = row0 + threadIdx.x;                      // rows beyond the end are never read
         const uint32_t head = row & 1u, t = row >> 1;
         const uint32_t b = t / (uint32_t)n_local, sm = t - b * (uint32_t)n_local;
         pre_row[threadIdx.x] = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b), 2u * head, (uint32_t)s_begin + sm);
     }
     __syncthreads();
-    if (i < nmask) {
-        const uint32_t off = rem0 + threadIdx.x, wrap = off >= 640u ? 1u : 0u;
-        const int chunk = (int)(off - 640u * wrap);
+    if (4 * i < nmask) {                                              // nmask is a multiple of 640: the four bytes are all in or all out
+        const uint32_t off = rem0 + 4u * threadIdx.x, wrap = (off >= 640u ? 1u : 0u) + (off >= 1280u ? 1u : 0u);
+        const int chunk = (int)(off - 640u * wrap);                   // multiple of 4: the four bytes lie in one row and in one pixel's channel run
         const uint32_t pre = pre_row[wrap];
         const int k0 = chunk * 8, pix = k0 >> 8, c0 = k0 & 255;
-        // hnet_mask_keep(pre, element, thr) for the 8 elements (c0 + e) * 20 + pix of the byte: element * 0xc2b2ae35 + 0x27d4eb2f (hnet_rng.h,
+        // hnet_mask_keep(pre, element, thr) for the 32 elements (c0 + e) * 20 + pix: element * 0xc2b2ae35 + 0x27d4eb2f (hnet_rng.h,
         // hnet_mask_bits) advances by the constant 20 * 0xc2b2ae35 (mod 2^32) from one to the next - one quarter-rate integer multiply per
-        // byte instead of eight (the two multiplies inside hnet_mix32 remain): same bits
+        // thread instead of one per element (the two multiplies inside hnet_mix32 remain): same bits
         uint32_t em = (uint32_t)(c0 * 20 + pix) * 0xc2b2ae35U + 0x27d4eb2fU;
+        const uint32_t thr8 = thr << 8;                               // (x >> 8) >= thr  <=>  x >= thr << 8 for thr < 2^24; thr = 2^24 (p = 1) keeps nothing
         uint32_t bits = 0;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            bits |= (hnet_mix32(pre ^ em) >> 8) >= thr ? (1u << e) : 0u;
+        for (int e = 0; e < 32; e++) {
+            const uint32_t x = hnet_mix32(pre ^ em);
+            bits |= (thr < (1u << 24) && x >= thr8) ? (1u << e) : 0u;
             em += 20U * 0xc2b2ae35U;
         }
-        mask[i] = (uint8_t)bits;
+        reinterpret_cast<uint32_t*>(mask)[i] = bits;
     }
 }
 

@@ -351,10 +351,10 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
                                   uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                   uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
                                   const uint64_t* seq_dev, int tile) {
-    const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 640);
-    // heads_prep_kernel forms its element and row indices in 32 bits (i0 = blockIdx.x * 256, row = i0 / 640): refuse what would wrap
-    // (batch x n_local beyond ~3.3 M rows; hnet_create rejects such a max_batch x N as well)
-    if (nwork + 256 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+    const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 160);      // one feature element, four mask bytes per thread
+    // heads_prep_kernel forms its byte and row indices in 32 bits (i0 = blockIdx.x * 1024, row = i0 / 640): refuse what would wrap
+    // (batch x n_local beyond ~3.3 M rows, or more than ~200 k pairs; hnet_create rejects such a max_batch x N as well)
+    if (4 * nwork + 1024 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
                        hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP);
     S3Params p = {};
