@@ -719,8 +719,10 @@ __device__ __forceinline__ int s3_swz_m16(int row, int chunk) {
     return CH == 4 ? (chunk ^ (((row >> 3) & 1) * 3)) * 8 : (chunk ^ ((row >> 1) & 7)) * 8;   // bf16 elements
 }
 
+// (launch bounds: the 128 x 128 tiles hold 64 x 64 per wave - 128 accumulator registers in the fp16 mode; asking for two waves per SIMD keeps
+// them at <= 256 registers, 226 without scratch, where the default heuristic took 264 and with it half of the occupancy)
 template <class L, int BM, int BN, int WGM, bool OUT32, int BKT = 64, int NP = 3>
-__global__ __launch_bounds__(256) void igemm_s3_lean_kernel(S3Params p) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 64 ? 2 : 1)) void igemm_s3_lean_kernel(S3Params p) {
     constexpr int BK = BKT;
     constexpr int CH = BK / 8, RPP = 256 / CH;
     constexpr int WGN = 4 / WGM;

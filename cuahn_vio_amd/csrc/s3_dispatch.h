@@ -164,8 +164,12 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
             if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         }
         if constexpr (CIN == 256) { if (big_m && tile != 9) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }   // (tile 9: experiment, 64 x 64 + split-K policy of run_s3)
-        // (fp16 mode: two accumulators per tile - the 128x128 tile would need 128 accumulator registers: 0.091 ms against 0.080 ms with 64x64)
-        if constexpr (CIN == 128 && KS == 5 && NP != 2) { if (big_m && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+        // (fp16 mode: two accumulators per tile = 128 accumulator registers.  At 264 registers, one wave per SIMD, the 128x128 tile lost - 0.091 ms
+        // against 0.080 ms with 64x64; with the kernel's launch bounds asking for two waves per SIMD it fits 226 without scratch and wins on
+        // this one layer, 0.0694 against 0.0769 ms at batch 256 (K = 3200, N = 128: the im2col tile is staged once for all of N); on every
+        // other layer and on the heads it still loses by 7 - 30 %: experiment 17)
+        // (measured per batch in the fp16 mode, 64x64 / 128x128: batch 64 0.0291 / 0.0344, 128 0.0537 / 0.0448, 256 0.0734 / 0.0676 ms -> from M = 8192)
+        if constexpr (CIN == 128 && KS == 5) { if ((NP == 2 ? p.M >= 8192 : big_m) && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
     }
 }
