@@ -882,6 +882,153 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 64 ? 2 : 1)) void igemm_s3_le
 }
 
 // ---------------------------------------------------------------------------------------------
+// Eight-wave variant of the lean kernel (experiment, HNET_S3_TILE=12): 128 x 128 workgroup tile, 512 threads as 2 x 4 waves
+// of 64 x 32 each, DOUBLE-BUFFERED LDS with ONE barrier per K-tile (tile it + 1 is stored into the other buffer after the MFMAs of tile it; every
+// wave left that buffer at the barrier of tile it - 1).  Per MFMA the activation tile is staged once for 128 instead of 64 output channels
+// (ds_write bytes - 33 %), the fragment reads are those of the four-wave kernel.  Same K order and MFMA sequence: same bits.  Dynamic LDS
+// (2 x 64 KB of tiles + the mask table).
+// ---------------------------------------------------------------------------------------------
+template <class L, bool OUT32, int NP>
+__global__ __launch_bounds__(512, 2) void igemm_s3_lean8_kernel(S3Params p) {
+    constexpr int BM = 128, BN = 128, BK = 64, WGM = 2, NT = 512;
+    constexpr int CH = BK / 8, RPP = NT / CH;
+    constexpr int WGN = (NT / 64) / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM16 = WM / 16, TN16 = WN / 16;
+    static_assert(NP == 2 && WM == 64 && WN == 32, "the fp16-plane mode, 64 x 32 per wave");
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;
+    constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
+    constexpr int NW = s3_wplanes_gemm<NP>;
+    constexpr int STAGE = NP * TILE_A + NW * TILE_B;               // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem8[];
+    uint16_t* const lut = smem8 + 2 * STAGE;                       // 256 entries x 16 bytes (heads only)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    int m0, n0;
+    s3_tile_origin(p, BM, BN, m0, n0);
+    const int srow = tid / CH, schunk = tid % CH;
+
+    if constexpr (L::HAS_MASK) {
+        if (tid < 256) {
+            u32x4 e;
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = ((tid >> (2 * j)) & 1u) * 0xFFFFu | ((tid >> (2 * j + 1)) & 1u) * 0xFFFF0000u;
+            *reinterpret_cast<u32x4*>(&lut[tid * 8]) = e;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7FFFFFF0, 0x00020000);
+
+    LeanRow<L> rows[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) rows[i] = LeanRow<L>::make(p, m0 + srow + i * RPP, n0, schunk);
+    uint32_t wvoff[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) {
+        const int n = n0 + srow + i * RPP;
+        wvoff[i] = n < p.N ? (uint32_t)((n * p.Kp + schunk * 8) * 2) : S3_OOB;
+    }
+    int a_lds[A_ROWS], b_lds[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; i++) a_lds[i] = (srow + i * RPP) * BK + s3_swz_m16<CH>(srow + i * RPP, schunk);
+#pragma unroll
+    for (int i = 0; i < B_ROWS; i++) b_lds[i] = (srow + i * RPP) * BK + s3_swz_m16<CH>(srow + i * RPP, schunk);
+
+    f32x4_m16 acc16[TM16][TN16], acc16l[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; i++)
+#pragma unroll
+        for (int j = 0; j < TN16; j++) { acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f}; acc16l[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f}; }
+
+    u32x4 areg[A_ROWS][3], breg[B_ROWS][3];
+    uint32_t amask[A_ROWS];
+    const int n_iter_total = (p.Kp + BK - 1) / BK;
+    const int it0 = (int)(((long)blockIdx.z * n_iter_total) / p.k_split);
+    const int n_iter = (int)(((long)(blockIdx.z + 1) * n_iter_total) / p.k_split) - it0;
+    const int a_pl = (int)(p.a_plane * 2), w_pl = (int)(p.w_plane * 2);
+
+    auto g_load = [&](int it) {
+        const typename LeanRow<L>::Tap t = LeanRow<L>::template tap<BK>(p, it);
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            const uint32_t vo = rows[i].voffset(p, t);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                areg[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, vo, pl * a_pl, 0));
+            if constexpr (L::HAS_MASK) amask[i] = p.mask[rows[i].moff + (size_t)it * (BK / 8)];
+        }
+        const int ws = it * BK * 2;
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++)
+#pragma unroll
+            for (int pl = 0; pl < NW; pl++)
+                breg[i][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, wvoff[i], ws + pl * w_pl, 0));
+    };
+    auto s_store = [&](int buf) {
+        uint16_t* As = smem8 + buf * STAGE;
+        uint16_t* Bs = As + NP * TILE_A;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; i++) {
+            u32x4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if constexpr (L::HAS_MASK) mk = *reinterpret_cast<const u32x4*>(&lut[amask[i] * 8]);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                u32x4 v = areg[i][pl];
+                if constexpr (L::HAS_MASK) { v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3]; }
+                *reinterpret_cast<u32x4*>(&As[pl * TILE_A + a_lds[i]]) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; i++)
+#pragma unroll
+            for (int pl = 0; pl < NW; pl++) *reinterpret_cast<u32x4*>(&Bs[pl * TILE_B + b_lds[i]]) = breg[i][pl];
+    };
+
+    if constexpr (L::HAS_MASK) __syncthreads();
+    g_load(it0);
+    s_store(0);
+    __syncthreads();
+
+    const int r16 = lane & 15, g16 = lane >> 4;
+    for (int it = 0; it < n_iter; it++) {
+        if (it + 1 < n_iter) g_load(it0 + it + 1);
+        const uint16_t* As = smem8 + (it & 1) * STAGE;
+        const uint16_t* Bs = As + NP * TILE_A;
+#pragma unroll
+        for (int step = 0; step < BK / 32; step++) {
+            bf16x8 af[TM16][3], bf[TN16][3];
+#pragma unroll
+            for (int i = 0; i < TM16; i++) {
+                const int r = wm * WM + i * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++)
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN16; j++) {
+                const int r = wn * WN + j * 16 + r16;
+#pragma unroll
+                for (int pl = 0; pl < NW; pl++)
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<CH>(r, 4 * step + g16)]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM16; i++)
+#pragma unroll
+                for (int j = 0; j < TN16; j++) s3_mfma16_2acc(acc16[i][j], acc16l[i][j], bf[j], af[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < n_iter) s_store((it + 1) & 1);      // the other buffer: every wave finished reading it before the previous barrier
+        __syncthreads();                                 // ONE barrier per K-tile
+    }
+#pragma unroll
+    for (int i = 0; i < TM16; i++)
+#pragma unroll
+        for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
+    s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem8 + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-DMA variant: the operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
 // no VGPR staging, no ds_write) into an NSTAGE-deep ring, two K-tiles in flight; one raw s_barrier per K-tile and
 // counted vmcnt waits (never __syncthreads(), which would drain the DMAs).  The DMA writes LDS linearly

@@ -34,7 +34,10 @@ static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hip
 }
 #define finish_split(p, split, ws, s) finish_split_impl<OUT32, NP>(p, split, ws, s)
 
-template <class L, int BM, int BN, int WGM, bool OUT32, int NP>
+constexpr int LEAN8_LDS_BYTES = 2 * (2 * 128 * 64 + 2 * 128 * 64) * 2 + 256 * 16;      // igemm_s3_lean8_kernel: two buffers of tiles + the mask table
+
+// LEAN8: the eight-wave double-buffered kernel (igemm_s3_lean8_kernel; 128 x 128 tiles, fp16-plane mode, layers whose K-tiles hold 64 channels)
+template <class L, int BM, int BN, int WGM, bool OUT32, int NP, bool LEAN8 = false>
 static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
     const long tiles = (long)grid.x * grid.y;
@@ -56,6 +59,14 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     // the lean staging of round 2 (0.1116 vs 0.1086 ms on block_3_2, profiles/r02_ab_s3_dma.log) -> off in split-bf16 mode, on in plain bf16
     static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : (NP == 3 ? 0 : 3);
 
+    if constexpr (NP == 2 && BM == 128 && BN == 128 && L::WIDE_TAPS) {
+        if constexpr (L::template lean_ok<64>()) {
+            if (LEAN8 || p.tile == 12) {                             // (tile 12: the experiment switch that puts every >= 128-channel layer on it)
+                hipLaunchKernelGGL((igemm_s3_lean8_kernel<L, OUT32, NP>), grid, dim3(512), LEAN8_LDS_BYTES, s, p);
+                return finish_split(p, split, ws, s);
+            }
+        }
+    }
     if constexpr (NP == 2) {
         // fp16 planes: the lean kernel (the measured winner of the split-bf16 dispatch below) on every layer it covers, its 64-wide K tiles
         // where a tap holds >= 64 channels; the register-staged kernel in its 16x16x32 form for the rest (ragged operator-level shapes)
@@ -159,7 +170,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         const bool big_m = p.M >= 4096;
         if constexpr (NP != 1) {
             if (tile == 1) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn);
-            if constexpr (COUT >= 128) { if (tile == 2) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+            if constexpr (COUT >= 128) { if (tile == 2 || (tile == 12 && big_m)) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
             if constexpr (COUT >= 128 && NP == 2) { if (tile == 8 && big_m) return run_s3<L, 64, 128, 2, OUT32, NP>(p, s, ws, wsn); }   // experiment: all (or half) of N per workgroup: the im2col tile is staged once
             if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         }
@@ -367,7 +378,14 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     p.M = batch * n_local; p.N = 512; p.Kp = 5120;
     p.mask = mask; p.n_local = n_local; p.tile = tile;
     if constexpr (NP == 2) {
-        if (tile == 2 && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn);
+        if ((tile == 2 || tile == 12) && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn);
+        // Eight waves on 128 x 128 tiles, double-buffered LDS, one barrier per K-tile (igemm_s3_lean8_kernel): one workgroup per CU, so it
+        // pays when the 4 x M / 128 tiles fill whole rounds of the 256 CUs.  heads_fc1, ms, 128 x 64 four-wave / this kernel (N = 32):
+        // batch 128 0.116 / 0.112, 192 0.162 / 0.144, 256 0.180 / 0.158, 320 0.255 / 0.276, 384 0.264 / 0.278, 512 0.359 / 0.319
+        // -> up to one round, or when the last round is at least three quarters full (HNET_S3_TILE=13: the four-wave kernel)
+        const long t8 = (long)((p.M + 127) / 128) * 4;
+        if (tile != 13 && tile != 3 && p.M >= 4096 && (t8 <= 256 || t8 % 256 == 0 || t8 % 256 >= 192))
+            return run_s3<HeadLoaderS3, 128, 128, 2, true, NP, true>(p, s, ws, wsn);
         if (tile == 3) return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, nullptr, 0);       // experiment: 64 x 64 tiles (four workgroups per CU) at large M
     }
     // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
@@ -422,6 +440,15 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
     }
     if constexpr (NP == 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<HeadLoaderS3, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        // (the conv-layer instances exist for the HNET_S3_TILE=12 experiment only)
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 5, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<64, 5, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<64, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }
