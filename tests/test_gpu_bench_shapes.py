@@ -286,3 +286,27 @@ def test_block42_fused_kernel_elementwise(blob, state, batch):
         for b in (9, 15):
             assert np.array_equal(eng.op_block42_fused(x[b:b + 1])[0], got[b])
     eng.close()
+
+
+@pytest.mark.parametrize("batch,n_mc", [(192, 32), (256, 32), (512, 16)])
+def test_heads_eight_wave_kernel_equals_the_four_wave_kernel_bitwise(blob, batch, n_mc):
+    """heads FC1 (model_to_trace.py:222-225,229-232) runs on igemm_s3_lean8_kernel (eight waves, 128 x 128 tiles, double-buffered LDS) when its
+    tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N = 6144 / 8192 / 8192 rows here = 192 / 256 / 256 tiles.  Same K order and MFMA
+    sequence as the four-wave 128 x 64 kernel (HNET_S3_TILE=13, read at hnet_create): every output bit must agree."""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, prior = _batch(9000 + batch, 16, batch)
+    out = []
+    for tile in ("0", "13"):
+        old = os.environ.get("HNET_S3_TILE")
+        os.environ["HNET_S3_TILE"] = tile
+        try:
+            eng = HnetEngine(blob, variant="prior3", mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=batch, precision=3)
+        finally:
+            if old is None:
+                del os.environ["HNET_S3_TILE"]
+            else:
+                os.environ["HNET_S3_TILE"] = old
+        out.append(eng.infer_batch(prev, curr, prior, pair_seq0=77))
+        eng.close()
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
