@@ -288,10 +288,10 @@ def test_block42_fused_kernel_elementwise(blob, state, batch):
     eng.close()
 
 
-@pytest.mark.parametrize("batch,n_mc", [(192, 32), (256, 32), (512, 16)])
+@pytest.mark.parametrize("batch,n_mc", [(192, 32), (250, 32), (256, 32), (512, 16)])
 def test_heads_eight_wave_kernel_equals_the_four_wave_kernel_bitwise(blob, batch, n_mc):
     """heads FC1 (model_to_trace.py:222-225,229-232) runs on igemm_s3_lean8_kernel (eight waves, 128 x 128 tiles, double-buffered LDS) when its
-    tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N = 6144 / 8192 / 8192 rows here = 192 / 256 / 256 tiles.  Same K order and MFMA
+    tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N = 6144 / 8000 (ragged last tile) / 8192 / 8192 rows here = 192 / 252 / 256 / 256 tiles.  Same K order and MFMA
     sequence as the four-wave 128 x 64 kernel (HNET_S3_TILE=13, read at hnet_create): every output bit must agree."""
     from cuahn_vio_amd.homography_net import HnetEngine
     prev, curr, prior = _batch(9000 + batch, 16, batch)
