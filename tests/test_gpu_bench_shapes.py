@@ -310,3 +310,22 @@ def test_heads_eight_wave_kernel_equals_the_four_wave_kernel_bitwise(blob, batch
         eng.close()
     assert np.isfinite(out[0][0]).all()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle):
+    """bench.py's workload with 256 DISTINCT pairs (textures, homographies), default arithmetic (two fp16 planes, fast sampler): all 256 slots
+    against the oracle, not a selection (tools/full_batch_check.py prints the distribution; profiles/r03_v10_full_batch_check.log: max 7.5e-5 px)."""
+    from cuahn_vio_amd.homography_net import HnetEngine
+    B, n_mc = 256, 32
+    prev, curr, _prior = _batch(70000, B, B)
+    eng = HnetEngine(blob, variant="full", mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=B, precision=3)
+    mean, cov = eng.infer_batch(prev, curr, None, pair_seq0=4242)
+    eng.close()
+    worst = 0.0
+    for b in range(B):
+        o = oracle.forward(prev[b], curr[b], None, 3, n_mc, 0.05, MC_SEED, 4242 + b)
+        d = float(np.abs(mean[b] - o["mean"]).max())
+        worst = max(worst, d)
+        assert d < TOL_PX_VS_ORACLE, (b, d)
+        assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
+    print(f"all {B} slots: max |hip - oracle| = {worst:.2e} px")
