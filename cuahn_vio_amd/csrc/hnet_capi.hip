@@ -1471,7 +1471,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
-                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes));
+                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes, c->s3_tile));
         } else {
             HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
             if (conv_is_first_s2(layer) && c->first_s2 && c->s2_frag[layer] && h == (layer == 0 ? 28 : 56) && w == (layer == 0 ? 40 : 80))

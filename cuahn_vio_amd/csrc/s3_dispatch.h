@@ -5,6 +5,7 @@
 #include "igemm.h"
 #include "conv_first.h"
 #include "igemm_s3.h"
+#include "igemm_pipe.h"
 #include "conv_b4_fused.h"
 #include "conv_b3_fused.h"
 #include "conv_b42_fused.h"
@@ -160,10 +161,37 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     }
 }
 
+// igemm_pipe.h: the software-pipelined LDS-DMA kernel on whole-pair tiles (fp16-plane mode).  Per layer shape the tile that makes the grid
+// exactly 256 or 512 workgroups at batch 256 (70 / 280 / 20 GEMM rows per pair):
+//   128 -> 256 3x3 (block_2_3 / 3_4 / 4_5, 70/pair)   160 (140) x 128, eight waves of 80 x 32                    2 pairs x 2 channel halves: 256 workgroups
+//   64 -> 128 5x5 / 3x3 (block_2_2, 3_3, 4_4, 280)    160 (140) x 128, eight waves                               half a pair: 512 workgroups
+template <class L, class C, bool OUT32>
+static hipError_t run_pipe(S3Params p, hipStream_t s) {
+    dim3 grid((p.M + C::BMV - 1) / C::BMV, p.N / C::BN, 1);
+    p.k_split = 1;
+    hipLaunchKernelGGL((igemm_s3_pipe_kernel<L, C, OUT32>), grid, dim3(C::NT), C::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+typedef PipeCfg<5, 2, 2, 4, 140> PipeCfg140;     // 160 x 128, 512 threads
+// the layers it serves, measured in process against the four-wave lean kernels at batch 256 (profiles/r04_ab_pipe*.log): the 160 (140) x 128 tile
+// wins on block_2_2 (- 18 %), block_2_3 / 3_4 / 4_5 (- 22 %) and block_3_3 / 4_4 (- 2 ... - 6 %).  Four-wave tiles of 80 x 128 / 80 x 64 for
+// block_1_2 and the 4 x 5 layers LOST (+ 4 % / + 21 %): they need 55 / 77 B / clk / CU from the texture addresser, whose limit is 64
+template <int CIN, int KS, int COUT>
+static bool pipe_ok(const S3Params& p) {
+    const int rows = p.Ho * p.Wo;                 // GEMM rows per pair
+    if ((p.M < 2048 && p.tile != 21) || p.tile == 20) return false;     // (HNET_S3_TILE=20: the four-wave lean kernels, A/B; 21: this kernel at any M, tests)
+    if (CIN == 128 && KS == 3 && COUT == 256 && rows % 70 == 0) return true;
+    if (CIN == 64 && COUT == 128 && rows % 140 == 0) return true;
+    return false;
+}
+
 template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
 static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
     const int tile = p.tile;                                 // experiments (HNET_S3_TILE, read by hnet_create)
+    if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
+        if (pipe_ok<CIN, KS, COUT>(p)) return run_pipe<L, PipeCfg140, OUT32>(p, s);
+    }
     if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
     else {
         // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
@@ -449,6 +477,10 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
+#define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
+        typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;
+        HNET_PIPE_ATTR(L1283, PipeCfg140, false); HNET_PIPE_ATTR(L645, PipeCfg140, false); HNET_PIPE_ATTR(L643, PipeCfg140, false);
+#undef HNET_PIPE_ATTR
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }
