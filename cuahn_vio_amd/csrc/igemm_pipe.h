@@ -310,7 +310,9 @@ __global__ __launch_bounds__(NT_, WPS_) void igemm_s3_pipe_kernel(S3Params p) {
 // Same products in the same order per accumulator as igemm_s3_lean8_kernel<HeadLoaderS3>: bit-identical results.
 // ---------------------------------------------------------------------------------------------
 struct HeadsPipeCfg {
-    static constexpr int BM = 128, BN = 128, BK = 64, NWAVE = 8, NT = 512, TM = 4, TN = 2, WVN = 4;
+    // waves as 4 (M) x 2 (N), 32 x 64 each: a masked A fragment (8 vector ANDs) then feeds 12 MFMAs - with 64 x 32 per wave (6 MFMAs per fragment) the
+    // ANDs and the MFMAs of the two waves of a SIMD filled 94 % of its vector issue (an MFMA holds it for 8 of its 16 cycles, a vector instruction for 4)
+    static constexpr int BM = 128, BN = 128, BK = 64, NWAVE = 8, NT = 512, TM = 2, TN = 4, WVN = 2;
     static constexpr int TILE_A = BM * BK, TILE_B = BN * BK;                  // halves per plane (A: up to 128 distinct pairs)
     static constexpr int MASK_H = BM * 8 / 2;                                 // the mask tile, in halves
     static constexpr int STAGE = 2 * (TILE_A + TILE_B) + MASK_H;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void igemm_heads_pipe_kernel(S3Params p) {
 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask, 0, p.M * 1280, 0x00020000);   // (reads beyond the last row's bytes return zeros)
     const int a_pl = (int)(p.a_plane * 2), w_pl = (int)(p.w_plane * 2);
 
     // ---- DMA: weights, two 8-row groups per wave (16 groups); the distinct pairs of A, group g by wave g % 8; the mask tile by wave 7
@@ -414,30 +416,36 @@ __global__ __launch_bounds__(512, 2) void igemm_heads_pipe_kernel(S3Params p) {
     }
     bf16x8 fa[2][TM][2], fb[2][TN][2];
     uint32_t mb[2][TM];                                              // keep byte of (M-tile i, this lane's chunk) per set
-    auto read_frags = [&](int set, int stage, int st) {
+    u32x4 mk[2][TM];                                                 // its 16-byte AND mask
+    // the reads of the next fragment set in three parts (scheduled under the MFMA groups of the current one): keep bytes + A rows | weights 0, 1 | weights 2, 3
+    auto read_part = [&](int set, int stage, int st, int part) {
         const uint16_t* sb = smem_h + stage * STAGE;
-        const uint8_t* mt = reinterpret_cast<const uint8_t*>(sb + 2 * (TILE_A + TILE_B));
+        if (part == 0) {
+            const uint8_t* mt = reinterpret_cast<const uint8_t*>(sb + 2 * (TILE_A + TILE_B));
 #pragma unroll
-        for (int i = 0; i < TM; i++) mb[set][i] = mt[m_off[i] + 4 * st];
+            for (int i = 0; i < TM; i++) mb[set][i] = mt[m_off[i] + 4 * st];
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++) fa[set][i][pl] = *reinterpret_cast<const bf16x8*>(&sb[a_off[st][i] + pl * TILE_A]);
+                for (int pl = 0; pl < 2; pl++) fa[set][i][pl] = *reinterpret_cast<const bf16x8*>(&sb[a_off[st][i] + pl * TILE_A]);
+        } else {
 #pragma unroll
-        for (int jn = 0; jn < TN; jn++)
+            for (int jn = 2 * (part - 1); jn < 2 * part; jn++)
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++) fb[set][jn][pl] = *reinterpret_cast<const bf16x8*>(&sb[b_off[st] + pl * TILE_B + jn * 16 * BK]);
+                for (int pl = 0; pl < 2; pl++) fb[set][jn][pl] = *reinterpret_cast<const bf16x8*>(&sb[b_off[st] + pl * TILE_B + jn * 16 * BK]);
+        }
     };
-    auto apply_mask = [&](int set) {                                 // keep byte -> 16-byte AND mask (LDS table) -> both planes of the fragment
+    auto read_frags = [&](int set, int stage, int st) { read_part(set, stage, st, 0); read_part(set, stage, st, 1); read_part(set, stage, st, 2); };
+    auto read_lut = [&](int set) {                                   // keep byte -> 16-byte AND mask (4 KB LDS table)
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const u32x4 mk = *reinterpret_cast<const u32x4*>(&lut[mb[set][i] * 8]);
+        for (int i = 0; i < TM; i++) mk[set][i] = *reinterpret_cast<const u32x4*>(&lut[mb[set][i] * 8]);
+    };
+    auto and_row = [&](int set, int i) {                             // both planes of the fragment of M-tile i
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++) {
-                u32x4 v = __builtin_bit_cast(u32x4, fa[set][i][pl]);
-                v[0] &= mk[0]; v[1] &= mk[1]; v[2] &= mk[2]; v[3] &= mk[3];
-                fa[set][i][pl] = __builtin_bit_cast(bf16x8, v);
-            }
+        for (int pl = 0; pl < 2; pl++) {
+            u32x4 v = __builtin_bit_cast(u32x4, fa[set][i][pl]);
+            v[0] &= mk[set][i][0]; v[1] &= mk[set][i][1]; v[2] &= mk[set][i][2]; v[3] &= mk[set][i][3];
+            fa[set][i][pl] = __builtin_bit_cast(bf16x8, v);
         }
     };
 
@@ -446,15 +454,32 @@ __global__ __launch_bounds__(512, 2) void igemm_heads_pipe_kernel(S3Params p) {
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int jn = 0; jn < TN; jn++) { acc[i][jn] = f32x4_m16{0.f, 0.f, 0.f, 0.f}; accl[i][jn] = f32x4_m16{0.f, 0.f, 0.f, 0.f}; }
-    auto mfma = [&](int set) {
+    auto mfma_part = [&](int set, int i, int j0) {                 // two of the four 16-channel tiles of M-tile i
 #pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int jn = 0; jn < TN; jn++) {
-                bf16x8 w3[3] = {fb[set][jn][0], fb[set][jn][1], fb[set][jn][0]}, a3[3] = {fa[set][i][0], fa[set][i][1], fa[set][i][0]};
-                s3_mfma16_2acc(acc[i][jn], accl[i][jn], w3, a3);
-            }
+        for (int jn = j0; jn < j0 + 2; jn++) {
+            bf16x8 w3[3] = {fb[set][jn][0], fb[set][jn][1], fb[set][jn][0]}, a3[3] = {fa[set][i][0], fa[set][i][1], fa[set][i][0]};
+            s3_mfma16_2acc(acc[i][jn], accl[i][jn], w3, a3);
+        }
     };
+    // One half of a K-tile: the 24 MFMAs of fragment set `cur` (whose table masks are in registers) in four groups of six with, underneath them, the AND
+    // of the second row, the reads of the next set (2 keep bytes + 12 fragments) and, once its keep bytes are back, its table lookups.
+#define HNET_HEADS_HALF(cur, nxt, stage, st, WITH_NEXT)                                         \
+    do {                                                                                        \
+        and_row(cur, 0);                                                                        \
+        if (WITH_NEXT) read_part(nxt, stage, st, 0);                                            \
+        mfma_part(cur, 0, 0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (WITH_NEXT) read_part(nxt, stage, st, 1);                                            \
+        mfma_part(cur, 0, 2);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        and_row(cur, 1);                                                                        \
+        if (WITH_NEXT) read_part(nxt, stage, st, 2);                                            \
+        mfma_part(cur, 1, 0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (WITH_NEXT) read_lut(nxt);                     /* the keep bytes came back long ago */ \
+        mfma_part(cur, 1, 2);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
 
     const bool y_half = wave >= NWAVE / 2;                           // (ping-pong of the DMA issue: igemm_s3_pipe_kernel)
     dma(0, 0);
@@ -463,35 +488,31 @@ __global__ __launch_bounds__(512, 2) void igemm_heads_pipe_kernel(S3Params p) {
     __builtin_amdgcn_sched_barrier(0);
     if (n_iter > 1 && !y_half) dma(1, 1);
     read_frags(0, 0, 0);
+    read_lut(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    apply_mask(0);
+    __builtin_amdgcn_sched_barrier(0);
 
     for (int it = 0; it < n_iter - 1; it++) {
         const int cur = it & 1;
         if (y_half) dma(it + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(1, cur, 1);
-        mfma(0);
-        __builtin_amdgcn_sched_barrier(0);
+        HNET_HEADS_HALF(0, 1, cur, 1, true);
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (it + 2 < n_iter && !y_half) dma(it + 2, cur);
         __builtin_amdgcn_sched_barrier(0);
-        apply_mask(1);
-        read_frags(0, cur ^ 1, 0);
-        mfma(1);
-        __builtin_amdgcn_sched_barrier(0);
+        HNET_HEADS_HALF(1, 0, cur ^ 1, 0, true);
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        apply_mask(0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     {
-        read_frags(1, (n_iter - 1) & 1, 1);
-        mfma(0);
+        HNET_HEADS_HALF(0, 1, (n_iter - 1) & 1, 1, true);
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        apply_mask(1);
-        mfma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        HNET_HEADS_HALF(1, 0, 0, 0, false);
     }
+#undef HNET_HEADS_HALF
 
 #pragma unroll
     for (int i = 0; i < TM; i++)

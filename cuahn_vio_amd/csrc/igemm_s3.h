@@ -678,7 +678,11 @@ struct LeanRow<ConvLoaderS3<CIN, KS, STRIDE, SEG>> {
     template <int BK>
     __device__ static inline Tap tap(const S3Params& p, int it) {
         static_assert(CIN % BK == 0 && L::RL % SEG == 0, "a K-tile lies inside one tap");
+#ifdef HNET_S3_TRACE
+        const int kp = (it * BK) % (KS * KS * CIN), t = kp / CIN, ci0 = kp - t * CIN;      // (tools/trace_pipe.hip: K sweeps beyond the filter wrap around)
+#else
         const int kp = it * BK, t = kp / CIN, ci0 = kp - t * CIN;
+#endif
         Tap x;
         x.kh = t / KS; x.kw = t - x.kh * KS;
         x.delta = ((x.kh * p.W + x.kw) * CIN + ci0) * 2;
@@ -1236,7 +1240,7 @@ static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
 static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __restrict__ feat, int batch, int n_local, int s_begin,
                                                          uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                          const uint64_t* __restrict__ seq_dev,
-                                                         uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask, int np) {
+                                                         uint16_t* __restrict__ feat16, size_t f_plane, uint8_t* __restrict__ mask, int np, int ktile_layout) {
     // (plain-bf16 mode reads plane 0 only; writing all three costs nothing measurable here)
     const size_t nfeat = (size_t)batch * 5120;
     const size_t nmask = (size_t)batch * n_local * 2 * 640;
@@ -1247,13 +1251,16 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
         feat16[i] = a; feat16[f_plane + i] = b;
         if (np != 2) feat16[2 * f_plane + i] = c;
     }
-    // keep bits: FOUR bytes (32 draws of one row) per thread, one 32-bit store.  A workgroup's 1024 bytes span at most three rows (b, sample,
+    // keep bits: FOUR bytes (32 draws of one row) per thread, one 32-bit store.
+    // Row-major layout (ktile_layout = 0: [B][n_local][2 heads][640 bytes]): a workgroup's 1024 bytes span at most three rows (b, sample,
     // head) of 640 bytes: the row's hash prefix (four hnet_mix32 and, with a run-time n_local, an integer division) is formed by three threads
     // and shared through LDS, and all index arithmetic is 32-bit - the 64-bit i % 640, i / 640, t % n_local per thread of the first version
-    // cost more than the hashing itself; with one byte per thread (round 2) the per-thread overhead was still half of the instructions
+    // cost more than the hashing itself; with one byte per thread (round 2) the per-thread overhead was still half of the instructions.
+    // K-tile-major layout (ktile_layout = 1, igemm_heads_pipe_kernel: [2 heads][80 K-tiles][M rows][8 bytes]): consecutive threads are the two
+    // halves of consecutive ROWS of one K-tile (coalesced 4-byte stores), every thread forms its own row prefix.
     __shared__ uint32_t pre_row[3];
     const uint32_t i0 = blockIdx.x * 1024u, row0 = i0 / 640u, rem0 = i0 - row0 * 640u;
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 3 && !ktile_layout) {
         const uint32_t row = row0 + threadIdx.x;                      // rows beyond the end are never read
         const uint32_t head = row & 1u, t = row >> 1;
         const uint32_t b = t / (uint32_t)n_local, sm = t - b * (uint32_t)n_local;
@@ -1261,9 +1268,21 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
     }
     __syncthreads();
     if (4 * i < nmask) {                                              // nmask is a multiple of 640: the four bytes are all in or all out
-        const uint32_t off = rem0 + 4u * threadIdx.x, wrap = (off >= 640u ? 1u : 0u) + (off >= 1280u ? 1u : 0u);
-        const int chunk = (int)(off - 640u * wrap);                   // multiple of 4: the four bytes lie in one row and in one pixel's channel run
-        const uint32_t pre = pre_row[wrap];
+        uint32_t pre, oidx;
+        int chunk;                                                    // multiple of 4: the four bytes lie in one row and in one pixel's channel run
+        if (ktile_layout) {
+            const uint32_t M = (uint32_t)batch * (uint32_t)n_local, g = (uint32_t)i, half = g & 1u, t = g >> 1;
+            const uint32_t q = t / M, m = t - q * M, head = q / 80u, it = q - head * 80u;
+            const uint32_t b = m / (uint32_t)n_local, sm = m - b * (uint32_t)n_local;
+            pre = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b), 2u * head, (uint32_t)s_begin + sm);
+            chunk = (int)(it * 8u + half * 4u);
+            oidx = (q * M + m) * 2u + half;
+        } else {
+            const uint32_t off = rem0 + 4u * threadIdx.x, wrap = (off >= 640u ? 1u : 0u) + (off >= 1280u ? 1u : 0u);
+            chunk = (int)(off - 640u * wrap);
+            pre = pre_row[wrap];
+            oidx = (uint32_t)i;
+        }
         const int k0 = chunk * 8, pix = k0 >> 8, c0 = k0 & 255;
         // hnet_mask_keep(pre, element, thr) for the 32 elements (c0 + e) * 20 + pix: element * 0xc2b2ae35 + 0x27d4eb2f (hnet_rng.h,
         // hnet_mask_bits) advances by the constant 20 * 0xc2b2ae35 (mod 2^32) from one to the next - one quarter-rate integer multiply per
@@ -1277,7 +1296,7 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
             bits |= (thr < (1u << 24) && x >= thr8) ? (1u << e) : 0u;
             em += 20U * 0xc2b2ae35U;
         }
-        reinterpret_cast<uint32_t*>(mask)[i] = bits;
+        reinterpret_cast<uint32_t*>(mask)[oidx] = bits;
     }
 }
 

@@ -173,6 +173,7 @@ static hipError_t run_pipe(S3Params p, hipStream_t s) {
     return hipGetLastError();
 }
 typedef PipeCfg<5, 2, 2, 4, 140> PipeCfg140;     // 160 x 128, 512 threads
+typedef PipeCfg<3, 2, 3, 4, 140> PipeCfg144;     // 144 x 128, 768 threads (three waves per SIMD): 2.8 % instead of 12.5 % padded rows
 // the layers it serves, measured in process against the four-wave lean kernels at batch 256 (profiles/r04_ab_pipe*.log): the 160 (140) x 128 tile
 // wins on block_2_2 (- 18 %), block_2_3 / 3_4 / 4_5 (- 22 %) and block_3_3 / 4_4 (- 2 ... - 6 %).  Four-wave tiles of 80 x 128 / 80 x 64 for
 // block_1_2 and the 4 x 5 layers LOST (+ 4 % / + 21 %): they need 55 / 77 B / clk / CU from the texture addresser, whose limit is 64
@@ -190,7 +191,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
     const int tile = p.tile;                                 // experiments (HNET_S3_TILE, read by hnet_create)
     if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
-        if (pipe_ok<CIN, KS, COUT>(p)) return run_pipe<L, PipeCfg140, OUT32>(p, s);
+        if (pipe_ok<CIN, KS, COUT>(p)) return p.tile == 23 ? run_pipe<L, PipeCfg140, OUT32>(p, s) : run_pipe<L, PipeCfg144, OUT32>(p, s);
     }
     if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
     else {
@@ -398,14 +399,24 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     // heads_prep_kernel forms its byte and row indices in 32 bits (i0 = blockIdx.x * 1024, row = i0 / 640): refuse what would wrap
     // (batch x n_local beyond ~3.3 M rows, or more than ~200 k pairs; hnet_create rejects such a max_batch x N as well)
     if (4 * nwork + 1024 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+    // whole rounds of 128 x 128 tiles on the 256 CUs: the pipelined kernel (igemm_pipe.h), which reads its keep bits K-tile major
+    const int Mh = batch * n_local;
+    const long t8h = (long)((Mh + 127) / 128) * 4;
+    const bool one_per_cu = Mh >= 4096 && (t8h <= 256 || t8h % 256 == 0 || t8h % 256 >= 192);
+    const bool pipe = NP == 2 && one_per_cu && tile != 13 && tile != 3 && tile != 2 && tile != 12 && tile != 22;     // (HNET_S3_TILE=22: the eight-wave kernel of round 3, A/B)
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
-                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP);
+                       hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP, pipe ? 1 : 0);
     S3Params p = {};
     p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
     p.out32 = hidden;
     p.M = batch * n_local; p.N = 512; p.Kp = 5120;
     p.mask = mask; p.n_local = n_local; p.tile = tile;
     if constexpr (NP == 2) {
+        if (pipe) {
+            p.k_split = 1;
+            hipLaunchKernelGGL(igemm_heads_pipe_kernel<NP>, dim3((unsigned)((p.M + 127) / 128), 4, 1), dim3(HeadsPipeCfg::NT), HeadsPipeCfg::LDS_BYTES, s, p);
+            return hipGetLastError();
+        }
         if ((tile == 2 || tile == 12) && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn);
         // Eight waves on 128 x 128 tiles, double-buffered LDS, one barrier per K-tile (igemm_s3_lean8_kernel): one workgroup per CU, so it
         // pays when the 4 x M / 128 tiles fill whole rounds of the 256 CUs.  heads_fc1, ms, 128 x 64 four-wave / this kernel (N = 32):
@@ -480,7 +491,9 @@ hipError_t conv_kernels_init_device_np() {
 #define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
         typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;
         HNET_PIPE_ATTR(L1283, PipeCfg140, false); HNET_PIPE_ATTR(L645, PipeCfg140, false); HNET_PIPE_ATTR(L643, PipeCfg140, false);
+        HNET_PIPE_ATTR(L1283, PipeCfg144, false); HNET_PIPE_ATTR(L645, PipeCfg144, false); HNET_PIPE_ATTR(L643, PipeCfg144, false);
 #undef HNET_PIPE_ATTR
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_heads_pipe_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadsPipeCfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }

@@ -288,15 +288,17 @@ def test_block42_fused_kernel_elementwise(blob, state, batch):
     eng.close()
 
 
-@pytest.mark.parametrize("batch,n_mc", [(192, 32), (250, 32), (256, 32), (512, 16)])
-def test_heads_eight_wave_kernel_equals_the_four_wave_kernel_bitwise(blob, batch, n_mc):
-    """heads FC1 (model_to_trace.py:222-225,229-232) runs on igemm_s3_lean8_kernel (eight waves, 128 x 128 tiles, double-buffered LDS) when its
-    tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N = 6144 / 8000 (ragged last tile) / 8192 / 8192 rows here = 192 / 252 / 256 / 256 tiles.  Same K order and MFMA
-    sequence as the four-wave 128 x 64 kernel (HNET_S3_TILE=13, read at hnet_create): every output bit must agree."""
+@pytest.mark.parametrize("batch,n_mc", [(192, 32), (250, 32), (256, 32), (512, 16), (700, 12), (2050, 2)])
+def test_heads_gemm_kernels_agree_bitwise(blob, batch, n_mc):
+    """heads FC1 (model_to_trace.py:222-225,229-232) runs on igemm_heads_pipe_kernel (round 4: LDS-DMA, only the DISTINCT pairs of an M-tile in LDS,
+    keep bits applied to the fragments, K-tile-major mask layout) when its 128 x 128 tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N =
+    6144 / 8000 (ragged last tile) / 8192 / 8192 / 8400 (N = 12: tiles straddle pairs, 11 - 12 pairs per tile) / 4100 (N = 2: 64 - 65 pairs per tile,
+    nine A groups) rows here.  Same K order and MFMA sequence as the eight-wave kernel of round 3 (HNET_S3_TILE=22) and as the four-wave 128 x 64
+    kernel (HNET_S3_TILE=13, read at hnet_create): every output bit must agree."""
     from cuahn_vio_amd.homography_net import HnetEngine
     prev, curr, prior = _batch(9000 + batch, 16, batch)
     out = []
-    for tile in ("0", "13"):
+    for tile in ("0", "22", "13") if batch * n_mc >= 6144 else ("0", "13", "13"):    # (below 192 tiles the eight-wave kernel of round 3 runs split-K: another summation order)
         old = os.environ.get("HNET_S3_TILE")
         os.environ["HNET_S3_TILE"] = tile
         try:
@@ -309,7 +311,8 @@ def test_heads_eight_wave_kernel_equals_the_four_wave_kernel_bitwise(blob, batch
         out.append(eng.infer_batch(prev, curr, prior, pair_seq0=77))
         eng.close()
     assert np.isfinite(out[0][0]).all()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for k in (1, 2):
+        assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1]), k
 
 
 def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle):

@@ -25,9 +25,11 @@ template <class C, class K> static int run(const char* name, K kern, S3Params p,
 #ifndef HNET_PIPE_ABLATE
 #define HNET_PIPE_ABLATE 0
 #endif
-    for (int abl : {HNET_PIPE_ABLATE}) {   // build with -DHNET_PIPE_ABLATE=91 (no DMA in the loop) / 92 (no MFMAs) / 93 (no fragment reads): wrong results, timing only
+    for (int kmul : {1, 2, 4}) {   // build with -DHNET_PIPE_ABLATE=91 (no DMA in the loop) / 92 (no MFMAs) / 93 (no fragment reads): wrong results, timing only
+        const int abl = HNET_PIPE_ABLATE;
         S3Params q = p;
         q.trace = nullptr;
+        q.Kp = p.Kp * kmul;                 // (timing only: the K loop runs kmul times as long over the same taps; slope = time per K-tile)
         hipEvent_t a0, a1;
         hipEventCreate(&a0); hipEventCreate(&a1);
         for (int i = 0; i < 5; i++) hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, 0, q);
@@ -36,7 +38,7 @@ template <class C, class K> static int run(const char* name, K kern, S3Params p,
         hipEventRecord(a1);
         CK(hipDeviceSynchronize());
         float ams; hipEventElapsedTime(&ams, a0, a1);
-        std::printf("   %s, ablation %d: %.4f ms per launch (untraced)\n", name, abl, ams / 20);
+        std::printf("   %s, ablation %d, K x %d (%d K-tiles): %.4f ms per launch (untraced)\n", name, abl, kmul, q.Kp / 64, ams / 20);
     }
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, 0, p);
     CK(hipMemset(tr, 0, n * 8));
