@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16
 PEAK_HBM_GBS = 8000.0
-TOL_PX = 1e-4                     # |HIP - oracle| gate of the self check (tests/conftest.py TOL_PX_VS_ORACLE; north_star's figure)
+TOL_PX = 1e-4                     # |HIP - oracle| gate of the self check in the default arithmetic (tests/conftest.py TOL_PX_VS_ORACLE; north_star's figure)
+TOL_PX_REFERENCE_MODES = 1.5e-4   # exact fp32 MFMA / split-bf16: their own fp32 accumulation noise against the double-accumulating oracle + margin (conftest.tol_px_vs_oracle)
 
 # precision -> (hnet_config.precision, bf16/fp32 MFMAs issued per multiply-accumulate, peak of the instruction issued, label)
 PRECISIONS = {
@@ -597,7 +598,8 @@ def run(args, ctx, primary):
         n_v, err_px, err_cov = verify_last_step(blob, prev_h, curr_h, prior_h, args.variant, n_mc, lambda b: s0 + b,
                                                 mean.cpu().numpy(), cov.cpu().numpy(), slots)
         gated = args.precision != "bf16"        # plain bf16 is a reported mode: its error is printed, not gated
-        ok = (err_px < TOL_PX and err_cov < 1e-4) or not gated
+        gate_px = TOL_PX if args.precision == "f16x2" else TOL_PX_REFERENCE_MODES
+        ok = (err_px < gate_px and err_cov < 1e-4) or not gated
         if collective:
             v = torch.tensor([err_px, err_cov, 0.0 if ok else 1.0], device="cpu" if shared else dev, dtype=torch.float64)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
@@ -606,7 +608,7 @@ def run(args, ctx, primary):
         res["max_px_err"] = float(f"{err_px:.3e}")
         res["max_cov_rel_err"] = float(f"{err_cov:.3e}")
         res["verify"] = {"against": "oracle/ (CPU restatement, double accumulation)", "slots_per_rank": slots, "step": last,
-                         "gate_px": TOL_PX if gated else None, "passed": bool(ok)}
+                         "gate_px": gate_px if gated else None, "passed": bool(ok)}
 
     if rank == 0 and primary and not mc_mode and not stream_mode:
         # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on.

@@ -33,7 +33,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device_id", C.c_int32), ("use_prior", C.c_int32),
                 ("blocks_to_run", C.c_int32), ("mc_samples", C.c_int32), ("dropout_p", C.c_float),
                 ("mc_seed", C.c_uint64), ("emit_error_map", C.c_int32), ("precision", C.c_int32),
-                ("max_batch", C.c_int32), ("mc_sample_begin", C.c_int32), ("mc_sample_end", C.c_int32)]
+                ("max_batch", C.c_int32), ("mc_sample_begin", C.c_int32), ("mc_sample_end", C.c_int32),
+                ("warp_exact", C.c_int32), ("graph", C.c_int32), ("variant", C.c_uint32)]
 
 
 class Camera(C.Structure):

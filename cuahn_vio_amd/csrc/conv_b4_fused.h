@@ -64,236 +64,7 @@ __device__ __forceinline__ f32x4_t b4_mfma(f32x4_t acc, const bf16x8 (&w)[3], co
     return s3_mfma16<NP>(acc, w, a);         // igemm_s3.h: six bf16 / three fp16 / one bf16 product(s)
 }
 
-// four values of one lane (bias, LeakyReLU, optional zeroing) -> NP packed 8-byte pieces
-template <int NP>
-__device__ __forceinline__ void b4_pack4(const f32x4_t& acc, const float (&bv)[4], bool ok, uint2 (&out)[3]) {
-    uint16_t s[3][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float v = acc[r] + bv[r];
-        v = v > 0.f ? v : v * 0.1f;
-        v = ok ? v : 0.f;
-        static_assert(NP != 2, "the v2 kernel is kept for A/B in the bf16 modes only");
-        s3p::split1<NP>(v, s[0][r], s[1][r], s[2][r]);
-    }
-#pragma unroll
-    for (int pl = 0; pl < NP; pl++)
-        out[pl] = make_uint2((uint32_t)s[pl][0] | ((uint32_t)s[pl][1] << 16), (uint32_t)s[pl][2] | ((uint32_t)s[pl][3] << 16));
-}
-
-// w0frag: [4 steps][3 planes][64 lanes] x 16 bytes (B fragments of the pixel-pair GEMM, pack in hnet_capi.hip)
-// w1frag: [7 steps][3 planes][64 lanes] x 16 bytes; odd lane groups hold channels (4..7, 0..3) (see the header comment)
-// flags bit 0: walk the tiles from the end of the batch.  Bits 1-3 exist only in a -DHNET_B4_ABLATE profiling build
-// (2 = drop phase-1 stores, 4 = drop phase-2 MFMAs, 8 = drop phase-1 MFMAs; wrong results).
-template <int TH1, int THREADS, int NP>
-__global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel_v2(const float* __restrict__ x_in, const u32x4* __restrict__ w0frag,
-                                                               const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
-                                                               const float* __restrict__ bias1, uint16_t* __restrict__ out16,
-                                                               size_t o_plane, int n_tiles, int flags) {
-    typedef B4Cfg<TH1, THREADS, NP> C;
-    constexpr int WAVES = C::WAVES, TW1 = C::TW1, RH = C::RH, RW = C::RW, PH0 = C::PH0, PW0 = C::PW0, PROW0 = C::PROW0;
-    constexpr int PPLANE = C::PPLANE, XH = C::XH, PLANE = C::PLANE, N_MT0 = C::N_MT0, N_MT1 = C::N_MT1;
-    constexpr int H0 = 224, W0 = 320, H1 = 112, W1 = 160;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint16_t* patch = reinterpret_cast<uint16_t*>(lds_raw);                    // [NP][PH0][PROW0] bf16
-    uint16_t* img = patch + NP * PPLANE;                                        // S3 image of the block_4_0 region
-#ifdef HNET_B4_ABLATE
-    const int dbg = flags >> 1;
-#else
-    constexpr int dbg = 0;
-#endif
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, g = lane >> 4;
-
-    // ---- weights -> registers, once per (persistent) workgroup
-    bf16x8 w0[4][3], w1[7][3];
-#pragma unroll
-    for (int st = 0; st < 4; st++)
-#pragma unroll
-        for (int pl = 0; pl < NP; pl++) w0[st][pl] = __builtin_bit_cast(bf16x8, w0frag[(st * 3 + pl) * 64 + lane]);
-#pragma unroll
-    for (int st = 0; st < 7; st++)
-#pragma unroll
-        for (int pl = 0; pl < NP; pl++) w1[st][pl] = __builtin_bit_cast(bf16x8, w1frag[(st * 3 + pl) * 64 + lane]);
-    // The MFMAs are issued with the operands swapped (weights as A, pixels as B), i.e. they produce the TRANSPOSED tile:
-    // D row 4g + r = output channel, D column m = pixel.  A lane then holds four consecutive channels of ONE pixel and
-    // stores them with one 8-byte LDS write per plane.
-    const int dx = g >> 1, co0 = 4 * (g & 1);            // phase 1: D row 4g + r = (dx, co0 + r)
-    float bv[4], bv1[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { bv[r] = bias0[co0 + r]; bv1[r] = bias1[4 * g + r]; }
-    // phase-1 A offsets of this lane group: step st covers kernel rows 2st, 2st+1; group g -> row 2st + (g>>1), taps 4(g&1)..
-    int aoff[4];
-#pragma unroll
-    for (int st = 0; st < 4; st++) aoff[st] = min(2 * st + (g >> 1), 6) * PROW0 + 8 * (g & 1);   // row 7 has zero weights
-    // phase-2 tap offsets: tap t = 4*step + g; the first 8-byte read takes the low channel half in even groups, the high in odd
-    int tapoff[7];
-#pragma unroll
-    for (int st = 0; st < 7; st++) {
-        const int t = 4 * st + g;
-        const int kh = t / 5, kw = t - kh * 5;
-        tapoff[st] = (t < 25 ? ((kh * 2 + (kw & 1)) * XH + (kw >> 1)) * 8 : 0) + 4 * (g & 1);
-    }
-    const int second = 4 - 8 * (g & 1);                  // element offset from the first to the second 8-byte read
-    // phase 1 reads its 16 bytes (8-byte aligned only) as two ds_read_b64 as well: fused into one ds_read2_b64 by the
-    // compiler they take 8 LDS cycles instead of 2 + 2 (MI355X_MICROARCH.md, LDS table), so the second offset is opaque
-    int hi4 = 4;
-    asm volatile("" : "+v"(hi4));
-    // phase-1 store position of this lane inside a regular M-tile: pixel column 2m + dx of a 32-column half, channels co0..co0+3
-    const int e_lane = (dx * XH + m) * 8 + co0;
-
-    // patch pixels of the NEXT tile are prefetched into registers while the current tile computes
-    constexpr int PPT = (PH0 * PW0 + THREADS - 1) / THREADS;     // patch pixels per thread
-    float2 pre[PPT];
-    uint32_t pre_ok = 0;            // validity bits; applied when the registers are consumed, so the loads stay in flight
-    const bool reverse = (flags & 1) != 0;
-    auto tile_origin = [&](int t, int& b, int& by, int& bx) {
-        int bid = reverse ? n_tiles - 1 - t : t;
-        bx = bid % (W1 / TW1); bid /= (W1 / TW1);
-        by = bid % (H1 / TH1);
-        b = bid / (H1 / TH1);
-    };
-    auto patch_load = [&](int t) {
-        pre_ok = 0;
-        int b, by, bx;
-        tile_origin(t, b, by, bx);
-        const int Ry0 = 2 * by * TH1 - 2, Rx0 = 2 * bx * TW1 - 2;
-        const float* inb = x_in + (size_t)b * H0 * W0 * 2;
-#pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const int i = min(tid + q * THREADS, PH0 * PW0 - 1);
-            const int pr = i / PW0, pc = i - pr * PW0;
-            const int iy = Ry0 - 3 + pr, ix = Rx0 - 3 + pc;
-            const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
-            pre[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W0 + ix) * 2 : 0));   // unconditional load
-            pre_ok |= ok ? (1u << q) : 0u;
-        }
-    };
-    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int b, by, bx;
-        tile_origin(tile, b, by, bx);
-        const int ty0 = by * TH1, tx0 = bx * TW1;
-        const int Ry0 = 2 * ty0 - 2, Rx0 = 2 * tx0 - 2;      // image coordinates of region pixel (0,0)
-
-        // ---- phase 0: prefetched patch -> bf16 planes in LDS
-        __syncthreads();                                     // previous tile's phase 2 is done with the LDS
-#pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const int i = tid + q * THREADS;
-            if (i < PH0 * PW0) {
-                const int pr = i / PW0, pc = i - pr * PW0;
-                const bool ok = (pre_ok >> q) & 1u;
-                uint16_t a[3], c[3];
-                if constexpr (NP == 3) {
-                    split3(ok ? pre[q].x : 0.f, a[0], a[1], a[2]);
-                    split3(ok ? pre[q].y : 0.f, c[0], c[1], c[2]);
-                } else {
-                    a[0] = f32_to_bf16_rn(ok ? pre[q].x : 0.f);
-                    c[0] = f32_to_bf16_rn(ok ? pre[q].y : 0.f);
-                }
-                const int e = pr * PROW0 + pc * 2;
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + e]) = (uint32_t)a[pl] | ((uint32_t)c[pl] << 16);
-            }
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
-
-        // ---- phase 1: block_4_0 over the region, into the S3 image
-        for (int mt = wave; mt < N_MT0; mt += WAVES) {
-            const bool regular = mt < 2 * RH;                // wave-uniform
-            int row, pair;                                   // this lane's A row (a pixel pair of the region)
-            if (regular) { row = mt >> 1; pair = (mt & 1) * 16 + m; }
-            else { const int idx = (mt - 2 * RH) * 16 + m; row = min(idx >> 1, RH - 1); pair = 32 + (idx & 1); }
-            const int abase = row * PROW0 + pair * 4;
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 4))
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) {            // 8 bf16 = taps 4(g&1)..+3 x 2 ch of one kernel row; 8-byte aligned
-                    const uint16_t* src = &patch[pl * PPLANE + abase + aoff[st]];
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(src + hi4);
-                    a[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                acc = b4_mfma<NP>(acc, w0[st], a);
-            }
-            // D (transposed): row 4g + r = (dx, co0 + r), column m = pixel pair of the M-tile.  Outside the image = block_4_1's zero padding.
-            int e = -1;
-            bool ok = false;
-            if (regular) {
-                const int rrow = mt >> 1, half = mt & 1;
-                const int ix = Rx0 + half * 32 + 2 * m + dx;
-                e = e_lane + (rrow * 2 * XH + half * 16) * 8;
-                ok = (unsigned)(Ry0 + rrow) < (unsigned)H0 && (unsigned)ix < (unsigned)W0;
-            } else {
-                const int idx = (mt - 2 * RH) * 16 + m;
-                const int rrow = idx >> 1, rcol = 2 * (32 + (idx & 1)) + dx;
-                if (rrow < RH && rcol < RW) {
-                    const int iy = Ry0 + rrow, ix = Rx0 + rcol;
-                    e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0;
-                    ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
-                }
-            }
-            if (dbg & 1) { if (acc[0] == 12345.f) img[0] = 1; }
-            else if (e >= 0) {
-                uint2 pk[3];
-                b4_pack4<NP>(acc, bv, ok, pk);
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&img[pl * PLANE + e]) = pk[pl];
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 2: block_4_1 from the S3 image; tap t = 4*step + g, chunk = its 8 channels (two 8-byte reads)
-        uint16_t* st_lds = patch + wave * (NP * 16 * 16);    // overlays the dead input patch
-#pragma unroll 1
-        for (int mt = wave; mt < N_MT1; mt += WAVES) {
-            const int oy = mt >> 1, half = mt & 1;
-            const int ox = half * 16 + m;
-            const int base = ((2 * oy) * 2 * XH + ox) * 8;
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2))
-#pragma unroll
-            for (int st = 0; st < 7; st++) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) {
-                    const uint16_t* src = &img[pl * PLANE + base + tapoff[st]];
-                    const bf16x4 first = *reinterpret_cast<const bf16x4*>(src);
-                    const bf16x4 other = *reinterpret_cast<const bf16x4*>(src + second);
-                    a[pl] = __builtin_shufflevector(first, other, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                acc = b4_mfma<NP>(acc, w1[st], a);
-            }
-            // D (transposed): row 4g + r = cout, column m = output pixel ox' = half*16 + m: 8 bytes (4 channels) per lane and plane
-            {
-                uint2 pk[3];
-                b4_pack4<NP>(acc, bv1, true, pk);
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&st_lds[(pl * 16 + m) * 16 + 4 * g]) = pk[pl];
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            const size_t orow = ((size_t)b * H1 + ty0 + oy) * W1 + tx0 + half * 16;
-#pragma unroll
-            for (int q = 0; q < (NP * 32 + 63) / 64; q++) {
-                const int piece = q * 64 + lane;             // NP x 32 pieces of 16 B: [plane][16 px][2 halves of 8 ch]
-                if (piece < NP * 32) {
-                    const int pl = piece >> 5, rem = piece & 31, px = rem >> 1, hh = rem & 1;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&st_lds[(pl * 16 + px) * 16 + hh * 8]);
-                    *reinterpret_cast<u32x4*>(out16 + pl * o_plane + (orow + px) * 16 + hh * 8) = v;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-        }
-    }   // persistent tile loop
-}
-
+// (the round-1 / round-2 "v2" form of this kernel, kept until round 3 for A/B, was removed in round 4: it lost every measurement since r02_v1)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v3 (round 2): the same algorithm with the VECTOR-ISSUE cost taken out.

@@ -89,8 +89,7 @@ struct hnet_ctx {
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
-    int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (HNET_B4_REV=1, experiments); bit 4: no XCD-aware tile order (HNET_B4_XCD=0)
-    int b4_cfg = 6;                    // fused-kernel variant (s3_dispatch.h launch_block4_fused_np, HNET_B4_CFG): 0 / 1 v3 fp32 input, 2 / 3 v2, 4 / 5 v3 + LDS-DMA staging, 6 = 5 + phase-1 fragment reuse
+    int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (hnet_op_block4_fused `reverse`, tests)
     uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
     size_t x16_plane = 0;              // dwords per plane
     int n_planes = 3;                  // 16-bit planes the matrix-core layers read and write = their arithmetic mode: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16), 2 = fp16 planes (HNET_PREC_F16X2, fp32-grade)
@@ -99,7 +98,6 @@ struct hnet_ctx {
     int patch_rb5 = 5;                 // HNET_PATCH_RB5: region rows per batch of staging loads in the 5x5 patch kernel (1 / 2 / as many as fit: 5 in the fp16 mode, 3 in split-bf16)
     int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
-    bool use_region5 = false;          // HNET_CONV5_REGION=1: block_1_2 / block_2_2 through conv5_region_kernel instead of the implicit GEMM (measured at parity: opt-in); weights in patch_frag[1], [4]
     bool fuse_b3 = false;              // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h): fp16-plane mode, HNET_FUSE_B3=0 switches back
     uint16_t* b3f_w0 = nullptr;        // its weights: block_3_0 as [7][2][64] x 16 B fragments (two planes), block_3_1 as [2][13][2][64] x 16 B
     uint16_t* b3f_w1 = nullptr;
@@ -158,6 +156,8 @@ struct hnet_ctx {
     uint8_t* pinned_img[2] = {nullptr, nullptr};         // host staging of the pushed frame, one per ring slot
     hipEvent_t ev_img[2] = {nullptr, nullptr};           // its upload has completed
     hipGraphExec_t g_infer[2] = {nullptr, nullptr};      // hnet_infer, one per ring orientation
+    const float* g_infer_H[2] = {nullptr, nullptr};      // where that graph's forward leaves H_part1 (H_last is only written while a forward is ENQUEUED, i.e. at capture time)
+    const float* g_batch_H = nullptr;
     struct GraphKey { const void *prev, *curr, *prior, *mean, *cov; int batch, fmt; bool operator==(const GraphKey& o) const {
         return prev == o.prev && curr == o.curr && prior == o.prior && mean == o.mean && cov == o.cov && batch == o.batch && fmt == o.fmt; } };
     GraphKey g_key = {};
@@ -246,7 +246,7 @@ std::vector<float> permute_fc(const float* w, int n_out) {
 
 // the launches of one forward of `batch` pairs, in order (what the STAGE macro of forward_chunk records events for): the latency path
 // (batch <= 8) has fewer of them
-void build_stages(hnet_ctx* c, int batch) {
+void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void* curr = nullptr) {      // (image pointers: forward_chunk fuses the block tail into a prep launch only for 16-byte-aligned images)
     c->stages.clear();
     const hnet_config& g = c->cfg;
     auto conv_flops = [&](int l, int h, int w) {
@@ -262,7 +262,7 @@ void build_stages(hnet_ctx* c, int batch) {
     }
     const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
     for (int blk = fb; blk < 4; blk++) {
-        const bool fused_prep = pend && (blk < 3 || c->x16_b4 != nullptr);
+        const bool fused_prep = pend && (prev ? prep_fc_supported(prev, curr, 8 >> blk, blk == 3 && c->x16_b4 != nullptr) : (blk < 3 || c->x16_b4 != nullptr));
         if (pend && !fused_prep) c->stages.push_back({blk == fb && g.use_prior ? "prior_dlt" : "fc_dlt_b" + std::to_string(blk), blk == fb && g.use_prior ? 0.0 : 2.0 * 8 * 5120});
         c->stages.push_back({std::string(fused_prep ? (blk == fb && g.use_prior ? "prior_dlt+" : "fc_dlt+") : "") + "prep_b" + std::to_string(blk + 1),
                              fused_prep && !(blk == fb && g.use_prior) ? 2.0 * 8 * 5120 : 0.0});
@@ -391,7 +391,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 const size_t cnt1 = c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
                 STAGE(launch_block4_fused(b4_dma ? (const void*)x16 : (const void*)in, c->x16_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16,
-                                          MB * cnt1, B, s, c->b4_flags, c->b4_cfg, c->n_planes));
+                                          MB * cnt1, B, s, c->b4_flags, c->n_planes));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -422,8 +422,6 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_first_s3(in, c->b30_frag, c->conv_b[l], o16, MB * cnt, B, h, w, s, c->n_planes));
             else if (c->s3 && conv_is_first_s2(l) && c->first_s2 && c->s2_frag[l] && o16)
                 STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
-            else if (c->s3 && c->use_region5 && conv_is_region5_layer(l) && h == (l == 1 ? 14 : 28) && w == (l == 1 ? 20 : 40))
-                STAGE(launch_conv5_region(l, in16, in_plane, B, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes));
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128, c->patch_rb5));
             else if (c->s3 && conv_is_s3_layer(l))
@@ -593,8 +591,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                 CK(hipMalloc((void**)&c->b3f_w0, f2.size() * 2));
                 CK(hipMemcpy(c->b3f_w0, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
             }
-            const char* e30 = getenv("HNET_B30_S3");
-            c->b30_s3 = !(e30 && atoi(e30) == 0) || c->n_planes == 2;     // (the fp32-MFMA fallback writes bf16 planes: not in the fp16 mode)
+            c->b30_s3 = true;
         }
         if (c->s3 && l == 8 && c->n_planes == 2) {   // block_3_1 for the fused kernel: lane (i, g) of n-tile nt, step st: channel 16 nt + i, tap 2 st + (g >> 1), ci 8 (g & 1) + j
             std::vector<uint16_t> f2((size_t)2 * 13 * 2 * 64 * 8, 0);
@@ -655,28 +652,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                     }
             CK(hipMalloc((void**)&c->s2_frag[l], fr.size() * 2));
             CK(hipMemcpy(c->s2_frag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
-            const char* e = getenv("HNET_FIRST_S2");
-            c->first_s2 = !(e && atoi(e) == 0) || c->n_planes == 2;
-        }
-        if (c->s3 && c->use_region5 && conv_is_region5_layer(l)) {   // MFMA A-fragments [step = chunk * 13 + s][wave wn][tile j][plane][lane]: lane (n, g) holds row n of
-            const int nch = d.cin / 16;            // output-channel tile 2 wn + j, K = 8 g + e = tap 2 s + (g >> 1), channel 16 chunk + 8 (g & 1) + e
-            std::vector<uint16_t> wp((size_t)nch * 13 * 4 * 2 * 3 * 64 * 8, 0);
-            for (int ch = 0; ch < nch; ch++)
-                for (int st = 0; st < 13; st++)
-                    for (int wn = 0; wn < 4; wn++)
-                        for (int j = 0; j < 2; j++)
-                            for (int ln = 0; ln < 64; ln++) {
-                                const int n = (2 * wn + j) * 16 + (ln & 15), gg = ln >> 4, t = 2 * st + (gg >> 1);
-                                if (t >= 25) continue;
-                                for (int e = 0; e < 8; e++) {
-                                    uint16_t sp[3];
-                                    wsplit_np(w->data[(((size_t)n * d.cin + 16 * ch + 8 * (gg & 1) + e) * 5 + t / 5) * 5 + t % 5], c->n_planes, sp[0], sp[1], sp[2]);
-                                    for (int pl = 0; pl < 3; pl++)
-                                        wp[((((((size_t)(ch * 13 + st) * 4 + wn) * 2 + j) * 3 + pl) * 64) + ln) * 8 + e] = sp[pl];
-                                }
-                            }
-            CK(hipMalloc((void**)&c->patch_frag[l], wp.size() * 2));
-            CK(hipMemcpy(c->patch_frag[l], wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+            c->first_s2 = true;
         }
         if (c->s3 && conv_is_patch32_layer(l)) {   // 32 -> 64, 3x3: step st = tap st; lane group g -> channels 8g .. 8g+7 (odd groups rotated by 4)
             std::vector<uint16_t> fr((size_t)4 * 9 * 3 * 64 * 8, 0);
@@ -826,22 +802,20 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->cfg = g;
     c->s3 = g.precision != HNET_PREC_FP32;   // the 16-bit matrix-core kernels; their arithmetic mode = the number of activation planes (s3_format.h)
     c->n_planes = g.precision == HNET_PREC_BF16 ? 1 : g.precision == HNET_PREC_F16X2 ? 2 : 3;
-    c->fuse_b4 = c->s3 && (!(getenv("HNET_FUSE_B4") && atoi(getenv("HNET_FUSE_B4")) == 0) || c->n_planes == 2);
-    c->use_patch = c->s3 && !(getenv("HNET_PATCH") && atoi(getenv("HNET_PATCH")) == 0);
-    c->use_patch32 = !(getenv("HNET_PATCH32") && atoi(getenv("HNET_PATCH32")) == 0);
-    c->warp_exact = getenv("HNET_WARP_EXACT") && atoi(getenv("HNET_WARP_EXACT")) != 0;
-    c->fuse_small = !(getenv("HNET_FUSE_SMALL") && atoi(getenv("HNET_FUSE_SMALL")) == 0);
-    c->fuse_b3 = c->n_planes == 2 && !(getenv("HNET_FUSE_B3") && atoi(getenv("HNET_FUSE_B3")) == 0);
-    c->fuse_b42 = c->n_planes == 2 && !(getenv("HNET_FUSE_B42") && atoi(getenv("HNET_FUSE_B42")) == 0);
-    c->s3_tile = getenv("HNET_S3_TILE") ? atoi(getenv("HNET_S3_TILE")) : 0;
-    c->patch_rb5 = getenv("HNET_PATCH_RB5") ? atoi(getenv("HNET_PATCH_RB5")) : 5;     // measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
-    c->use_region5 = getenv("HNET_CONV5_REGION") && atoi(getenv("HNET_CONV5_REGION")) != 0;
-    c->patch_b128 = !(getenv("HNET_PATCH_B128") && atoi(getenv("HNET_PATCH_B128")) == 0);
-    c->b4_flags = getenv("HNET_B4_REV") && atoi(getenv("HNET_B4_REV")) ? 1 : 0;
-    if (getenv("HNET_B4_XCD") && atoi(getenv("HNET_B4_XCD")) == 0) c->b4_flags |= 16;      // tile = slot (round-robin over the XCDs) instead of the XCD-aware order
-    // default 5: v3 kernel, 7x32 tiles, two 256-thread workgroups per CU, LDS-DMA staging (in-process A/B, ms at batch 256:
-    // v2 8x512 0.505 / v2 7x256 0.515 / v3 8x512 0.412 / v3 7x256 0.397 / v3 DMA 8x512 0.387 / v3 DMA 7x256 0.365)
-    c->b4_cfg = getenv("HNET_B4_CFG") ? std::max(0, std::min(6, atoi(getenv("HNET_B4_CFG")))) : 6;
+    // Kernel selection.  The library reads NO environment variable: what used to be HNET_* switches read at hnet_create (rounds 1 - 3) is either
+    // gone with the kernels that lost ("Removed in round 4") or a documented field of hnet_config (warp_exact, graph, variant) that
+    // the tests and tools/ab_bench.py set explicitly.
+    c->fuse_b4 = c->s3;
+    c->use_patch = c->s3;
+    c->use_patch32 = true;
+    c->warp_exact = g.warp_exact != 0;
+    c->fuse_small = !(g.variant & HNET_VARIANT_NO_LATENCY_PATH);
+    c->fuse_b3 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B3);
+    c->fuse_b42 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B42);
+    c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
+    c->patch_rb5 = 5;                  // region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
+    c->patch_b128 = true;
+    c->b4_flags = 0;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -881,8 +855,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     // (45 short dependent kernels), not host launch cost, so replay is opt-in (HNET_GRAPH=1)
     // streaming entry point: one graph launch instead of ~43 kernel launches per frame: end-to-end p50 0.380 -> 0.334 ms
     // (device time of the forward 0.289 -> 0.300 ms)
-    c->use_graph = !(getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) == 0);
-    c->graph_timing = getenv("HNET_GRAPH") && atoi(getenv("HNET_GRAPH")) == 1;
+    c->use_graph = g.graph != HNET_GRAPH_OFF;
+    c->graph_timing = g.graph == HNET_GRAPH_TIMING;
     CK(hipMalloc((void**)&c->d_seq, 8));
     CK(hipMemset(c->d_seq, 0, 8));
     CK(hipMalloc((void**)&c->d_flag, 4));
@@ -892,7 +866,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipHostMalloc((void**)&c->pinned_img[i], NPIX, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&c->ev_img[i], hipEventDisableTiming));
     }
-    if (c->fuse_b4 && b4_cfg_is_dma(c->b4_cfg)) {            // zeroed once: the border is block_4_0's zero padding and is never written again
+    if (c->fuse_b4) {                                        // zeroed once: the border is block_4_0's zero padding and is never written again
         c->x16_plane = MB * B4_HP * B4_WP;
         CK(hipMalloc((void**)&c->x16_b4, 3 * c->x16_plane * 4));
         CK(hipMemset(c->x16_b4, 0, 3 * c->x16_plane * 4));
@@ -1201,11 +1175,15 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
                 if (hipMemcpyAsync(pin->mean, c->d_mean, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (hipMemcpyAsync(pin->cov, c->d_cov, 256, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (c->cfg.emit_error_map && hipMemcpyAsync(pin->err, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
+                // the host entry points inspect (and, for an overflow, repair) their own results: the device flag is for the device-resident entry points only
+                if (hipMemsetAsync(c->d_flag, 0, 4, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 return HNET_OK;
             });
             if (!c->g_infer[slot]) c->use_graph = false;      // capture unavailable: eager path below, same kernels
+            c->g_infer_H[slot] = c->H_last;
         }
         if (c->g_infer[slot]) {
+            c->H_last = c->g_infer_H[slot];
             pin->seq = (uint64_t)c->timing.n_inferences;
             if (c->cfg.use_prior) for (int i = 0; i < 8; i++) pin->prior[i] = (float)prior_px[i];    // :160-165 toType(kFloat)
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1241,6 +1219,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     HIPCHK(c, hipMemcpyAsync(mean_out, c->d_mean, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (err_map_out) HIPCHK(c, hipMemcpyAsync(err_map_out, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));      // (see the graph path)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->n_planes == 2 && !(all_finite(mean_out, 8) && all_finite(cov_out, 64)) && prior_finite(c->cfg.use_prior ? prior_px : nullptr, 8)) {
         const int rd = demote_to_bf16x3(c);
@@ -1286,6 +1265,7 @@ int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fm
     HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, (size_t)batch * 8 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(cov, c->d_cov, (size_t)batch * 64 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (err_map) HIPCHK(c, hipMemcpyAsync(err_map, c->d_err, (size_t)batch * NPIX * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, s));              // host results are inspected below: hnet_overflow_flag reports device-resident batches only
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->n_planes == 2 && !(all_finite(mean, (size_t)batch * 8) && all_finite(cov, (size_t)batch * 64)) &&
         (!prior || all_finite(prior, (size_t)batch * 8)) &&
@@ -1350,9 +1330,10 @@ int hnet_time_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, 
                 return forward(c, ga, c->stream);
             });
             c->g_key = key;
+            c->g_batch_H = c->H_last;
         }
         gx = c->g_batch;
-        if (gx) c->pinned->seq = pair_seq0;
+        if (gx) { c->pinned->seq = pair_seq0; c->H_last = c->g_batch_H; }
     }
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
     for (int i = 0; i < iters && rc == HNET_OK; i++) {
@@ -1385,7 +1366,7 @@ int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_cur
                               uint64_t pair_seq0, float* d_mean, float* d_cov, int iters, float* stage_ms_avg) {
     if (!c || iters < 1 || !stage_ms_avg) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    build_stages(c, batch);               // the launches of a forward of THIS batch (the latency path has fewer): hnet_stage_name follows
+    build_stages(c, batch, d_prev, d_curr);   // the launches of a forward of THIS batch and THESE images (the latency path has fewer): hnet_stage_name follows
     const size_t ns = c->stages.size();
     std::vector<double> acc(ns, 0.0);
     // the per-stage events live in the context only for the duration of this call: whatever happens, they are destroyed
@@ -1462,10 +1443,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         int out_np = c->n_planes;            // plane format p_out is written in
         HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32));
         HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
-        if (c->use_region5 && conv_is_region5_layer(layer) && h == (layer == 1 ? 14 : 28) && w == (layer == 1 ? 20 : 40)) {
-            HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
-            HIPCHK(c, launch_conv5_region(layer, p_in, n_in, batch, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes));
-        } else if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
+        if (c->use_patch && (conv_is_patch_layer(layer) || (c->use_patch32 && conv_is_patch32_layer(layer) && h == 56 && w == 80))) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_patch(layer, p_in, n_in, batch, h, w, c->patch_frag[layer], c->conv_b[layer], p_out, n_out, c->stream, c->n_planes, c->patch_b128, c->patch_rb5));
         } else if (conv_is_s3_layer(layer)) {
@@ -1503,7 +1481,7 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
     HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, IMG_H, IMG_W, c->stream));
     const void* x_in = d_b;
     size_t x_plane = 0;
-    if (b4_cfg_is_dma(c->b4_cfg)) {      // the DMA-staged kernel reads padded bf16 planes with a zero border
+    {                                    // the kernel reads padded 16-bit planes with a zero border
         uint32_t* d_p = nullptr;
         x_plane = (size_t)batch * B4_HP * B4_WP;
         HIPCHK(c, t.alloc(&d_p, 3 * x_plane));
@@ -1512,7 +1490,7 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
         x_in = d_p;
     }
     HIPCHK(c, launch_block4_fused(x_in, x_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0,
-                                  c->b4_cfg, c->n_planes));
+                                  c->n_planes));
     HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));

@@ -1032,207 +1032,9 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_lean8_kernel(S3Params p) {
     s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem8 + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
 }
 
-// ---------------------------------------------------------------------------------------------
-// LDS-DMA variant: the operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
-// no VGPR staging, no ds_write) into an NSTAGE-deep ring, two K-tiles in flight; one raw s_barrier per K-tile and
-// counted vmcnt waits (never __syncthreads(), which would drain the DMAs).  The DMA writes LDS linearly
-// (wave base + lane*16 B), which is exactly the [row][4 chunks] tile: lane l -> row l/4, physical chunk l%4; the XOR
-// swizzle is applied on the SOURCE side (the lane fetches logical chunk phys ^ ((row>>2)&3)).  Padding taps and rows
-// beyond M/N read a zero page instead.  Conv loaders only (the heads apply a per-element mask while staging).
-// ---------------------------------------------------------------------------------------------
-template <class L, int BM, int BN, int WGM, bool OUT32, int NSTAGE, int MF = 32, int NP = 3>
-static __global__ __launch_bounds__(256) void igemm_s3_dma_kernel(S3Params p) {
-    constexpr int BK = IG_BK;
-    constexpr int WGN = 4 / WGM;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && !L::HAS_MASK, "DMA variant: 64-row multiples, no mask");
-    constexpr int A_INST = BM / 64, B_INST = BN / 64;        // wave-instructions per wave, plane and stage (16 rows each)
-    static_assert(NP == 3 || MF == 16, "plain bf16 and the fp16 planes exist in the transposed 16x16x32 form");
-    constexpr int NW = s3_wplanes_gemm<NP>;                  // weight planes
-    constexpr int PER_STAGE = NP * A_INST + NW * B_INST;     // DMA instructions a wave issues per K-tile
-    constexpr int TILE_A = BM * BK, TILE_B = BN * BK;
-    constexpr int STAGE = NP * TILE_A + NW * TILE_B;         // 16-bit elements per ring stage
-    constexpr int SMEM_ELEMS = NSTAGE * STAGE > 4 * 3 * 32 * 32 ? NSTAGE * STAGE : 4 * 3 * 32 * 32;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM_ELEMS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    int m0, n0;
-    s3_tile_origin(p, BM, BN, m0, n0);
-    const int lrow = lane >> 2, lphys = lane & 3;
-
-    typename L::Row rows[A_INST];
-    int akp[A_INST];                                         // K offset of the logical chunk this lane fetches
-#pragma unroll
-    for (int i = 0; i < A_INST; i++) {
-        const int r = (wave + 4 * i) * 16 + lrow;
-        rows[i] = L::make_row(p, m0 + r, n0);
-        akp[i] = (MF == 16 ? (lphys ^ (((r >> 3) & 1) * 3)) : (lphys ^ ((r >> 2) & 3))) * 8;   // 16x16x32 reads: the conflict-free 64-byte-row swizzle of s3_swz_m16
-    }
-    const uint16_t* wsrc[B_INST];
-    bool wvalid[B_INST];
-#pragma unroll
-    for (int i = 0; i < B_INST; i++) {
-        const int r = (wave + 4 * i) * 16 + lrow;
-        wvalid[i] = n0 + r < p.N;
-        wsrc[i] = p.Wp + (size_t)(wvalid[i] ? n0 + r : 0) * p.Kp + (MF == 16 ? (lphys ^ (((r >> 3) & 1) * 3)) : (lphys ^ ((r >> 2) & 3))) * 8;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-
-    constexpr int TM16 = WM / 16, TN16 = WN / 16;
-    f32x4_m16 acc16[TM16][TN16];
-#pragma unroll
-    for (int i = 0; i < TM16; i++)
-#pragma unroll
-        for (int j = 0; j < TN16; j++) acc16[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
-    f32x4_m16 acc16l[NP == 2 ? TM16 : 1][NP == 2 ? TN16 : 1];     // fp16 mode: the cross terms, scaled by 4096
-#pragma unroll
-    for (int i = 0; i < (NP == 2 ? TM16 : 1); i++)
-#pragma unroll
-        for (int j = 0; j < (NP == 2 ? TN16 : 1); j++) acc16l[i][j] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
-
-    const int n_iter = (p.Kp + BK - 1) / BK;                 // no split-K in this variant
-
-    auto issue = [&](int it, int stage) {
-        uint16_t* sbase = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < A_INST; i++) {
-            bool ok;
-            const size_t off = L::offset(p, rows[i], it * BK + akp[i], ok);
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                const uint16_t* src = ok ? p.A + pl * p.a_plane + off : p.zeros;
-                uint16_t* dst = sbase + pl * TILE_A + (wave + 4 * i) * 16 * BK;      // wave-uniform; the DMA adds lane*16 B
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                 (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_INST; i++) {
-            const bool ok = wvalid[i] && (it * BK < p.Kp);   // Kp is a multiple of 8 and chunks never straddle it
-#pragma unroll
-            for (int pl = 0; pl < NW; pl++) {
-                const uint16_t* src = ok ? wsrc[i] + it * BK + pl * p.w_plane : p.zeros;
-                uint16_t* dst = sbase + NP * TILE_A + pl * TILE_B + (wave + 4 * i) * 16 * BK;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                 (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-            }
-        }
-    };
-
-    const int frow = lane & 31, fh = lane >> 5;
-    auto compute = [&](int stage) {
-        const uint16_t* As = smem + stage * STAGE;
-        const uint16_t* Bs = As + NP * TILE_A;
-        if constexpr (MF == 16) {                              // one k32 step of 16x16x32 MFMAs, weights as A operand (igemm_s3_kernel)
-            const int r16 = lane & 15, g16 = lane >> 4;
-            bf16x8 af[TM16][3], bf[TN16][3];
-#pragma unroll
-            for (int i = 0; i < TM16; i++) {
-                const int r = wm * WM + i * 16 + r16;
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz_m16<4>(r, g16)]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN16; j++) {
-                const int r = wn * WN + j * 16 + r16;
-#pragma unroll
-                for (int pl = 0; pl < NW; pl++) bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz_m16<4>(r, g16)]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM16; i++)
-#pragma unroll
-                for (int j = 0; j < TN16; j++) {
-                    if constexpr (NP == 2) s3_mfma16_2acc(acc16[i][j], acc16l[i][j], bf[j], af[i]);
-                    else acc16[i][j] = s3_mfma16<NP>(acc16[i][j], bf[j], af[i]);
-                }
-            return;
-        }
-#pragma unroll
-        for (int step = 0; step < 2; step++) {
-            bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const int r = wm * WM + i * 32 + frow;
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(&As[pl * TILE_A + r * BK + s3_swz<4>(r, 2 * step + fh)]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int r = wn * WN + j * 32 + frow;
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[pl * TILE_B + r * BK + s3_swz<4>(r, 2 * step + fh)]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    issue(0, 0);
-    if (n_iter > 1) issue(1, 1);
-    for (int it = 0; it < n_iter; it++) {
-        // this wave's DMAs of K-tile `it` have landed (the next tile's may still be in flight) ...
-        if (it + 1 < n_iter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                        // ... and so have every other wave's; tile it-1 is no longer read
-        asm volatile("" ::: "memory");
-        if (it + 2 < n_iter) issue(it + 2, (it + 2) % NSTAGE);
-        compute(it % NSTAGE);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                            // all fragment reads done before the epilogue reuses the LDS
-
-    if constexpr (MF == 16) {
-        if constexpr (NP == 2) {
-#pragma unroll
-            for (int i = 0; i < TM16; i++)
-#pragma unroll
-                for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
-        }
-        s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
-        return;
-    }
-    const int col = lane & 31, rbase = 4 * fh;
-    if constexpr (OUT32) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + wn * WN + j * 32 + col;
-            const float bv = n < p.N ? p.bias[n] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (m < p.M && n < p.N) {
-                        const float v = acc[i][j][r] + bv;
-                        p.out32[(size_t)m * p.N + n] = v > 0.0f ? v : v * 0.1f;
-                    }
-                }
-        }
-    } else {
-        igemm_store_s3<TM, TN>(acc, smem + wave * (3 * 32 * 32), p.bias, p.out16, p.o_plane, p.M, p.N, m0 + wm * WM,
-                               n0 + wn * WN, lane);
-    }
-}
+// (The LDS-DMA ring variant of rounds 1 - 3, igemm_s3_dma_kernel - global_load_lds_dwordx4 into a 3 / 4 stage ring of 32-deep K tiles on 64 x 64 tiles - lost
+// every in-process measurement (profiles/r02_ab_s3_dma.log, r03_experiments_not_shipped.log item 10) and was removed in round 4; igemm_pipe.h is the
+// LDS-DMA design that won: 64-deep tiles = full 128-byte rows, 144 x 128 tiles, fragments double-buffered in registers, staggered issue.)
 
 // heads preparation: (a) featS3 = split3(feat * scale) as three planes [3][B][5120]; (b) the keep bits of both heads'
 // first dropout for every local sample, one byte per 8 consecutive NHWC elements.  The hash is evaluated on the

@@ -31,9 +31,6 @@ bool conv_is_s3_layer(int layer);
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
                           float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3, int tile = 0);
-bool conv_is_region5_layer(int layer);    // block_1_2 / block_2_2 at their network size (conv5_region.h); wpack = [CIN/16][13 steps][3][128][32] bf16
-hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
-                               size_t o_plane, hipStream_t s, int n_planes = 3);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 bool conv_is_patch32_layer(int layer);    // block_3_2 / block_4_3 at their network size 56x80 (conv_patch32_s2_kernel); same launcher, wfrag [4][9][3][64] x 16 B
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
@@ -46,12 +43,9 @@ hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const floa
 inline bool conv_is_first_s2(int layer) { return layer == 0 || layer == 3; }
 hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 hipStream_t s, int n_planes = 3);
-// cfg (s3_dispatch.h): 0 / 1 fp32 NHWC input (8x32 tiles x 512 threads / 7x32 x 256, two workgroups per CU), 2 / 3 the older v2 kernel,
-// 4 / 5 the same geometries fed from the padded bf16 planes (B4_* above, x_plane dwords per plane) by LDS-DMA
-inline bool b4_cfg_is_dma(int cfg) { return cfg >= 4 && cfg <= 6; }
+// block_4_0 + block_4_1 in one launch (conv_b4_fused.h): x_in = the padded 16-bit planes B4_* below (x_plane dwords per plane)
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */,
-                               int cfg = 1, int n_planes = 3);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */, int n_planes = 3);
 // block_3_0 + block_3_1 in one launch (conv_b3_fused.h), fp16-plane mode (n_planes == 2) only: x_in fp32 NHWC [B][112][160][2] (the block's prep output),
 // w0frag [7][2][64] x 16 B, w1frag [2][13][2][64] x 16 B (packed by hnet_create), out16 [2][B][56][80][32]
 hipError_t launch_block3_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,

@@ -605,13 +605,9 @@ static hipError_t prep_dispatch(const PIX* i1, const PIX* i2, const float* H, in
         hipLaunchKernelGGL(prep_k1_kernel<PIX>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, i1, i2, H, out, batch);
         return launch_f32_nhwc_to_s3pad(out, out_s3, s3_plane, batch, n_planes, s);
     }
-    const bool tiled = !(std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 0);   // 0: direct-gather kernels
-    // measured at batch 256 (ms, tiled vs direct): K=1 0.085 / 0.094, K=2 0.076 / 0.080, K=4 0.068 / 0.062 -> tiled for K <= 2
-    // (HNET_PREP_TILED=2 forces it for every K: the parity tests run both)
-    const bool tiled_all = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 2;
-    // the fast sampler exists in the tiled kernel only: with it the tiled kernel serves every K (HNET_PREP_TILED=1 keeps K >= 4 on the direct kernel)
-    const bool tiled_k2 = std::getenv("HNET_PREP_TILED") && std::atoi(std::getenv("HNET_PREP_TILED")) == 1;
-    if (H && tiled && (k <= 2 || tiled_all || (!exact && !tiled_k2)) && (((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {   // 4-pixel groups: u8 4 B, f32 16 B loads
+    // measured at batch 256 (ms, tiled vs direct, exact sampler): K=1 0.085 / 0.094, K=2 0.076 / 0.080, K=4 0.068 / 0.062 -> the bit-faithful sampler runs
+    // tiled for K <= 2 only; the fast sampler exists in the tiled kernel only and serves every K
+    if (H && (k <= 2 || !exact) && (((uintptr_t)i1 | (uintptr_t)i2) & 15) == 0) {   // 4-pixel groups: u8 4 B, f32 16 B loads
         const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
 #define HNET_TILED(KK)                                                                                                                 \
     if (exact) hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, false, true>), dim3(blocks), dim3(256), 0, s, i1, i2, H, out);       \

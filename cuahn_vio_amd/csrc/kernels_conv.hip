@@ -33,14 +33,8 @@ int conv_padded_k(int layer) {
 // Measured (HNET_SPLITK_MIN_ITERS / HNET_SPLITK_BLOCKS sweeps): with a handful of tiles (batch 1-4) fewer, longer slices win
 // (4 K-tiles, 192 workgroups: batch-1 p50 0.289 -> 0.278 ms: less partial-sum traffic for the reduce kernel), with 16+ tiles
 // 3 K-tiles and 384 workgroups do (block_1_2 at batch 256: 0.109 vs 0.142 ms).
-int splitk_min_iters(long tiles) {
-    static const int v = std::getenv("HNET_SPLITK_MIN_ITERS") ? std::max(1, std::atoi(std::getenv("HNET_SPLITK_MIN_ITERS"))) : 0;
-    return v ? v : (tiles < 16 ? 4 : 3);
-}
-int splitk_target_blocks(long tiles) {
-    static const int v = std::getenv("HNET_SPLITK_BLOCKS") ? std::max(64, std::atoi(std::getenv("HNET_SPLITK_BLOCKS"))) : 0;
-    return v ? v : (tiles < 16 ? 192 : 384);
-}
+int splitk_min_iters(long tiles) { return tiles < 16 ? 4 : 3; }
+int splitk_target_blocks(long tiles) { return tiles < 16 ? 192 : 384; }
 
 template <class L, int BM, int BN, int WGM, int MF>
 static hipError_t run(IgemmParams p, hipStream_t s, float* ws, size_t ws_floats) {
@@ -76,12 +70,6 @@ static hipError_t run_conv(const IgemmParams& p, hipStream_t s, float* ws, size_
     } else if constexpr (COUT == 32) {
         return run<L, 128, 32, 4, 32>(p, s, ws, wsn);
     } else {
-        static const int force = std::getenv("HNET_TILE") ? std::atoi(std::getenv("HNET_TILE")) : -1;   // experiments
-        const long tiles128 = (long)((p.M + 127) / 128) * (COUT / 64);
-        if (force == 0) return run<L, 64, 64, 2, 32>(p, s, ws, wsn);
-        if (force == 1) return run<L, 128, 64, 2, 32>(p, s, ws, wsn);
-        if constexpr (COUT >= 128) { if (force == 2) return run<L, 128, 128, 2, 32>(p, s, ws, wsn); }
-        (void)tiles128;
         return run<L, 64, 64, 2, 32>(p, s, ws, wsn);   // 64x64: 4 workgroups/CU; measured faster than 128x64 / 128x128 on every layer
     }
 }
@@ -148,8 +136,8 @@ hipError_t conv_kernels_init_device() {
 #define HNET_NP(fn, ...) (n_planes == 1 ? fn<1>(__VA_ARGS__) : n_planes == 2 ? fn<2>(__VA_ARGS__) : fn<3>(__VA_ARGS__))
 
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg, int n_planes) {
-    return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, cfg);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int n_planes) {
+    return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
 hipError_t launch_block42_fused(const uint16_t* in16, size_t i_plane, const void* w2frag, const float* bias2, const void* w3frag, const float* bias3,
@@ -170,12 +158,6 @@ hipError_t launch_conv_first_s3(const float* x_in, const void* wfrag, const floa
 hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 hipStream_t s, int n_planes) {
     return HNET_NP(launch_conv_first_s2_np, layer, x_in, wfrag, bias, out16, o_plane, batch, s);
-}
-
-bool conv_is_region5_layer(int layer) { return layer == 1 || layer == 4; }   // block_1_2, block_2_2
-hipError_t launch_conv5_region(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
-                               size_t o_plane, hipStream_t s, int n_planes) {
-    return HNET_NP(launch_conv5_region_np, layer, in, i_plane, batch, wpack, bias, out16, o_plane, s);
 }
 
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
@@ -222,8 +204,6 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
     p.mc_seed = mc_seed;
     p.pair_seq0 = pair_seq0;
     p.seq_dev = seq_dev;
-    static const int force = std::getenv("HNET_TILE") ? std::atoi(std::getenv("HNET_TILE")) : -1;   // experiments
-    if (force == 1) return run<HeadLoader, 128, 64, 2, 32>(p, s, ws, wsn);
     return run<HeadLoader, 64, 64, 2, 32>(p, s, ws, wsn);
 }
 

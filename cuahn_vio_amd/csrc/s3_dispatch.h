@@ -10,7 +10,6 @@
 #include "conv_b3_fused.h"
 #include "conv_b42_fused.h"
 #include "conv_patch_s2.h"
-#include "conv5_region.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -53,112 +52,30 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     p.k_split = split;
     p.partial = ws;
     grid.z = split;
-    // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel LDS-DMA layers -> wide taps only
-    static const int xcd = std::getenv("HNET_XCD_REMAP") ? std::atoi(std::getenv("HNET_XCD_REMAP")) : -1;
-    p.xcd_remap = xcd >= 0 ? xcd : (L::WIDE_TAPS ? 1 : 0);
-    // LDS-DMA ring (HNET_S3_DMA=3 stages) for the Cin-32 layers: 2-8 % faster than the round-1 register staging, but 1-3 % slower than
-    // the lean staging of round 2 (0.1116 vs 0.1086 ms on block_3_2, profiles/r02_ab_s3_dma.log) -> off in split-bf16 mode, on in plain bf16
-    static const int dma = std::getenv("HNET_S3_DMA") ? std::atoi(std::getenv("HNET_S3_DMA")) : (NP == 3 ? 0 : 3);
+    // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel ones -> wide taps only
+    p.xcd_remap = L::WIDE_TAPS ? 1 : 0;
 
-    if constexpr (NP == 2 && BM == 128 && BN == 128 && L::WIDE_TAPS) {
+    if constexpr (NP == 2 && BM == 128 && BN == 128 && L::WIDE_TAPS && LEAN8) {      // the eight-wave double-buffered kernel of round 3 (heads; since round 4 only as the A/B reference of igemm_heads_pipe_kernel)
+        hipLaunchKernelGGL((igemm_s3_lean8_kernel<L, OUT32, NP>), grid, dim3(512), LEAN8_LDS_BYTES, s, p);
+        return finish_split(p, split, ws, s);
+    }
+    // The lean kernel (buffer loads with scalar tap offsets, igemm_s3.h) on every layer it covers, with 64-wide K tiles where a tap holds >= 64
+    // channels; the register-staged kernel in its 16x16x32 form for the rest (ragged operator-level shapes).  Round-2 / round-3 measurements that
+    // chose this (all removed from the tree in round 4, profiles/r0*_experiments_not_shipped.log): 32x32x16 MFMA shape, double-buffered register
+    // staging, the LDS-DMA ring (igemm_s3_dma_kernel), 96 / 64x128 / 128x64 tiles for the 128-channel layers, the eight-wave kernel on the conv layers.
+    if constexpr (NP != 1 && BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {      // (plain bf16, reported only: the register-staged kernel throughout)
         if constexpr (L::template lean_ok<64>()) {
-            if (LEAN8 || p.tile == 12) {                             // (tile 12: the experiment switch that puts every >= 128-channel layer on it)
-                hipLaunchKernelGGL((igemm_s3_lean8_kernel<L, OUT32, NP>), grid, dim3(512), LEAN8_LDS_BYTES, s, p);
-                return finish_split(p, split, ws, s);
-            }
+            hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
+            return finish_split(p, split, ws, s);
         }
     }
-    if constexpr (NP == 2) {
-        // fp16 planes: the lean kernel (the measured winner of the split-bf16 dispatch below) on every layer it covers, its 64-wide K tiles
-        // where a tap holds >= 64 channels; the register-staged kernel in its 16x16x32 form for the rest (ragged operator-level shapes)
-        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
-            if (p.tile == 7 && split == 1 && p.zeros) {      // experiment: LDS-DMA ring for the 32-channel layers (HNET_PATCH32=0 routes them here)
-                hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, NP>), grid, dim3(256), 0, s, p);
-                return hipGetLastError();
-            }
-        }
-        if constexpr (!L::HAS_MASK && BM == 64 && BN == 64) {        // experiments: the LDS-DMA ring (no register staging, no ds_write, two K-tiles in flight) on every conv layer
-            if ((p.tile == 10 || p.tile == 11) && split == 1 && p.zeros) {
-                if (p.tile == 10) hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, NP>), grid, dim3(256), 0, s, p);
-                else hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4, 16, NP>), grid, dim3(256), 0, s, p);
-                return hipGetLastError();
-            }
-        }
-        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
-            if constexpr (L::template lean_ok<64>()) {
-                hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
-                return finish_split(p, split, ws, s);
-            }
-        }
-        if constexpr (L::template lean_ok<32>() && BM != 96)
-            hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, NP>), grid, dim3(256), 0, s, p);
-        return finish_split(p, split, ws, s);
-    } else if constexpr (NP == 1) {
-        // plain bf16 operands: the measured winners of the split-bf16 dispatch below, in their 16x16x32 form (the only form
-        // the NP = 1 kernels exist in), no experiment switches
-        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
-            if (dma && split == 1 && p.zeros) {
-                hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16, 1>), grid, dim3(256), 0, s, p);
-                return hipGetLastError();
-            }
-        }
-        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96)
-            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16, 1>), grid, dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, 1>), grid, dim3(256), 0, s, p);
-        return finish_split(p, split, ws, s);
-    } else {
-        static const int nbuf = std::getenv("HNET_S3_NBUF") ? std::atoi(std::getenv("HNET_S3_NBUF")) : 1;   // experiments
-        if constexpr (!L::HAS_MASK && BM % 64 == 0 && BN % 64 == 0 && BM * BN <= 128 * 64 && !L::WIDE_TAPS) {
-            if (dma && split == 1 && p.zeros) {
-                if constexpr (BM * BN <= 128 * 64) {
-                    if (dma == 4) { hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 4>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
-                }
-                // the 16x16x32 shape gains nothing on these short-K (288) 32-channel layers (0.110 vs 0.109 ms): 32x32x16 unless HNET_S3_MF16=2
-                static const int mf16d = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 0;
-                if (mf16d == 2) hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3, 16>), grid, dim3(256), 0, s, p);
-                else hipLaunchKernelGGL((igemm_s3_dma_kernel<L, BM, BN, WGM, OUT32, 3>), grid, dim3(256), 0, s, p);
-                return hipGetLastError();
-            }
-        }
-        // MFMA shape 16x16x32 (transposed tiles) by default: -4..-9 % per layer against 32x32x16 at the same LDS traffic (HNET_S3_MF16=0: 32x32x16)
-        static const int mf16 = std::getenv("HNET_S3_MF16") ? std::atoi(std::getenv("HNET_S3_MF16")) : 1;
-        // 64-wide K tiles (full 128-byte lines per staged row) for layers whose taps hold >= 64 channels: ~10 % faster than the
-        // 32-wide tiles there (the texture addresser is the busy unit); HNET_S3_BK64=0 disables
-        static const int bk64 = std::getenv("HNET_S3_BK64") ? std::atoi(std::getenv("HNET_S3_BK64")) : 1;
-        const int t96 = p.tile;
-        const bool bk64_ok = BM != 96 || t96 == 6;               // 96-row tiles: 32-wide K tiles keep three workgroups per CU (61 KB of LDS at BK 64)
-        // lean operand staging (igemm_s3.h: buffer loads with scalar tap offsets, no selects): same tiles, bit-identical results,
-        // a fraction of the VALU instructions per MFMA (HNET_S3_LEAN=0: the round-1 staging)
-        static const int lean = std::getenv("HNET_S3_LEAN") ? std::atoi(std::getenv("HNET_S3_LEAN")) : 1;
-        if (lean && mf16) {
-            if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS && BM != 96) {
-                if constexpr (L::template lean_ok<64>()) {
-                    if (bk64) { hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
-                }
-            }
-            if constexpr (L::template lean_ok<32>() && BM != 96) {
-                hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
-                return finish_split(p, split, ws, s);
-            }
-        }
-        if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {
-            if (bk64 && mf16 && bk64_ok) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
-            if constexpr (BM != 96) {
-                if (bk64) { hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64>), grid, dim3(256), 0, s, p); return finish_split(p, split, ws, s); }
-            }
-        }
-        if constexpr (BM == 96) {     // 96-row tiles exist only in the 16x16x32 form (wave tile 48 x 32)
-            hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
-        } else {
-            if (nbuf == 2) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 2>), grid, dim3(256), 0, s, p);
-            else if (mf16) hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1>), grid, dim3(256), 0, s, p);
-        }
-        return finish_split(p, split, ws, s);
-    }
+    if constexpr (NP != 1 && L::template lean_ok<32>())
+        hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
+    else if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS)
+        hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16, NP>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, NP>), grid, dim3(256), 0, s, p);
+    return finish_split(p, split, ws, s);
 }
 
 // igemm_pipe.h: the software-pipelined LDS-DMA kernel on whole-pair tiles (fp16-plane mode).  Per layer shape the tile that makes the grid
@@ -189,71 +106,40 @@ static bool pipe_ok(const S3Params& p) {
 template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
 static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
-    const int tile = p.tile;                                 // experiments (HNET_S3_TILE, read by hnet_create)
     if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
         if (pipe_ok<CIN, KS, COUT>(p)) return p.tile == 23 ? run_pipe<L, PipeCfg140, OUT32>(p, s) : run_pipe<L, PipeCfg144, OUT32>(p, s);
     }
     if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
     else {
-        // long-K layers amortise a bigger tile (measured at batch 256): 256->256 3x3 (K 2304) 128x64, 128->128 5x5 (K 3200) 128x128
+        // long-K layers amortise a bigger tile (measured at batch 256): 256 -> 256 3x3 (K 2304) 128 x 64; 128 -> 128 5x5 (K 3200, N = 128: the im2col tile
+        // staged once for all of N) 128 x 128 - in the fp16 mode from M = 8192 (64 x 64 / 128 x 128 at batch 64: 0.0291 / 0.0344, 128: 0.0537 / 0.0448,
+        // 256: 0.0734 / 0.0676 ms); every other layer 64 x 64 = four workgroups per CU (profiles/r03_experiments_not_shipped.log, items 7, 9, 17)
         const bool big_m = p.M >= 4096;
-        if constexpr (NP != 1) {
-            if (tile == 1) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn);
-            if constexpr (COUT >= 128) { if (tile == 2 || (tile == 12 && big_m)) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
-            if constexpr (COUT >= 128 && NP == 2) { if (tile == 8 && big_m) return run_s3<L, 64, 128, 2, OUT32, NP>(p, s, ws, wsn); }   // experiment: all (or half) of N per workgroup: the im2col tile is staged once
-            if constexpr (CIN == 128 && KS == 3 && NP == 3) { if (big_m && (tile == 5 || tile == 6)) return run_s3<L, 96, 64, 2, OUT32, NP>(p, s, ws, wsn); }
-        }
-        if constexpr (CIN == 256) { if (big_m && tile != 9) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }   // (tile 9: experiment, 64 x 64 + split-K policy of run_s3)
-        // (fp16 mode: two accumulators per tile = 128 accumulator registers.  At 264 registers, one wave per SIMD, the 128x128 tile lost - 0.091 ms
-        // against 0.080 ms with 64x64; with the kernel's launch bounds asking for two waves per SIMD it fits 226 without scratch and wins on
-        // this one layer, 0.0694 against 0.0769 ms at batch 256 (K = 3200, N = 128: the im2col tile is staged once for all of N); on every
-        // other layer and on the heads it still loses by 7 - 30 %: experiment 17)
-        // (measured per batch in the fp16 mode, 64x64 / 128x128: batch 64 0.0291 / 0.0344, 128 0.0537 / 0.0448, 256 0.0734 / 0.0676 ms -> from M = 8192)
-        if constexpr (CIN == 128 && KS == 5) { if ((NP == 2 ? p.M >= 8192 : big_m) && tile != 4) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
+        if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
+        if constexpr (CIN == 128 && KS == 5) { if (NP == 2 ? p.M >= 8192 : big_m) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
         return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
     }
 }
 
-// block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in fp32 [B][224][320][2] -> out16 S3 planes [3][B][112][160][16]
-// cfg 0: 8 x 32 tiles, one 512-thread workgroup per CU;  cfg 1: 7 x 32 tiles, two 256-thread workgroups per CU
-template <int TH1, int THREADS, int NP, bool V2 = false, bool DMA = false, bool REUSE = false>
-static hipError_t run_b4(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                         uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
-    typedef B4Cfg<TH1, THREADS, NP, DMA> C;
-    const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
-    const int per_cu = std::max(1, std::min(2, std::min(2048 / THREADS, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
-    const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
-    if constexpr (V2)
-        hipLaunchKernelGGL((block4_fused_kernel_v2<TH1, THREADS, NP>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, (const float*)x_in,
-                           (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
-    else
-        hipLaunchKernelGGL((block4_fused_kernel<TH1, THREADS, NP, DMA, REUSE>), dim3(blocks), dim3(THREADS), C::LDS_BYTES, s, x_in, x_plane,
-                           (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
-    return hipGetLastError();
-}
-
-// x_in: fp32 NHWC [B][224][320][2] for cfg 0-3; the padded bf16 planes of kernels.h B4_* (x_plane dwords per plane) for cfg 4, 5
+// block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in = the padded 16-bit planes of kernels.h B4_* (x_plane dwords per plane) -> out16 planes [NP][B][112][160][16].
+// 7 x 32 tiles, two 256-thread workgroups per CU, LDS-DMA staging, phase-1 fragment reuse: the winner of the round-2 / round-3 measurements
+// (8 x 32 / 512 threads, fp32 input without DMA, no fragment reuse and the v2 kernel were removed in round 4; DESIGN.md section 3.4 keeps the table)
 template <int NP>
 hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                                  uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int cfg) {
-#ifdef HNET_B4_ABLATE   // profiling build only (make FLAGS+=-DHNET_B4_ABLATE): HNET_B4_DBG drops phases of the kernel, results are wrong
+                                  uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
+#ifdef HNET_B4_ABLATE   // profiling build only (make ablate): HNET_B4_DBG drops phases of the kernel, results are wrong
     static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
-    flags = (flags & 1) | ((dbg_env & 7) << 1);
+    flags = (flags & 17) | ((dbg_env & 7) << 1);
 #else
-    flags &= 1;
+    flags &= 17;
 #endif
-    // cfg 0 / 1: the v3 kernel (immediate addressing, hand-counted waits) in the two geometries; 2 / 3: the round-2 v2 kernel kept
-    // for in-process A/B (tools/ab_bench.py) and as the reference implementation of the same arithmetic
-    // 4 / 5: v3 with LDS-DMA staging from the padded bf16-plane input
-    if (cfg == 0) return run_b4<8, 512, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if constexpr (NP != 2) {      // the v2 kernel exists in the bf16 modes only
-        if (cfg == 2) return run_b4<8, 512, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-        if (cfg == 3) return run_b4<7, 256, NP, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    }
-    if (cfg == 4) return run_b4<8, 512, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 5) return run_b4<7, 256, NP, false, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    if (cfg == 6) return run_b4<7, 256, NP, false, true, true>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);   // 5 + phase-1 fragment reuse
-    return run_b4<7, 256, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    typedef B4Cfg<7, 256, NP, true> C;
+    const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
+    const int per_cu = std::max(1, std::min(2, std::min(2048 / 256, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
+    const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
+    hipLaunchKernelGGL((block4_fused_kernel<7, 256, NP, true, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, x_in, x_plane,
+                       (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+    return hipGetLastError();
 }
 
 // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h; fp16-plane mode only): x_in fp32 [B][112][160][2] -> out16 fp16 planes [2][B][56][80][32]
@@ -288,7 +174,7 @@ hipError_t launch_conv_first_s3_np(const float* x_in, const void* wfrag, const f
                                    int h, int w, hipStream_t s) {
     const int tx = (w + 31) / 32, ty = (h + 15) / 16;
     const int n_tiles = batch * tx * ty;
-    static const int per_cu = std::getenv("HNET_B30_WGS") ? std::atoi(std::getenv("HNET_B30_WGS")) : 2;    // measured 0.113 (2) / 0.119 (3) / 0.114 (4) ms at batch 256
+    constexpr int per_cu = 2;    // measured 0.113 (2) / 0.119 (3) / 0.114 (4) ms at batch 256
     hipLaunchKernelGGL(conv7_c2_s1_s3_kernel<NP>, dim3((unsigned)std::min(n_tiles, 256 * per_cu)), dim3(256), 0, s, x_in, (const u32x4*)wfrag, bias,
                        out16, o_plane, h, w, tx, ty, n_tiles);
     return hipGetLastError();
@@ -329,8 +215,8 @@ static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfra
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int n_tiles = batch * ((ho + C::TH - 1) / C::TH) * ((wo + C::TW - 1) / C::TW);
     const unsigned blocks = (unsigned)std::min(n_tiles, 512);      // persistent, 2 workgroups per CU
-    // bit 0: reverse the 5x5 kernel (block_3_1), bit 1: reverse the 3x3 kernel (block_4_2)
-    static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
+    // the tiles are walked from the end of the batch (Infinity-Cache order): bit 0 the 5x5 kernel (block_3_1), bit 1 the 3x3 kernel (block_4_2)
+    constexpr int rev = 3;
     const int r = KS == 5 ? (rev & 1) : ((rev >> 1) & 1);
     if constexpr (KS == 5 && NP != 1) {      // more region rows per batch of staging loads (HNET_PATCH_RB5): the staging was latency bound
         constexpr int RBMAX = NP == 2 ? 5 : 3;   // what fits the 256 registers next to the 156 weight registers
@@ -362,30 +248,12 @@ hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, i
     if ((layer == 9 || layer == 16) && h == 56 && w == 80) {     // block_3_2 / block_4_3
         typedef Patch32Cfg<NP> C;
         const int n_tiles = batch * (28 / C::TH) * (40 / C::TW);
-        static const int rev = std::getenv("HNET_PATCH_REV") ? std::atoi(std::getenv("HNET_PATCH_REV")) : 3;
+        constexpr int rev = 3;      // (bit 2 = conv_patch32: forward walk)
         hipLaunchKernelGGL((conv_patch32_s2_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
                            (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
-}
-
-// block_1_2 (layer 1) / block_2_2 (layer 4): 5x5 stride 2 from an LDS-resident input region (conv5_region.h); wpack [CIN/16][13][3][128][32] bf16
-template <int NP>
-hipError_t launch_conv5_region_np(int layer, const uint16_t* in, size_t i_plane, int batch, const void* wpack, const float* bias, uint16_t* out16,
-                                  size_t o_plane, hipStream_t s) {
-    if (layer == 1) {
-        typedef Conv5Cfg<128, 14, 20, NP> C;
-        hipLaunchKernelGGL((conv5_region_kernel<128, 14, 20, NP>), dim3((unsigned)(batch * C::TILES_Y)), dim3(512), C::LDS_BYTES, s, in, i_plane,
-                           (const u32x4*)wpack, bias, out16, o_plane);
-    } else if (layer == 4) {
-        typedef Conv5Cfg<64, 28, 40, NP> C;
-        hipLaunchKernelGGL((conv5_region_kernel<64, 28, 40, NP>), dim3((unsigned)(batch * C::TILES_Y)), dim3(512), C::LDS_BYTES, s, in, i_plane,
-                           (const u32x4*)wpack, bias, out16, o_plane);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 // first FC of both heads on the bf16 matrix cores.  feat fp32 [B][5120]; w1planes [3][512][5120] bf16;
@@ -399,11 +267,14 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     // heads_prep_kernel forms its byte and row indices in 32 bits (i0 = blockIdx.x * 1024, row = i0 / 640): refuse what would wrap
     // (batch x n_local beyond ~3.3 M rows, or more than ~200 k pairs; hnet_create rejects such a max_batch x N as well)
     if (4 * nwork + 1024 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
-    // whole rounds of 128 x 128 tiles on the 256 CUs: the pipelined kernel (igemm_pipe.h), which reads its keep bits K-tile major
+    // whole rounds of 128 x 128 tiles on the 256 CUs: the pipelined kernel (igemm_pipe.h), which reads its keep bits K-tile major.  It is a
+    // one-workgroup-per-CU kernel, so it pays when its 4 x M / 128 tiles fill whole rounds (heads_fc1, ms, four-wave 128 x 64 / eight waves, N = 32, round 3:
+    // batch 128 0.116 / 0.112, 192 0.162 / 0.144, 256 0.180 / 0.158, 320 0.255 / 0.276, 384 0.264 / 0.278, 512 0.359 / 0.319) -> up to one round, or when
+    // the last round is at least three quarters full.  tile (hnet_config.variant): 13 = the four-wave kernel, 22 = the eight-wave kernel of round 3 (A/B, bitwise tests)
     const int Mh = batch * n_local;
     const long t8h = (long)((Mh + 127) / 128) * 4;
-    const bool one_per_cu = Mh >= 4096 && (t8h <= 256 || t8h % 256 == 0 || t8h % 256 >= 192);
-    const bool pipe = NP == 2 && one_per_cu && tile != 13 && tile != 3 && tile != 2 && tile != 12 && tile != 22;     // (HNET_S3_TILE=22: the eight-wave kernel of round 3, A/B)
+    const bool one_per_cu = Mh >= 4096 && (t8h <= 256 || t8h % 256 == 0 || t8h % 256 >= 192) && tile != 13;
+    const bool pipe = NP == 2 && one_per_cu && tile != 22;
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
                        hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP, pipe ? 1 : 0);
     S3Params p = {};
@@ -417,15 +288,7 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
             hipLaunchKernelGGL(igemm_heads_pipe_kernel<NP>, dim3((unsigned)((p.M + 127) / 128), 4, 1), dim3(HeadsPipeCfg::NT), HeadsPipeCfg::LDS_BYTES, s, p);
             return hipGetLastError();
         }
-        if ((tile == 2 || tile == 12) && p.M >= 4096) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP>(p, s, ws, wsn);
-        // Eight waves on 128 x 128 tiles, double-buffered LDS, one barrier per K-tile (igemm_s3_lean8_kernel): one workgroup per CU, so it
-        // pays when the 4 x M / 128 tiles fill whole rounds of the 256 CUs.  heads_fc1, ms, 128 x 64 four-wave / this kernel (N = 32):
-        // batch 128 0.116 / 0.112, 192 0.162 / 0.144, 256 0.180 / 0.158, 320 0.255 / 0.276, 384 0.264 / 0.278, 512 0.359 / 0.319
-        // -> up to one round, or when the last round is at least three quarters full (HNET_S3_TILE=13: the four-wave kernel)
-        const long t8 = (long)((p.M + 127) / 128) * 4;
-        if (tile != 13 && tile != 3 && p.M >= 4096 && (t8 <= 256 || t8 % 256 == 0 || t8 % 256 >= 192))
-            return run_s3<HeadLoaderS3, 128, 128, 2, true, NP, true>(p, s, ws, wsn);
-        if (tile == 3) return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, nullptr, 0);       // experiment: 64 x 64 tiles (four workgroups per CU) at large M
+        if (one_per_cu) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP, true>(p, s, ws, wsn);
     }
     // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
     if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn);
@@ -469,25 +332,9 @@ hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int
 // dynamic-LDS limits of the kernels that use more than 64 KB, for this NP; once per device
 template <int NP>
 hipError_t conv_kernels_init_device_np() {
-    hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 512, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP, true>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
-    if constexpr (NP != 2) {
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<8, 512, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 512, NP>::LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel_v2<7, 256, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP>::LDS_BYTES);
-    }
+    hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if constexpr (NP == 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<HeadLoaderS3, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        // (the conv-layer instances exist for the HNET_S3_TILE=12 experiment only)
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 5, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<64, 5, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<64, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<128, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, false, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<ConvLoaderS3<256, 3, 2, 32>, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
 #define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
         typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;
         HNET_PIPE_ATTR(L1283, PipeCfg140, false); HNET_PIPE_ATTR(L645, PipeCfg140, false); HNET_PIPE_ATTR(L643, PipeCfg140, false);
@@ -497,29 +344,23 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
     }
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if constexpr (NP != 1) {
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true, (NP == 2 ? 5 : 3)>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<128, 14, 20, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<128, 14, 20, NP>::LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv5_region_kernel<64, 28, 40, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv5Cfg<64, 28, 40, NP>::LDS_BYTES);
     return e;
 }
 
 // the explicit instantiations live in kernels_conv.hip (NP = 3), kernels_conv_bf16.hip (NP = 1) and kernels_conv_f16x2.hip (NP = 2)
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
-                                                      uint16_t*, size_t, int, hipStream_t, int, int);                                    \
+                                                      uint16_t*, size_t, int, hipStream_t, int);                                         \
     KW template hipError_t launch_block42_fused_np<NP>(const uint16_t*, size_t, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_block3_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s2_np<NP>(int, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
-    KW template hipError_t launch_conv5_region_np<NP>(int, const uint16_t*, size_t, int, const void*, const float*, uint16_t*, size_t, hipStream_t); \
     KW template hipError_t launch_conv_patch_np<NP>(int, const uint16_t*, size_t, int, int, int, const void*, const float*, uint16_t*,   \
                                                     size_t, hipStream_t, bool, int);                                                           \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \

@@ -26,6 +26,22 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def kernel_selection_from_env():
+    """hnet_config.warp_exact / .graph / .variant from this process's environment.  The C library reads no environment variable (round 4);
+    the test suite and tools/ab_bench.py keep selecting reference kernels with HNET_WARP_EXACT, HNET_GRAPH (0 eager, 1 replay also in the timing
+    entry point), HNET_S3_TILE (13 / 20 / 21 / 22 / 23: include/hnet.h HNET_VARIANT_*), HNET_FUSE_SMALL=0, HNET_FUSE_B3=0, HNET_FUSE_B42=0 - mapped here."""
+    env = os.environ.get
+    variant = int(env("HNET_S3_TILE", "0")) & 0xff
+    if env("HNET_FUSE_SMALL", "1") == "0":
+        variant |= 1 << 8
+    if env("HNET_FUSE_B3", "1") == "0":
+        variant |= 1 << 9
+    if env("HNET_FUSE_B42", "1") == "0":
+        variant |= 1 << 10
+    graph = {"0": 1, "1": 2}.get(env("HNET_GRAPH", ""), 0)
+    return int(env("HNET_WARP_EXACT", "0") != "0"), graph, variant
+
+
 class HnetEngine:
     """One hnet context (one GPU).  `weights` is an HNETW001 blob (bytes) or a path to one."""
 
@@ -42,6 +58,7 @@ class HnetEngine:
         cfg.emit_error_map, cfg.precision, cfg.max_batch = int(emit_error_map), precision, max_batch
         if mc_shard is not None:
             cfg.mc_sample_begin, cfg.mc_sample_end = mc_shard
+        cfg.warp_exact, cfg.graph, cfg.variant = kernel_selection_from_env()
         self.cfg, self.variant, self._L = cfg, variant, L
         self._h = C.c_void_p()
         if isinstance(weights, (bytes, bytearray)):

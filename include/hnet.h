@@ -71,7 +71,24 @@ typedef struct hnet_config {
     int32_t  max_batch;        /* capacity (frame pairs) of the persistent activation buffers, >= 1 */
     int32_t  mc_sample_begin;  /* this context evaluates global samples [begin, end) in the *_partial entry points; */
     int32_t  mc_sample_end;    /* 0,0 = all */
+    /* Kernel selection (round 4: the library reads no environment variable; 0 everywhere = the measured defaults = what hnet_default_config sets).
+     * These fields replace the HNET_* switches that rounds 1 - 3 read with getenv at hnet_create: a stray variable in a deployment can no longer
+     * change kernels or summation order.  The tests and tools/ab_bench.py set them explicitly (the Python mirror maps its own environment onto them). */
+    int32_t  warp_exact;       /* 1: the warp keeps grid_sample's sampling positions bit for bit (warp.py:70); 0: fast sampler, positions within 6e-5 px */
+    int32_t  graph;            /* HNET_GRAPH_*: hipGraph replay of the batch-1 forward of hnet_infer */
+    uint32_t variant;          /* HNET_VARIANT_*: reference kernels for in-process A/B measurements and the bitwise cross-kernel tests */
 } hnet_config;
+
+enum { HNET_GRAPH_DEFAULT = 0 /* replay */, HNET_GRAPH_OFF = 1 /* eager launches */, HNET_GRAPH_TIMING = 2 /* replay, also inside hnet_time_batch_device */ };
+enum {
+    HNET_VARIANT_GEMM_MASK = 0xff,            /* low byte: implicit-GEMM kernel selection (csrc/s3_dispatch.h):
+                                                  0 = defaults; 13 = heads FC1 on the four-wave 128 x 64 kernel; 22 = on the eight-wave kernel of round 3;
+                                                  20 = conv layers on the four-wave lean kernels (no pipelined LDS-DMA kernel); 21 = the pipelined kernel at any
+                                                  batch (tests); 23 = its 160 x 128 / 512-thread tile instead of 144 x 128 / 768 threads */
+    HNET_VARIANT_NO_LATENCY_PATH = 1u << 8,   /* batch <= 8 on the multi-launch path (bit-identical; tests/test_gpu_latency_path.py) */
+    HNET_VARIANT_UNFUSED_B3 = 1u << 9,        /* block_3_0 and block_3_1 as separate launches (fp16-plane mode) */
+    HNET_VARIANT_UNFUSED_B42 = 1u << 10       /* block_4_2 and block_4_3 as separate launches (fp16-plane mode) */
+};
 
 typedef struct hnet_ctx hnet_ctx;
 

@@ -23,7 +23,16 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # golden is below the reference's own noise; the gates are:
 TOL_PX_VS_REF32 = 3e-4      # |offset - reference fp32 golden|, px
 TOL_PX_VS_REF64 = 1e-4      # |offset - reference fp64 golden|, px  (north_star's 1e-4 px, against the reference evaluated in double)
-TOL_PX_VS_ORACLE = 1e-4     # |HIP - oracle (double accumulation)|, px  (north_star's figure; measured <= 4e-5)
+TOL_PX_VS_ORACLE = 1e-4     # |HIP - oracle (double accumulation)|, px, DEFAULT arithmetic (two fp16 planes, fast sampler): north_star's figure.
+                            # Measured: <= 3.8e-5 on the 28 goldens, worst slot of a 256-pair batch 7.5e-5 (profiles/r03_v10_full_batch_check.log)
+
+
+def tol_px_vs_oracle(precision):
+    """gate of |HIP - oracle| per arithmetic mode.  The oracle accumulates in double; what a mode is compared against is its
+    own fp32 accumulation noise.  The default mode (3, two fp16 planes) is GATED at north_star's 1e-4 px.  The two reference modes - exact fp32 MFMA (0)
+    and split-bf16 (2) - measure 1.0e-4 on the worst slot of a 256-pair batch (the network's fp32 accumulation noise sits ON 1e-4: r03_v10_full_batch_check.log)
+    and are gated at 1.5e-4 = that noise + margin, so that a reordering of the summation or another seed does not flake.  Plain bf16 (1) is reported, never gated."""
+    return {3: TOL_PX_VS_ORACLE, 2: 1.5e-4, 0: 1.5e-4}[int(precision)]
 TOL_COV_REL = 2e-5          # max |cov - ref| / max |ref|
 
 

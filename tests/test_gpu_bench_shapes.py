@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE
+from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE, tol_px_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def _check_batch(blob, oracle, variant, batch, n_mc, precision, check_pairs, n_d
         o = oracle.forward(prev[b], curr[b], None if prior is None else prior[b], btr, n_mc, 0.05, MC_SEED, s0 + b)
         d = float(np.abs(mean[b] - o["mean"]).max())
         worst = max(worst, d)
-        assert d < TOL_PX_VS_ORACLE, (b, d)
+        assert d < tol_px_vs_oracle(precision), (b, d)
         assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
     print(f"{variant} B={batch} N={n_mc} precision={precision}: max |hip - oracle| over pairs {list(check_pairs)} = {worst:.2e} px")
     # slot invariance at the benchmarked batch: pair b sits in slot b + rot with the same mask sequence number
@@ -76,26 +76,17 @@ def _conv2(state, x):
     return pyoracle.conv_lrelu(y, state[pre + "block_4_1.0.weight"], state[pre + "block_4_1.0.bias"], 2)
 
 
-@pytest.mark.parametrize("prec,cfg", [(2, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (2, 6), (3, 0), (3, 1), (3, 4), (3, 5), (3, 6)])
+@pytest.mark.parametrize("prec", [2, 3])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 5])
-def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, cfg, prec):
+def test_block4_fused_kernel_elementwise(blob, state, batch, reverse, prec):
     """block4_fused_kernel (block_4_0 + block_4_1 in one launch, the 8-channel map never leaves LDS) against
     conv_lrelu(conv_lrelu(.)) of the oracle, every element of every pair, random inputs that are non-zero up to the image
     border (so the zero padding of BOTH layers matters), forward and reverse tile walk, batches that give every persistent
-    workgroup 1 tile (70, 210 tiles) and more than one (350 tiles over 256 workgroups); both geometries of the kernel
-    (cfg 0: 8x32 tiles, 512 threads, one workgroup per CU; cfg 1: 7x32 tiles, 256 threads, two per CU: 80 / 240 / 400 tiles; cfg 2, 3: the same
-    geometries in the v2 kernel kept for A/B)"""
+    workgroup 1 tile (80, 240 tiles) and more than one (400 tiles over 256 workgroups).  (Rounds 2 - 3 ran this over six kernel variants;
+    round 4 removed the five that lost: 7 x 32 tiles / 256 threads / LDS-DMA staging / phase-1 fragment reuse is the kernel.)"""
     from cuahn_vio_amd.homography_net import HnetEngine
-    old = os.environ.get("HNET_B4_CFG")
-    os.environ["HNET_B4_CFG"] = str(cfg)          # read by hnet_create
-    try:
-        eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=prec)
-    finally:
-        if old is None:
-            del os.environ["HNET_B4_CFG"]
-        else:
-            os.environ["HNET_B4_CFG"] = old
+    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=prec)
     rng = np.random.default_rng(100 + batch)
     x = rng.standard_normal((batch, 2, 224, 320)).astype(np.float32)
     x[:, :, :3, :] += 2.0          # make the borders stand out: a wrong border / padding rule cannot hide
@@ -177,28 +168,6 @@ def test_iekf_reruns_do_not_enter_the_timing_average(blob):
     assert t["n_inferences"] == 5 and t["n_main_inferences"] == 2
 
 
-@pytest.mark.parametrize("layer,batch", [(1, 5), (4, 5)])
-def test_conv5_region_kernel_opt_in(blob, state, layer, batch, monkeypatch):
-    """conv5_region_kernel (block_1_2 / block_2_2 from an LDS-resident region, weights streamed into registers) is opt-in
-    (HNET_CONV5_REGION=1: measured at parity with the implicit GEMM): every element vs the oracle conv, and a golden forward"""
-    from cuahn_vio_amd.homography_net import HnetEngine
-    from cuahn_vio_amd.weights import CONV_LAYERS
-    from oracle import pyoracle
-    monkeypatch.setenv("HNET_CONV5_REGION", "1")
-    eng = HnetEngine(blob, variant="full", mc_samples=1, dropout_p=0.0, max_batch=1, precision=2)
-    name, cin, cout, k, s = CONV_LAYERS[layer]
-    h, w = {1: (14, 20), 4: (28, 40)}[layer]
-    rng = np.random.default_rng(200 + layer)
-    x = rng.standard_normal((batch, cin, h, w)).astype(np.float32)
-    got = eng.op_conv(layer, x)
-    for b in range(batch):
-        ref = pyoracle.conv_lrelu(x[b], state["model_part1." + name + ".0.weight"], state["model_part1." + name + ".0.bias"], s)
-        err = float(np.abs(got[b] - ref).max())
-        assert err < 2e-5 * max(1.0, float(np.abs(ref).max())), (name, b, err)
-    eng.close()
-
-
-# ---------------------------------------------------------------------------------------------- the fused block-3 kernel, element by element
 def _conv2_b3(state, x):
     from oracle import pyoracle
     pre = "model_part1."
@@ -315,20 +284,31 @@ def test_heads_gemm_kernels_agree_bitwise(blob, batch, n_mc):
         assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1]), k
 
 
-def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle):
-    """bench.py's workload with 256 DISTINCT pairs (textures, homographies), default arithmetic (two fp16 planes, fast sampler): all 256 slots
-    against the oracle, not a selection (tools/full_batch_check.py prints the distribution; profiles/r03_v10_full_batch_check.log: max 7.5e-5 px)."""
+_ORACLE_256 = {}      # the oracle's answers for the 256 distinct pairs, computed once for the three modes
+
+
+@pytest.mark.parametrize("precision", [pytest.param(3, id="f16x2"), pytest.param(2, id="bf16x3"), pytest.param(0, id="fp32")])
+def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle, precision):
+    """bench.py's workload with 256 DISTINCT pairs (textures, homographies), fast sampler, in the default arithmetic (two fp16 planes: gate 1e-4 px,
+    north_star's figure) and in the two reference modes (gate 1.5e-4: conftest.tol_px_vs_oracle): all 256 slots against the oracle, not a selection.
+    Prints the worst slot per mode (tools/full_batch_check.py prints the distribution; profiles/r03_v10_full_batch_check.log: default mode max 7.5e-5 px)."""
     from cuahn_vio_amd.homography_net import HnetEngine
     B, n_mc = 256, 32
     prev, curr, _prior = _batch(70000, B, B)
-    eng = HnetEngine(blob, variant="full", mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=B, precision=3)
+    eng = HnetEngine(blob, variant="full", mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=B, precision=precision)
     mean, cov = eng.infer_batch(prev, curr, None, pair_seq0=4242)
     eng.close()
-    worst = 0.0
+    worst, gate = 0.0, tol_px_vs_oracle(precision)
     for b in range(B):
-        o = oracle.forward(prev[b], curr[b], None, 3, n_mc, 0.05, MC_SEED, 4242 + b)
+        if b not in _ORACLE_256:
+            _ORACLE_256[b] = oracle.forward(prev[b], curr[b], None, 3, n_mc, 0.05, MC_SEED, 4242 + b)
+        o = _ORACLE_256[b]
         d = float(np.abs(mean[b] - o["mean"]).max())
         worst = max(worst, d)
-        assert d < TOL_PX_VS_ORACLE, (b, d)
+        assert d < gate, (b, d)
         assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
-    print(f"all {B} slots: max |hip - oracle| = {worst:.2e} px")
+    print(f"all {B} slots, precision {precision}: max |hip - oracle| = {worst:.2e} px (gate {gate:.1e})")
+    out = os.environ.get("HNET_FULL_BATCH_LOG")
+    if out:
+        with open(out, "a") as f:
+            f.write(f"precision={precision} slots={B} max_abs_err_vs_oracle_px={worst:.3e} gate_px={gate:.1e}\n")

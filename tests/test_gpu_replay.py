@@ -3,7 +3,7 @@ priors from the filter's mean propagation, through the prior-3 model the referen
 import numpy as np
 import pytest
 
-from conftest import TOL_COV_REL, TOL_PX_VS_ORACLE
+from conftest import TOL_COV_REL, tol_px_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -20,5 +20,5 @@ def test_replayed_pairs_match_the_oracle(blob, oracle, precision):
     eng.close()
     for b in range(10):
         o = oracle.forward(prev[b], curr[b], prior[b], 3, 16, 0.05, 9, 120 + b)
-        assert np.abs(mean[b] - o["mean"]).max() < TOL_PX_VS_ORACLE, b
+        assert np.abs(mean[b] - o["mean"]).max() < tol_px_vs_oracle(precision), b
         assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b

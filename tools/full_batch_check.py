@@ -34,7 +34,8 @@ for b in range(B):
     err[b] = np.abs(mean[b] - o["mean"]).max()
     cre[b] = np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max()
 print(f"{variant} B={B} N={N}, {nd} distinct pairs, precision {prec}, HNET_WARP_EXACT={os.environ.get('HNET_WARP_EXACT', '0')}, oracle time {time.time() - t0:.1f} s")
-print(f"|offset - oracle| px: max {err.max():.3e} (slot {int(err.argmax())}), p99 {np.percentile(err, 99):.3e}, median {np.median(err):.3e}; gate 1e-4")
+gate = 1e-4 if prec == 3 else 1.5e-4        # tests/conftest.py tol_px_vs_oracle: the default mode at north_star's figure, the reference modes at their own fp32 noise + margin
+print(f"|offset - oracle| px: max {err.max():.3e} (slot {int(err.argmax())}), p99 {np.percentile(err, 99):.3e}, median {np.median(err):.3e}; gate {gate:.1e}")
 print(f"cov rel err: max {cre.max():.3e}, median {np.median(cre):.3e}; gate 2e-5")
 print(f"max |offset| in the batch: {np.abs(mean).max():.2f} px; stages: {len(eng.stages())}")
-sys.exit(0 if err.max() < 1e-4 and cre.max() < 2e-5 else 1)
+sys.exit(0 if err.max() < gate and cre.max() < 2e-5 else 1)
