@@ -19,7 +19,7 @@ ERR_NOT_READY = 4
 # every symbol include/hnet.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "hnet_default_config", "hnet_create", "hnet_create_from_memory", "hnet_destroy", "hnet_status_string",
-    "hnet_last_error", "hnet_version", "hnet_push_image", "hnet_image_count", "hnet_latest_time", "hnet_infer",
+    "hnet_last_error", "hnet_version", "hnet_push_image", "hnet_attach_images", "hnet_image_count", "hnet_latest_time", "hnet_infer",
     "hnet_infer_batch", "hnet_infer_batch_device", "hnet_infer_mc_partial_device", "hnet_mc_finish_device",
     "hnet_synchronize", "hnet_last_timing", "hnet_time_batch_device", "hnet_stage_count", "hnet_stage_name",
     "hnet_stage_flops_per_pair", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
@@ -83,6 +83,7 @@ def lib():
     L.hnet_get_undistort_maps.argtypes = [vp, fp, fp]
     L.hnet_push_raw_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     L.hnet_op_undistort.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.hnet_attach_images.argtypes = [vp, vp]
     L.hnet_image_count.argtypes = [vp]
     L.hnet_precision.argtypes = [vp]
     L.hnet_latest_time.argtypes = [vp]

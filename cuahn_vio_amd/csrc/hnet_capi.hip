@@ -136,6 +136,7 @@ struct hnet_ctx {
     int curr_slot = 0;
     int img_counter = 0;
     double latest_t = -1.0;
+    hnet_ctx* img_src = nullptr;       // hnet_attach_images: frames, counters and the mask sequence number are read from this context (the IEKF's iterative model)
     int n_local = 0, s_begin = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1092,8 +1093,8 @@ int hnet_op_undistort(hnet_ctx* c, const uint8_t* raw, int rows, int cols, int r
     return rc;
 }
 
-int hnet_image_count(const hnet_ctx* c) { return c ? c->img_counter : 0; }
-double hnet_latest_time(const hnet_ctx* c) { return c ? c->latest_t : -1.0; }
+int hnet_image_count(const hnet_ctx* c) { return c ? (c->img_src ? c->img_src : c)->img_counter : 0; }
+double hnet_latest_time(const hnet_ctx* c) { return c ? (c->img_src ? c->img_src : c)->latest_t : -1.0; }
 
 // `main_model`: the call the reference times (num_of_inference == 0, HomographyNet.cpp:174-189); IEKF re-runs (iteration > 0)
 // advance the mask sequence number (n_inferences) but not the timing statistics (:245-251 sit under `num_of_inference == 0`)
@@ -1154,20 +1155,22 @@ static bool prior_finite(const double* p, size_t n) {
 
 int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_out[8], float cov_out[64], uint8_t* err_map_out) {
     if (!c || !mean_out || !cov_out) return HNET_ERR_INVALID_ARG;
-    if (c->img_counter < 2) return fail(c, HNET_ERR_NOT_READY, "HNet cannot inference! Only has one image!");   // :155-158
+    hnet_ctx* src = c->img_src ? c->img_src : c;                 // the context that owns the frames and the sequence count (hnet_attach_images)
+    if (src->img_counter < 2) return fail(c, HNET_ERR_NOT_READY, "HNet cannot inference! Only has one image!");   // :155-158
     if (err_map_out && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     auto t0 = std::chrono::steady_clock::now();
     if (c->cfg.use_prior && !prior_px) return fail(c, HNET_ERR_INVALID_ARG, "prior required");
+    if (src != c) HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_img[src->curr_slot], 0));      // the frame's upload runs on the source's stream
     if (c->use_graph) {
         // one graph per ring orientation: H2D {seq, prior} from pinned memory -> forward -> D2H {mean, cov, err} to pinned
-        const int slot = c->curr_slot;
+        const int slot = src->curr_slot;
         hnet_ctx::Pinned* pin = c->pinned;
         if (!c->g_infer[slot]) {
             c->g_infer[slot] = capture_graph(c, [&]() -> int {
                 if (hipMemcpyAsync(c->d_seq, &pin->seq, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (c->cfg.use_prior && hipMemcpyAsync(c->d_prior, pin->prior, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
-                FwdArgs ga = {c->ring[slot ^ 1], c->ring[slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1, 0, c->d_mean, c->d_cov,
+                FwdArgs ga = {src->ring[slot ^ 1], src->ring[slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1, 0, c->d_mean, c->d_cov,
                               nullptr, c->cfg.emit_error_map ? c->d_err_u8 : nullptr, nullptr, nullptr, nullptr, false};
                 ga.seq_dev = c->d_seq;
                 const int rc = forward(c, ga, c->stream);
@@ -1184,7 +1187,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
         }
         if (c->g_infer[slot]) {
             c->H_last = c->g_infer_H[slot];
-            pin->seq = (uint64_t)c->timing.n_inferences;
+            pin->seq = (uint64_t)src->timing.n_inferences;
             if (c->cfg.use_prior) for (int i = 0; i < 8; i++) pin->prior[i] = (float)prior_px[i];    // :160-165 toType(kFloat)
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
             HIPCHK(c, hipGraphLaunch(c->g_infer[slot], c->stream));
@@ -1200,6 +1203,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             float gms = 0;
             HIPCHK(c, hipEventElapsedTime(&gms, c->ev0, c->ev1));
             note_timing(c, gms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), iteration == 0);
+            if (src != c) src->timing.n_inferences++;             // one shared sequence count
             return HNET_OK;
         }
     }
@@ -1209,8 +1213,8 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
         HIPCHK(c, hipMemcpyAsync(c->d_prior, pf, sizeof pf, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    FwdArgs a = {c->ring[c->curr_slot ^ 1], c->ring[c->curr_slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1,
-                 (uint64_t)c->timing.n_inferences, c->d_mean, c->d_cov, nullptr, err_map_out ? c->d_err_u8 : nullptr,
+    FwdArgs a = {src->ring[src->curr_slot ^ 1], src->ring[src->curr_slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1,
+                 (uint64_t)src->timing.n_inferences, c->d_mean, c->d_cov, nullptr, err_map_out ? c->d_err_u8 : nullptr,
                  nullptr, nullptr, nullptr, false};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     int rc = forward(c, a, c->stream);
@@ -1228,6 +1232,14 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     note_timing(c, ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), iteration == 0);
+    if (src != c) src->timing.n_inferences++;
+    return HNET_OK;
+}
+
+int hnet_attach_images(hnet_ctx* c, hnet_ctx* source) {
+    if (!c || !source || c == source || source->img_src) return HNET_ERR_INVALID_ARG;
+    if (c->cfg.device_id != source->cfg.device_id) return fail(c, HNET_ERR_INVALID_ARG, "hnet_attach_images: both contexts must live on one device");
+    c->img_src = source;
     return HNET_OK;
 }
 

@@ -292,18 +292,27 @@ class HomographyNet:
 
     def __init__(self, network_model_path, network_model_iterative_path="", use_prior=False, num_of_iteration=1,
                  show_imgs=False, *, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=0, device_id=0,
-                 weights_blob=None, precision=None):
+                 weights_blob=None, precision=None, blocks_to_run_iterative=None, weights_blob_iterative=None):
         self.use_prior_4pt_offset = bool(use_prior)
-        self.show_phtometric_error = "_showError" in str(network_model_path)
         self.cv_imshow = bool(show_imgs)
         self.iteration = num_of_iteration > 1
+        main_err, iter_err = "_showError" in str(network_model_path), "_showError" in str(network_model_iterative_path)
+        self.show_phtometric_error = iter_err if self.iteration else main_err       # one member in the reference: the file loaded last decides (:96-100, :117-121)
         variant = {3: "prior3", 2: "prior2", 1: "prior1"}[blocks_to_run] if use_prior else "full"
         print("Loading the Network Model (HNETW001 weights) ...")
         self._eng = HnetEngine(weights_blob if weights_blob is not None else network_model_path, variant=variant,
                                mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
-                               emit_error_map=self.show_phtometric_error, device_id=device_id, precision=precision)
+                               emit_error_map=main_err and not self.iteration, device_id=device_id, precision=precision)
         t = self._eng.last_timing()
         print(f"[TIME]: {t['host_ms']:.4f} milliseconds for the first network inference")
+        self._eng_iter = None
+        if self.iteration:      # HomographyNet.cpp:20-24: a second model for iteration > 0, warmed up (:49-56), fed the same frames
+            v_it = {3: "prior3", 2: "prior2", 1: "prior1"}[blocks_to_run_iterative or blocks_to_run] if use_prior else "full"
+            w_it = weights_blob_iterative if weights_blob_iterative is not None else (weights_blob if weights_blob is not None else network_model_iterative_path)
+            self._eng_iter = HnetEngine(w_it, variant=v_it, mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
+                                        emit_error_map=iter_err, device_id=device_id, precision=precision)
+            check(self._eng_iter.handle, self._eng._L.hnet_attach_images(self._eng_iter.handle, self._eng.handle))
+            print("IEKF! Load the Network for Iteration!")
         self._pred_mean = np.zeros((8, 1), np.float32)
         self._pred_Cov = np.zeros((8, 8), np.float32)
         self.last_error_map = None
@@ -328,17 +337,18 @@ class HomographyNet:
         """HomographyNet.cpp:153-252"""
         mean = np.zeros(8, np.float32)
         cov = np.zeros((8, 8), np.float32)
-        err = np.zeros((IMG_H, IMG_W), np.uint8) if self.show_phtometric_error else None
+        net = self._eng_iter if (self._eng_iter is not None and num_of_inference > 0) else self._eng      # HomographyNet_model / _model_iterative (:183, :211)
+        err = np.zeros((IMG_H, IMG_W), np.uint8) if (self.show_phtometric_error and (net is self._eng_iter or not self.iteration)) else None
         pr = None
         if self.use_prior_4pt_offset:
             pr = np.ascontiguousarray(prior_4pt_offset_vec, dtype=np.float64).reshape(8)
-        rc = self._eng._L.hnet_infer(self._eng.handle, pr.ctypes.data_as(C.POINTER(C.c_double)) if pr is not None else None,
+        rc = self._eng._L.hnet_infer(net.handle, pr.ctypes.data_as(C.POINTER(C.c_double)) if pr is not None else None,
                                      int(num_of_inference), _fp(mean), _fp(cov),
                                      err.ctypes.data_as(C.POINTER(C.c_uint8)) if err is not None else None)
         if rc == _capi.ERR_NOT_READY:   # :155-158 prints and returns with the previous outputs
             print("HNet cannot inference! Only has one image!")
             return
-        check(self._eng.handle, rc)
+        check(net.handle, rc)
         self._pred_mean = mean.reshape(8, 1)
         self._pred_Cov = cov
         self.last_error_map = err
@@ -356,3 +366,17 @@ class HomographyNet:
 
     def get_latest_inference_time(self):
         return self._eng._L.hnet_latest_time(self._eng.handle)
+
+    def close(self):
+        """the iterative model's context reads the main context's frames (hnet_attach_images): it goes first"""
+        if getattr(self, "_eng_iter", None) is not None:
+            self._eng_iter.close()
+            self._eng_iter = None
+        if getattr(self, "_eng", None) is not None:
+            self._eng.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -19,8 +19,10 @@
 //   * what the reference freezes into the traced file is read from optional environment variables:
 //     HNET_BLOCKS_TO_RUN (1..3, default 3 = "3_blocks_using_prior"), HNET_MC_SAMPLES (default 16),
 //     HNET_DROPOUT_P (default 0.05), HNET_MC_SEED (default 0), HNET_DEVICE (default 0), HNET_PRECISION (hnet.h).
-//   * the IEKF "iterative" model of the reference is the same network traced a second time; here one context
-//     serves every iteration (`network_model_iterative_path` is accepted and ignored).
+//   * the IEKF "iterative" model (HomographyNet.cpp:20-24,104-124): with num_of_iteration > 1 a SECOND context is created from
+//     `network_model_iterative_path` (its own "_showError" sniff - as in the reference the flag of the file loaded last wins, :117-121 -
+//     and its own HNET_ITER_BLOCKS_TO_RUN, default HNET_BLOCKS_TO_RUN), warmed up like the first (:49-56), attached to the main
+//     context's frames (hnet_attach_images) and used for every call with iteration > 0 (:209-219).
 //   * a failed load throws std::runtime_error instead of printing and crashing at the first forward
 //     (HomographyNet.cpp:91-93).
 //
@@ -52,11 +54,12 @@ class HomographyNet {
 public:
     HomographyNet(std::string& network_model_path, std::string& network_model_iterative_path, bool use_prior,
                   int num_of_iteration, bool show_imgs) {
-        (void)network_model_iterative_path;
         use_prior_4pt_offset = use_prior;
         iteration = num_of_iteration > 1;
         cv_imshow = show_imgs;
-        show_phtometric_error = network_model_path.find("_showError") != std::string::npos;   // HomographyNet.cpp:96-100
+        const bool main_err = network_model_path.find("_showError") != std::string::npos;       // HomographyNet.cpp:96-100
+        const bool iter_err = network_model_iterative_path.find("_showError") != std::string::npos;   // :117-121
+        show_phtometric_error = iteration ? iter_err : main_err;      // one member in the reference: the file loaded last decides
         hnet_config cfg;
         hnet_default_config(&cfg);
         cfg.device_id = env_int("HNET_DEVICE", 0);
@@ -66,15 +69,29 @@ public:
         cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", 0.05);
         cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);
         cfg.precision = env_int("HNET_PRECISION", cfg.precision);      // HNET_PREC_F16X2 (3, default), HNET_PREC_BF16X3 (2), HNET_PREC_FP32 (0), HNET_PREC_BF16 (1)
-        cfg.emit_error_map = show_phtometric_error ? 1 : 0;
+        cfg.emit_error_map = (main_err && !iteration) ? 1 : 0;         // with an iterative model the main model's map is never read (:199)
         cfg.max_batch = 1;
         std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());
-        const int rc = hnet_create(&cfg, network_model_path.c_str(), &ctx_);   // also runs the warm-up forward (:28-45)
+        int rc = hnet_create(&cfg, network_model_path.c_str(), &ctx_);   // also runs the warm-up forward (:28-45)
         if (rc != HNET_OK)
             throw std::runtime_error(std::string("error loading the model !!! (") + hnet_status_string(rc) + ")");
         hnet_timing t;
         hnet_last_timing(ctx_, &t);
         std::printf(HNET_BLUE "[TIME]: %.4f milliseconds for the first network inference\n" HNET_RESET, t.host_ms);
+        if (iteration) {                                               // :20-24, warm-up :49-56
+            hnet_config ci = cfg;
+            ci.blocks_to_run = env_int("HNET_ITER_BLOCKS_TO_RUN", cfg.blocks_to_run);
+            ci.emit_error_map = iter_err ? 1 : 0;
+            std::printf("Loading the Network Model for IEKF (HNETW001 weights) from %s ...\n", network_model_iterative_path.c_str());
+            rc = hnet_create(&ci, network_model_iterative_path.c_str(), &ctx_iter_);
+            if (rc == HNET_OK) rc = hnet_attach_images(ctx_iter_, ctx_);
+            if (rc != HNET_OK) {
+                hnet_destroy(ctx_iter_);
+                hnet_destroy(ctx_);
+                throw std::runtime_error(std::string("error loading the model !!! (iterative: ") + hnet_status_string(rc) + ")");
+            }
+            std::printf("IEKF! Load the Network for Iteration!\n");
+        }
         if (show_phtometric_error) err_map_.resize(HNET_IMG_ROWS * HNET_IMG_COLS);
         _pred_mean.setZero();
         _pred_Cov.setZero();
@@ -87,6 +104,7 @@ public:
     }
 
     ~HomographyNet() {
+        hnet_destroy(ctx_iter_);
         hnet_destroy(ctx_);
         std::printf("HomographyNet Object is being deleted! End of this run ...\n");
     }
@@ -108,7 +126,7 @@ public:
     Eigen::Matrix<double, 8, 8> get_pred_Cov() { return _pred_Cov.template cast<double>(); }
     double get_latest_inference_time() { return hnet_latest_time(ctx_); }
     // extension: wall time of the last network_inference call (ms), for the timing CSV of VioManager.cpp:304-311
-    double last_host_ms() { hnet_timing t; hnet_last_timing(ctx_, &t); return t.host_ms; }
+    double last_host_ms() { hnet_timing t; hnet_last_timing(last_net_ ? last_net_ : ctx_, &t); return t.host_ms; }
 
     // HomographyNet.cpp:153-252
     void network_inference(Eigen::Matrix<double, 8, 1>& prior_4pt_offset_vec, int num_of_inference) {
@@ -117,9 +135,11 @@ public:
         for (int i = 0; i < 8; i++) prior[i] = prior_4pt_offset_vec[i];
         float mean[8], cov[64];
         const bool want_err = cv_imshow && show_phtometric_error;
-        const int rc = hnet_infer(ctx_, use_prior_4pt_offset ? prior : nullptr, num_of_inference, mean, cov,
-                                  show_phtometric_error ? err_map_.data() : nullptr);
-        if (rc != HNET_OK) { std::fprintf(stderr, "network_inference: %s (%s)\n", hnet_status_string(rc), hnet_last_error(ctx_)); return; }
+        hnet_ctx* net = (iteration && num_of_inference > 0) ? ctx_iter_ : ctx_;       // HomographyNet_model / HomographyNet_model_iterative (:183, :211)
+        const bool net_err = show_phtometric_error && (net == ctx_iter_ || !iteration);
+        last_net_ = net;
+        const int rc = hnet_infer(net, use_prior_4pt_offset ? prior : nullptr, num_of_inference, mean, cov, net_err ? err_map_.data() : nullptr);
+        if (rc != HNET_OK) { std::fprintf(stderr, "network_inference: %s (%s)\n", hnet_status_string(rc), hnet_last_error(net)); return; }
         for (int i = 0; i < 8; i++) {
             _pred_mean(i, 0) = mean[i];
             for (int j = 0; j < 8; j++) _pred_Cov(i, j) = cov[i * 8 + j];   // symmetric: the reference's column-major Map of row-major data is the same matrix
@@ -167,6 +187,8 @@ private:
     static double env_double(const char* name, double dflt) { const char* v = std::getenv(name); return v ? std::atof(v) : dflt; }
 
     hnet_ctx* ctx_ = nullptr;
+    hnet_ctx* ctx_iter_ = nullptr;      // the IEKF's second model (num_of_iteration > 1)
+    hnet_ctx* last_net_ = nullptr;      // the context of the last network_inference call
     bool cv_imshow = false;
     bool use_prior_4pt_offset = false;
     bool show_phtometric_error = false;

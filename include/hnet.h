@@ -133,6 +133,13 @@ int hnet_precision(const hnet_ctx* ctx);
  * (row_stride in bytes) to the device, prev <- curr, curr <- img; counts images; records `t` from the second
  * image on. */
 int hnet_push_image(hnet_ctx* ctx, const uint8_t* data, int rows, int cols, int row_stride, double t);
+
+/* The reference's IEKF keeps a SECOND traced model for iteration > 0 (`HomographyNet_model_iterative`, loaded from network_model_iterative_path when
+ * num_of_iteration > 1: HomographyNet.cpp:20-24,104-124, run at :209-219) - a separate file that may be another variant (fewer blocks).  Both
+ * modules see the same nn_inputs (:160-172).  hnet_attach_images makes `ctx` (the iterative model's context) read the frame pair, the image counter,
+ * the time stamp and the MC-dropout sequence number of `source` (the main model's context, same device): images are pushed to `source` only, and
+ * hnet_infer(ctx, ...) runs on source's current pair with the next sequence number of the shared count.  `source` must outlive `ctx`. */
+int hnet_attach_images(hnet_ctx* ctx, hnet_ctx* source);
 int hnet_image_count(const hnet_ctx* ctx);             /* the public `img_counter` (HomographyNet.h:33) */
 
 /* ---- image pre-processing ahead of load_current_img --------------------------------------------

@@ -19,7 +19,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 5) { std::fprintf(stderr, "usage\n"); return 2; }
-    std::string model = argv[1], iter_model = "";
+    std::string model = argv[1], iter_model = argv[1];      // (the reference's launch files name the same traced file twice unless an iterative variant was traced)
     const int n = std::atoi(argv[3]), max_it = std::atoi(argv[4]);
     std::FILE* f = std::fopen(argv[2], "rb");
     if (!f) return 2;

@@ -61,6 +61,43 @@ def test_adapter_runs_like_the_reference_call_sites(blob, tmp_path):
     eng.close()
 
 
+@pytest.mark.gpu
+def test_adapter_routes_iterations_to_the_iterative_model(blob, tmp_path):
+    """network_model_iterative_path (HomographyNet.cpp:20-24,104-124,209-219): a prior-3 main model and a prior-1 ITERATIVE model (another variant,
+    as the reference allows: it is a separate traced file); iteration 0 of every frame must be the prior-3 engine's answer, iteration 1 the prior-1
+    engine's, bit for bit, with one shared MC-dropout sequence count"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    _build()
+    wmain = tmp_path / "traced_model_3_blocks_using_prior.hnw"
+    witer = tmp_path / "traced_model_1_blocks_using_prior.hnw"
+    wmain.write_bytes(blob)
+    witer.write_bytes(blob)
+    frames = np.stack([synth.make_pair(90 + i)[0] for i in range(4)])
+    fpath = tmp_path / "frames.u8"
+    frames.tofile(fpath)
+    env = dict(os.environ, HNET_MC_SEED="4321", HNET_DROPOUT_P="0.05", HNET_BLOCKS_TO_RUN="3", HNET_ITER_BLOCKS_TO_RUN="1")
+    r = subprocess.run([BIN, str(wmain), str(fpath), "4", "1", str(witer), "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "IEKF! Load the Network for Iteration!" in r.stdout
+    res = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert [(int(x[1]), int(x[2])) for x in res] == [(k, it) for k in (1, 2, 3) for it in (0, 1)]
+    engs = {0: HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=4321, max_batch=1),
+            1: HnetEngine(blob, variant="prior1", mc_samples=16, dropout_p=0.05, mc_seed=4321, max_batch=1)}
+    prior = np.array([[1.0, -2.0, 0.5, 3.0, -1.5, 0.25, 2.0, -0.75]], np.float32)
+    for seq, x in enumerate(res):                    # one sequence count for both models
+        k, it = int(x[1]), int(x[2])
+        vals = np.array([float(v) for v in x[3:]], np.float64)
+        m, c = engs[it].infer_batch(frames[k - 1][None], frames[k][None], prior, pair_seq0=seq)
+        assert np.array_equal(vals[:8].astype(np.float32), m[0]), (k, it)
+        assert np.array_equal(vals[8:].astype(np.float32).reshape(8, 8), c[0]), (k, it)
+    m3, _ = engs[0].infer_batch(frames[0][None], frames[1][None], prior, pair_seq0=1)
+    m1, _ = engs[1].infer_batch(frames[0][None], frames[1][None], prior, pair_seq0=1)
+    assert not np.array_equal(m3, m1)                # the two variants really differ
+    for e in engs.values():
+        e.close()
+
+
 IEKF_BIN = os.path.join(ROOT, "tests", "cpp", "iekf_demo.bin")
 
 
