@@ -74,10 +74,20 @@ def parse(argv=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="wall-clock budget of the whole cpu_baseline leg")
+    ap.add_argument("--config", type=int, default=None, choices=[4, 5],
+                    help="BASELINE.json presets for the multi-GPU configurations: 4 = --mode mc --mc 32 --batch 1 (one frame pair, the N = 32 MC-dropout "
+                         "samples sharded over the GPUs, RCCL gather of the per-sample head outputs); 5 = --pairs-total 256 --mode stream --replay "
+                         "indoor_forward_7 --variant prior3 --mc 16 (UZH-FPV replay, 256 streamed pairs per step across the GPUs, PCIe inclusive, RCCL "
+                         "gather of the [B, 72] outputs on a side stream).  Use with --gpus N")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank start-up, process-group creation and the max-over-ranks reduction only (gloo, no GPU): the CPU "
                          "test of the multi-rank launch path")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.config == 4:
+        a.mode, a.mc, a.batch = "mc", 32, 1
+    elif a.config == 5:
+        a.pairs_total, a.mode, a.replay, a.variant, a.mc = 256, "stream", "indoor_forward_7", "prior3", 16
+    return a
 
 
 # ------------------------------------------------------------------------------------------------ multi-rank launch
@@ -257,24 +267,55 @@ def verify_last_step(blob, prev_h, curr_h, prior_h, variant, n_mc, seq_of_slot, 
 
 
 def dry_run(args, rank, world):
-    """the multi-rank plumbing without a GPU: process group (gloo), barrier, max-over-ranks of a timer, one JSON line"""
+    """the multi-rank plumbing without a GPU: process group (gloo), the resolved configuration of the presets, the double-buffered gather of the packed
+    [B, 72] outputs (cuahn_vio_amd.dist.OverlappedGather on CPU tensors: same order of operations as on the GPU, synchronous), barrier, max-over-ranks
+    of a timer, one JSON line"""
     import torch
     import torch.distributed as dist
+    if args.pairs_total is not None:
+        if args.pairs_total % world:
+            raise SystemExit("--pairs-total must be divisible by the number of GPUs")
+        args.batch = args.pairs_total // world
+    if args.mode == "mc" and args.mc % world:
+        raise SystemExit("--mode mc needs N divisible by the number of GPUs")
     if world > 1:
         dist.init_process_group("gloo")
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     dt = time.perf_counter() - t0
-    backend, ranks = None, 1
+    backend, ranks, gather_ok = None, 1, None
     if world > 1:
+        from cuahn_vio_amd import dist as hdist
+        B = min(args.batch, 64)
+        if args.mode == "mc":       # config 4: the per-sample head outputs of this rank's sample range
+            n_loc = args.mc // world
+            ms = torch.full((B, n_loc, 8), float(rank)) + torch.arange(n_loc).view(1, n_loc, 1)
+            ms_all, lv_all, _ = hdist.gather_mc_samples(ms, -ms, None)
+            want = torch.cat([torch.full((B, n_loc, 8), float(r)) + torch.arange(n_loc).view(1, n_loc, 1) for r in range(world)], 1)
+            gather_ok = bool(torch.equal(ms_all, want) and torch.equal(lv_all, -want))
+        else:                       # pairs / stream (config 5): three slabs through the double-buffered gather (small steps are grouped, as in run())
+            og = hdist.OverlappedGather(B, "cpu", group_steps=max(1, 128 // args.batch))
+            fill = lambda i, r: torch.full((B, 72), float(1000 * i + r)) + torch.arange(B).view(B, 1)     # noqa: E731
+            gather_ok = True
+            for i in range(3 * og.G):
+                og.acquire(i)
+                og.buffer(i).copy_(fill(i, rank))
+                og.submit(i)
+                if i % og.G == og.G - 1:          # the slab has been gathered: every step of it, every rank's rows, in rank order
+                    for j in range(i - og.G + 1, i + 1):
+                        gather_ok = gather_ok and bool(torch.equal(og.result(j), torch.stack([fill(j, r) for r in range(world)], 0)))
         dist.barrier()
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt, 0.0 if gather_ok else 1.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, gather_ok = float(t[0]), float(t[1]) == 0.0
         backend, ranks = dist.get_backend(), dist.get_world_size()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "backend": backend, "steps": args.steps,
-                          "warmup": args.warmup, "max_over_ranks_s": round(dt, 4), "value": None}), flush=True)
+                          "warmup": args.warmup, "max_over_ranks_s": round(dt, 4), "value": None,
+                          "resolved": {"config": args.config, "mode": args.mode, "batch_per_gpu": args.batch, "pairs_total": args.pairs_total,
+                                       "mc": args.mc, "mc_per_gpu": args.mc // world if args.mode == "mc" else args.mc, "variant": args.variant,
+                                       "replay": args.replay, "gathers": world > 1 or args.force_collective},
+                          "gather_checked": gather_ok}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -301,6 +342,7 @@ def main():
     # mode regularly shared a queue with the compute stream on the pool's boxes and H2D did not overlap the forward at all
     # (3.6 instead of 3.0 ms per step).  Read by the runtime when HIP initialises, i.e. it has to be set before torch is imported.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")     # the process group's RCCL stream on a high-priority hardware queue: the gather runs UNDER the next forward (dist.py OverlappedGather)
     import torch
     import torch.distributed as dist
 
@@ -409,9 +451,14 @@ def run(args, ctx, primary):
     curr = torch.from_numpy(np.tile(curr_h, (reps, 1, 1))[:B]).to(dev)
     prior = torch.from_numpy(np.tile(prior_h, (reps, 1))[:B]).to(dev)
     d_prior = prior.data_ptr() if args.variant != "full" else None
-    out = torch.zeros(B, 72, device=dev)            # [mean8 | cov64] per pair
-    mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
-    gathered = torch.zeros(world * B, 72, device=dev) if collective else None
+    # [mean8 | cov64] per pair: written directly by the ensemble kernel (hnet_infer_batch_packed_device); with a collective, two such buffers and the
+    # all-gather of step i on a side stream under the forward of step i + 1 (cuahn_vio_amd.dist.OverlappedGather)
+    # (small steps are grouped: one collective per >= 128 pairs - at 32 pairs per GPU a step is 0.35 ms and the host-side cost of a Python collective call
+    # per step, ~40 us, is visible; a C++ caller's ncclAllGather costs a few us and needs no grouping)
+    og = hdist.OverlappedGather(B, dev, group_steps=max(1, 128 // B)) if collective and args.mode != "mc" else None
+    out = torch.zeros(B, 72, device=dev)
+    out_of_step = (lambda i: og.buffer(i)) if og is not None else (lambda i: out)
+    mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)       # (--mode mc: the un-packed finish entry point)
 
     mc_mode = args.mode == "mc"
     shard = hdist.shard_range(n_mc, world, rank) if mc_mode else None
@@ -495,13 +542,16 @@ def run(args, ctx, primary):
             elif early and skip != "copy":
                 upload(i + 1)
             comp_stream.wait_event(ev_ready[k])
+            if og is not None:
+                og.acquire(i, comp_stream)
             if skip != "compute":
-                eng.infer_batch_device(dbuf[k][0].data_ptr(), dbuf[k][1].data_ptr(), PIX_U8, dbuf[k][2].data_ptr() if args.variant != "full" else None,
-                                       B, seq0_of_step(i), mean.data_ptr(), cov.data_ptr(), None, comp_stream)
+                eng.infer_batch_packed_device(dbuf[k][0].data_ptr(), dbuf[k][1].data_ptr(), PIX_U8, dbuf[k][2].data_ptr() if args.variant != "full" else None,
+                                              B, seq0_of_step(i), out_of_step(i).data_ptr(), None, comp_stream)
             ev_free[k].record(comp_stream)
+            if og is not None:                                              # BASELINE config 5: the streamed step gathers too, on the side stream
+                og.submit(i, comp_stream)
             with torch.cuda.stream(comp_stream):
-                hdist.pack_outputs(mean, cov, out)
-                host_out[k].copy_(out, non_blocking=True)
+                host_out[k].copy_(out_of_step(i), non_blocking=True)
             # the next step's pairs cross PCIe while this step computes (enqueued AFTER the forward: the runtime may hold the
             # calling thread until an H2D copy has been handed to the DMA engine, which must not delay the kernel launches)
             if use_thread:
@@ -518,10 +568,11 @@ def run(args, ctx, primary):
                 ms_all, lv_all = ms_loc, lv_loc
             eng.mc_finish_device(ms_all.data_ptr(), lv_all.data_ptr(), n_mc, h1.data_ptr(), B, mean.data_ptr(), cov.data_ptr(), sp)
             return
-        eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i),
-                               mean.data_ptr(), cov.data_ptr(), None, sp)
-        if collective:
-            hdist.gather_outputs(mean, cov, out, gathered)
+        if og is not None:
+            og.acquire(i, stream)
+        eng.infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None, sp)
+        if og is not None:
+            og.submit(i, stream)
 
     def sync():
         if stream_mode and use_thread:
@@ -595,8 +646,17 @@ def run(args, ctx, primary):
     if not args.no_verify:
         slots = sorted({0, 1, B // 2, B - 1} & set(range(B)))
         s0 = seq0_of_step(last)
-        n_v, err_px, err_cov = verify_last_step(blob, prev_h, curr_h, prior_h, args.variant, n_mc, lambda b: s0 + b,
-                                                mean.cpu().numpy(), cov.cpu().numpy(), slots)
+        if mc_mode:
+            mean_np, cov_np = mean.cpu().numpy(), cov.cpu().numpy()
+        else:
+            fin = out_of_step(last)                                       # the packed [B, 72] record of the last executed step
+            mean_np, cov_np = fin[:, :8].cpu().numpy(), fin[:, 8:].cpu().numpy()
+            if og is not None:                                            # ... and what the side-stream gather delivered for it: this rank's rows, bit for bit
+                og.submit(last, stream, flush=True)                      # (a partly filled group of small steps)
+                g = og.result(last)
+                if not torch.equal(g[rank], fin):
+                    raise SystemExit("bench.py: the gathered outputs differ from the local ones")
+        n_v, err_px, err_cov = verify_last_step(blob, prev_h, curr_h, prior_h, args.variant, n_mc, lambda b: s0 + b, mean_np, cov_np, slots)
         gated = args.precision != "bf16"        # plain bf16 is a reported mode: its error is printed, not gated
         gate_px = TOL_PX if args.precision == "f16x2" else TOL_PX_REFERENCE_MODES
         ok = (err_px < gate_px and err_cov < 1e-4) or not gated

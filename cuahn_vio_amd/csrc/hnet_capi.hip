@@ -325,6 +325,7 @@ struct FwdArgs {
     int pair0 = 0;            // first pair of this chunk inside the persistent buffers (caller arrays are pre-offset)
     bool use_ws = true;       // may use the context's split-K workspace (false for concurrent chunks)
     const uint64_t* seq_dev = nullptr;   // device addend to seq0 (graph replays)
+    int mean_stride = 8, cov_stride = 64;   // floats between consecutive pairs of `mean` / `cov` (72 / 72: the packed [B][72] record)
 };
 
 #define STAGE(call)                                                                                         \
@@ -464,10 +465,10 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     float* lv = c->logvar_s + P0 * c->n_local * 8;
     if (small && c->n_local <= HEADS_FC2_FINISH_MAX_N) {
         STAGE(launch_heads_fc2_finish(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, Hm, a.mean, a.cov, Htot, s,
-                                      a.seq_dev, c->d_flag));
+                                      a.seq_dev, c->d_flag, a.mean_stride, a.cov_stride));
     } else {
         STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s, a.seq_dev));
-        STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag));
+        STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag, a.mean_stride, a.cov_stride));
     }
     if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
         STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, Htot, a.err, a.err_u8, B, s));
@@ -1253,6 +1254,17 @@ int hnet_infer_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr,
     return forward(c, a, stream ? (hipStream_t)stream : c->stream);
 }
 
+int hnet_infer_batch_packed_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                                   uint64_t pair_seq0, float* d_out72, float* d_err_map, void* stream) {
+    if (!c || !d_prev || !d_curr || !d_out72) return HNET_ERR_INVALID_ARG;
+    if (pix_fmt != HNET_PIX_U8 && pix_fmt != HNET_PIX_F32) return fail(c, HNET_ERR_INVALID_ARG, "pix_fmt");
+    if (d_err_map && !c->cfg.emit_error_map) return fail(c, HNET_ERR_INVALID_ARG, "context was created without emit_error_map");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    FwdArgs a = {d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_out72, d_out72 + 8, d_err_map, nullptr, nullptr, nullptr, nullptr, false};
+    a.mean_stride = a.cov_stride = HNET_PACKED_FLOATS;
+    return forward(c, a, stream ? (hipStream_t)stream : c->stream);
+}
+
 int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fmt, const float* prior, int batch,
                      uint64_t pair_seq0, float* mean, float* cov, float* err_map) {
     if (!c || !prev || !curr || !mean || !cov) return HNET_ERR_INVALID_ARG;
@@ -1305,6 +1317,15 @@ int hnet_mc_finish_device(hnet_ctx* c, const float* d_mean_s, const float* d_log
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, launch_mc_finish(d_mean_s, d_logvar_s, n_total, d_h_part1, batch, d_mean, d_cov, nullptr,
                                stream ? (hipStream_t)stream : c->stream, c->d_flag));
+    return HNET_OK;
+}
+
+int hnet_mc_finish_packed_device(hnet_ctx* c, const float* d_mean_s, const float* d_logvar_s, int n_total, const float* d_h_part1,
+                                 int batch, float* d_out72, void* stream) {
+    if (!c || !d_mean_s || !d_logvar_s || !d_h_part1 || !d_out72 || n_total < 1 || batch < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, launch_mc_finish(d_mean_s, d_logvar_s, n_total, d_h_part1, batch, d_out72, d_out72 + 8, nullptr,
+                               stream ? (hipStream_t)stream : c->stream, c->d_flag, HNET_PACKED_FLOATS, HNET_PACKED_FLOATS));
     return HNET_OK;
 }
 

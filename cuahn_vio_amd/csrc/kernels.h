@@ -123,13 +123,14 @@ hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_b
 
 // ensemble/transfer from gathered per-sample outputs [B][n][8]
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
-                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag = nullptr);
+                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag = nullptr,
+                            int mean_stride = 8, int cov_stride = 64 /* floats between consecutive pairs: 72 / 72 with cov = mean + 8 for the packed [B][72] record */);
 
 // latency path (n_local <= 64): both launches above in one, one 1024-thread workgroup per pair; bit-identical results
 constexpr int HEADS_FC2_FINISH_MAX_N = 64;
 hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed, uint64_t pair_seq0, const float* w2,
                                    const float* b2, const float* H1, float* mean, float* cov, float* Htot, hipStream_t s,
-                                   const uint64_t* seq_dev = nullptr, uint32_t* flag = nullptr);
+                                   const uint64_t* seq_dev = nullptr, uint32_t* flag = nullptr, int mean_stride = 8, int cov_stride = 64);
 
 // layout helpers for the operator-level entry points
 hipError_t launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int h, int w, hipStream_t s);

@@ -949,11 +949,13 @@ __device__ __forceinline__ void mc_finish_wave(const float* ms, const float* lv,
     }
     if (flag && bad) atomicOr(flag, 1u);           // hnet_overflow_flag: a non-finite output of this pair
 }
+// out_stride: floats between the records of consecutive pairs in `mean` and in `cov` (8 / 64 for separate arrays; 72 / 72 for the packed
+// [B][72] record mean | cov that a multi-GPU caller all-gathers: cov = mean + 8)
 __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
                                                        const float* __restrict__ H1, int batch, float* __restrict__ mean,
-                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag) {
+                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag, int mean_stride, int cov_stride) {
     const int b = blockIdx.x;
-    mc_finish_wave(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + b * 8, cov + b * 64,
+    mc_finish_wave(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride,
                    Htot ? Htot + b * 9 : nullptr, flag, threadIdx.x);
 }
 
@@ -965,7 +967,7 @@ __global__ __launch_bounds__(1024) void heads_fc2_finish_kernel(const float* __r
                                                                 uint64_t mc_seed, uint64_t pair_seq0, const uint64_t* __restrict__ seq_dev,
                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                                 const float* __restrict__ H1, float* __restrict__ mean, float* __restrict__ cov,
-                                                                float* __restrict__ Htot, uint32_t* __restrict__ flag) {
+                                                                float* __restrict__ Htot, uint32_t* __restrict__ flag, int mean_stride, int cov_stride) {
     __shared__ float w2s[4096];
     __shared__ float hid[4][FC2_CHUNK * 512];
     __shared__ uint32_t pre_row[4][FC2_CHUNK * 2];
@@ -980,20 +982,20 @@ __global__ __launch_bounds__(1024) void heads_fc2_finish_kernel(const float* __r
                         pre_row[grp], ms_l, lv_l, nullptr);
     }
     __syncthreads();
-    if (tid < 64) mc_finish_wave(ms_l, lv_l, n_local, H1 + b * 9, mean + b * 8, cov + b * 64, Htot ? Htot + b * 9 : nullptr, flag, tid);
+    if (tid < 64) mc_finish_wave(ms_l, lv_l, n_local, H1 + b * 9, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride, Htot ? Htot + b * 9 : nullptr, flag, tid);
 }
 hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed, uint64_t pair_seq0, const float* w2,
                                    const float* b2, const float* H1, float* mean, float* cov, float* Htot, hipStream_t s, const uint64_t* seq_dev,
-                                   uint32_t* flag) {
+                                   uint32_t* flag, int mean_stride, int cov_stride) {
     if (n_local < 1 || n_local > FC2M_MAX_N) return hipErrorInvalidValue;
     hipLaunchKernelGGL(heads_fc2_finish_kernel, dim3((unsigned)batch), dim3(1024), 0, s, hidden, n_local, s_begin, hnet_drop_threshold(p), 1.0f / (1.0f - p),
-                       mc_seed, pair_seq0, seq_dev, w2, b2, H1, mean, cov, Htot, flag);
+                       mc_seed, pair_seq0, seq_dev, w2, b2, H1, mean, cov, Htot, flag, mean_stride, cov_stride);
     return hipGetLastError();
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
-                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag) {
-    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot, flag);
+                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag, int mean_stride, int cov_stride) {
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot, flag, mean_stride, cov_stride);
     return hipGetLastError();
 }
 

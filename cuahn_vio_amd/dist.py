@@ -59,3 +59,65 @@ def gather_mc_samples(mean_s, logvar_s, h_part1, group=None):
     _all_gather(g, both, group)
     g = g.permute(1, 2, 0, 3, 4).reshape(2, b, world * n_local, 8)        # rank-major = global sample order
     return g[0].contiguous(), g[1].contiguous(), h_part1
+
+
+class OverlappedGather:
+    """The gather of the packed [B, 72] outputs OFF the compute stream: two packed output slabs and two gathered slabs; step i
+    writes its outputs into its slab (hnet_infer_batch_packed_device: no packing copies), then `submit(i)` hands a full slab to a side stream, which
+    waits for the forward's completion event and runs all_gather_into_tensor there - under the forward of the next step.  `acquire(i)` makes the compute
+    stream wait for the gather that last read the slab step i writes into; `result(i)` waits for step i's gather and returns its [world, B, 72] rows.
+    group_steps = G > 1: "fewer, larger collectives" - a slab holds the outputs of G consecutive steps and is gathered once, after its last step (the
+    message is G x B x 288 bytes; at 32 pairs per GPU a step is 0.35 ms and the Python-side cost of one collective call per step, ~40 us, shows: bench.py
+    groups small steps).  With CPU tensors (gloo tests) everything is synchronous: same order of operations, same results.
+    The timed region of bench.py still ends with barrier + synchronize, which covers the side stream."""
+
+    def __init__(self, batch, device, group=None, group_steps=1):
+        self.group, self.world, self.B, self.G = group, dist.get_world_size(group), batch, max(1, int(group_steps))
+        self.cuda = torch.device(device).type == "cuda"
+        self.out = [torch.zeros(self.G * batch, 72, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(self.world * self.G * batch, 72, device=device) for _ in range(2)]
+        self.pending = [False, False]
+        if self.cuda:
+            # its own priority level: the HIP runtime multiplexes the streams of ONE priority over its hardware queues, and a side stream that lands on the
+            # compute stream's queue serialises the gather between two forwards instead of running it under the next one (bench.py, stream mode, saw
+            # the same with its copy stream); queues of different priority are never shared.  (The process group's internal RCCL stream: TORCH_NCCL_HIGH_PRIORITY=1)
+            self.side = torch.cuda.Stream(device, priority=-1)
+            self.ev_done = [torch.cuda.Event() for _ in range(2)]        # the forwards of the slab's steps have finished (recorded on the compute stream)
+            self.ev_gathered = [torch.cuda.Event() for _ in range(2)]    # its gather has finished (recorded on the side stream)
+
+    def _slab(self, i):
+        return (i // self.G) % 2
+
+    def buffer(self, i):
+        j = i % self.G
+        return self.out[self._slab(i)][j * self.B:(j + 1) * self.B]
+
+    def acquire(self, i, compute_stream=None):
+        """before the forward of step i writes its part of a slab"""
+        k = self._slab(i)
+        if self.cuda and self.pending[k] and i % self.G == 0:
+            (compute_stream or torch.cuda.current_stream()).wait_event(self.ev_gathered[k])
+
+    def submit(self, i, compute_stream=None, flush=False):
+        """after the forward of step i has been enqueued on the compute stream; flush = gather a partly filled slab (end of a run)"""
+        if i % self.G != self.G - 1 and not flush:
+            return
+        k = self._slab(i)
+        if not self.cuda:
+            _all_gather(self.gathered[k], self.out[k], self.group)
+            self.pending[k] = True
+            return
+        cs = compute_stream or torch.cuda.current_stream()
+        self.ev_done[k].record(cs)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_done[k])
+            _all_gather(self.gathered[k], self.out[k], self.group)
+            self.ev_gathered[k].record(self.side)
+        self.pending[k] = True
+
+    def result(self, i):
+        """[world, B, 72]: step i's records of every rank (after the slab of step i has been submitted)"""
+        k, j = self._slab(i), i % self.G
+        if self.cuda and self.pending[k]:
+            self.ev_gathered[k].synchronize()
+        return self.gathered[k].view(self.world, self.G, self.B, 72)[:, j]

@@ -117,6 +117,13 @@ class HnetEngine:
         check(self._h, self._L.hnet_infer_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,
                                                        d_err, self._stream(stream)))
 
+    def infer_batch_packed_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_out72, d_err=None, stream=None):
+        """the same forward with the packed [batch, 72] record (mean | cov) as output: the message of the multi-GPU gather, written by the ensemble kernel"""
+        check(self._h, self._L.hnet_infer_batch_packed_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_out72, d_err, self._stream(stream)))
+
+    def mc_finish_packed_device(self, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_out72, stream=None):
+        check(self._h, self._L.hnet_mc_finish_packed_device(self._h, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_out72, self._stream(stream)))
+
     def infer_mc_partial_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s, d_logvar_s, d_h1, stream=None):
         check(self._h, self._L.hnet_infer_mc_partial_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s,
                                                             d_logvar_s, d_h1, self._stream(stream)))

@@ -200,6 +200,13 @@ int hnet_infer_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_cur
                             const float* d_prior, int batch, uint64_t pair_seq0,
                             float* d_mean, float* d_cov, float* d_err_map, void* stream);
 
+/* The same forward with PACKED outputs: d_out72 [batch][72] fp32, record of pair b = mean (8 corner offsets) followed by the row-major 8 x 8 covariance
+ * (64).  This is the message a multi-GPU caller exchanges (one ncclAllGather / all_gather_into_tensor of batch x 288 bytes per rank:
+ * tests/cpp/rccl_gather_example.cpp, cuahn_vio_amd/dist.py); written directly by the ensemble kernel, no packing copies.  Bit-identical values. */
+#define HNET_PACKED_FLOATS 72
+int hnet_infer_batch_packed_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                                   uint64_t pair_seq0, float* d_out72, float* d_err_map, void* stream);
+
 /* MC-dropout sharding: the trunk runs on every rank, the heads only for this context's
  * global samples [mc_sample_begin, mc_sample_end).  Outputs per pair: mean_s / logvar_s
  * [B][n_local][8] and H_part1 [B][9].  After gathering all N samples (rank order = sample order) the
@@ -210,6 +217,9 @@ int hnet_infer_mc_partial_device(hnet_ctx* ctx, const void* d_prev, const void* 
                                  float* d_mean_s, float* d_logvar_s, float* d_h_part1, void* stream);
 int hnet_mc_finish_device(hnet_ctx* ctx, const float* d_mean_s, const float* d_logvar_s, int n_total,
                           const float* d_h_part1, int batch, float* d_mean, float* d_cov, void* stream);
+/* ... with the packed [batch][72] record of hnet_infer_batch_packed_device as output */
+int hnet_mc_finish_packed_device(hnet_ctx* ctx, const float* d_mean_s, const float* d_logvar_s, int n_total, const float* d_h_part1,
+                                 int batch, float* d_out72, void* stream);
 
 int hnet_synchronize(hnet_ctx* ctx, void* stream);
 int hnet_last_timing(const hnet_ctx* ctx, hnet_timing* out);

@@ -3,8 +3,8 @@
 // (HomographyNet.cpp:10-16).  What a C++ integrator adds around the C ABI of include/hnet.h:
 //
 //   one hnet context per GPU (weights replicated, 26 MB) -> the pairs of a batch split contiguously over the GPUs -> every GPU runs
-//   hnet_infer_batch_device on its shard, on its own stream -> the [nb, 8] means and [nb, 64] covariances are packed to [nb, 72] with two
-//   strided device copies -> ONE ncclAllGather of nb x 288 bytes per GPU (latency bound; xGMI bandwidth is irrelevant) -> every GPU
+//   hnet_infer_batch_packed_device on its shard, on its own stream: the ensemble kernel writes the packed [nb, 72] records (mean | cov) itself
+//   (round 4; rounds 2 - 3 packed with two strided device copies) -> ONE ncclAllGather of nb x 288 bytes per GPU (latency bound; xGMI bandwidth is irrelevant) -> every GPU
 //   holds all pairs' outputs in pair order.
 //
 // One process drives all visible GPUs here (ncclCommInitAll + group calls); a one-process-per-GPU deployment replaces ncclCommInitAll
@@ -70,12 +70,11 @@ int main(int argc, char** argv) {
         HIP_OK(hipMemcpy(g[d].curr, hc.data(), nb * npix, hipMemcpyHostToDevice));
     }
 
-    // one step: forward of every shard, pack, all-gather - everything of a GPU on its one stream
+    // one step: forward of every shard into its packed record buffer, all-gather - everything of a GPU on its one stream.  (A streaming caller
+    // double-buffers `out` and issues the gather on a second stream behind an event, under the next step's forward: cuahn_vio_amd/dist.py OverlappedGather.)
     for (int d = 0; d < ndev; d++) {
         HIP_OK(hipSetDevice(d));
-        HNET_CHECK(hnet_infer_batch_device(g[d].ctx, g[d].prev, g[d].curr, HNET_PIX_U8, nullptr, nb, (uint64_t)d * nb, g[d].mean, g[d].cov, nullptr, g[d].s));
-        HIP_OK(hipMemcpy2DAsync(g[d].out, 72 * 4, g[d].mean, 8 * 4, 8 * 4, nb, hipMemcpyDeviceToDevice, g[d].s));
-        HIP_OK(hipMemcpy2DAsync(g[d].out + 8, 72 * 4, g[d].cov, 64 * 4, 64 * 4, nb, hipMemcpyDeviceToDevice, g[d].s));
+        HNET_CHECK(hnet_infer_batch_packed_device(g[d].ctx, g[d].prev, g[d].curr, HNET_PIX_U8, nullptr, nb, (uint64_t)d * nb, g[d].out, nullptr, g[d].s));
     }
     NCCL_OK(ncclGroupStart());
     for (int d = 0; d < ndev; d++) NCCL_OK(ncclAllGather(g[d].out, g[d].all, (size_t)nb * 72, ncclFloat, comm[d], g[d].s));

@@ -37,3 +37,30 @@ def test_bench_refuses_a_mismatched_world():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_config_4_preset_at_world_2():
+    """BASELINE config 4 (`--config 4` = --mode mc --mc 32 --batch 1): two ranks, the 32 MC-dropout samples split 16 / 16, one gather of the per-sample
+    head outputs in global sample order (cuahn_vio_amd.dist.gather_mc_samples, executed here on gloo with CPU tensors)"""
+    r = _run("--gpus", "2", "--config", "4", "--dry-run")
+    z = r["resolved"]
+    assert r["n_gpus"] == 2 and r["gather_checked"] is True
+    assert z["mode"] == "mc" and z["mc"] == 32 and z["mc_per_gpu"] == 16 and z["batch_per_gpu"] == 1 and z["gathers"] is True
+
+
+def test_config_5_preset_at_world_2():
+    """BASELINE config 5 (`--config 5` = --pairs-total 256 --mode stream --replay indoor_forward_7 --variant prior3 --mc 16): two ranks, 128 streamed pairs
+    each, and the streamed step GATHERS (VERDICT r3 missing #1): three steps through the double-buffered gather of the packed [B, 72] outputs
+    (cuahn_vio_amd.dist.OverlappedGather; gloo, CPU tensors), every step's result in rank order"""
+    r = _run("--gpus", "2", "--config", "5", "--dry-run")
+    z = r["resolved"]
+    assert r["n_gpus"] == 2 and r["gather_checked"] is True
+    assert z["mode"] == "stream" and z["pairs_total"] == 256 and z["batch_per_gpu"] == 128 and z["replay"] == "indoor_forward_7"
+    assert z["variant"] == "prior3" and z["mc"] == 16 and z["gathers"] is True
+
+
+def test_config_4_refuses_an_indivisible_sample_count():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--config", "4", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0

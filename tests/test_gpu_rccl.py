@@ -43,10 +43,12 @@ def test_gathers_run_through_rccl_on_a_one_rank_communicator(tmp_path):
             f.write("tests/rccl_worker.py: " + json.dumps(res) + "\n")
 
 
-@pytest.mark.parametrize("extra", [[], ["--pairs-total", "64", "--variant", "prior3", "--mc", "16"]])
+@pytest.mark.parametrize("extra", [[], ["--pairs-total", "64", "--variant", "prior3", "--mc", "16"], ["--config", "5", "--steps", "8"], ["--config", "4"]])
 def test_bench_runs_its_collective_through_rccl_with_one_rank(extra):
-    """bench.py --gpus 1 --force-collective: a 1-rank RCCL communicator, the per-step all-gather of [B, 72] inside the timed region, the
-    barrier and the max-over-ranks all-reduce; the oracle check of the last step still gates the run"""
+    """bench.py --gpus 1 --force-collective: a 1-rank RCCL communicator, the per-step all-gather of the packed [B, 72] outputs on a SIDE stream under the
+    next step's forward (round 4: cuahn_vio_amd.dist.OverlappedGather; bench.py itself asserts gathered == local bit for bit on the last step), the
+    barrier and the max-over-ranks all-reduce; the oracle check of the last step still gates the run.  Also BASELINE's presets: --config 5 (streamed
+    UZH-FPV replay, 256 pairs, the streamed step gathers) and --config 4 (MC samples over the ranks)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "5", "--warmup", "2",
            "--no-cpu-baseline", "--no-latency", "--no-extras"] + extra
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
@@ -54,8 +56,10 @@ def test_bench_runs_its_collective_through_rccl_with_one_rank(extra):
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert res["backend"] == "nccl (RCCL)" and res["rccl_ranks"] == 1 and res["n_gpus"] == 1
     assert res["verify"]["passed"] and res["value"] > 0
-    if extra:
+    if extra and extra[0] == "--pairs-total":
         assert res["config"]["batch_per_gpu"] == 64 and res["scaling"] == "strong"
+    if extra and extra[:2] == ["--config", "5"]:
+        assert res["config"]["batch_per_gpu"] == 256 and "STREAMED" in res["config"]["workload"]
     log = os.environ.get("HNET_RCCL_LOG")
     if log:
         with open(log, "a") as f:

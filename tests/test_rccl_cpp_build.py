@@ -23,4 +23,4 @@ def test_rccl_gather_example_compiles_and_links():
     exe = build()
     out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
     used = {l.split()[-1].split("@")[0] for l in out.splitlines()}
-    assert {"ncclAllGather", "ncclCommInitAll", "ncclGroupStart", "hnet_infer_batch_device", "hnet_create"} <= used
+    assert {"ncclAllGather", "ncclCommInitAll", "ncclGroupStart", "hnet_infer_batch_packed_device", "hnet_create"} <= used
