@@ -87,6 +87,7 @@ struct hnet_ctx {
     // split-bf16 mode (HNET_PREC_BF16X3): activations of the layers feeding a conv are three bf16 planes
     bool s3 = false;
     uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
+    uint16_t* conv_wfrag[20] = {};     // fp16-plane mode, igemm_region.h layers (block_1_2, block_1_3, block_2_4 / 3_5 / 4_6): the weights as MFMA fragments in consumption order
     uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
     bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
     int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (hnet_op_block4_fused `reverse`, tests)
@@ -109,7 +110,6 @@ struct hnet_ctx {
     const float* H_last = nullptr;     // where the last forward left H_part1 (Hm or Hm2)
     bool warp_exact = false;           // HNET_WARP_EXACT=1: the prep kernels keep grid_sample's sampling positions bit for bit (kernels.hip, A/B switch); default: the fast sampler
     bool use_patch32 = true;           // block_3_2 / block_4_3 through conv_patch32_s2_kernel (HNET_PATCH32=0: implicit GEMM)
-    uint16_t* zero_page = nullptr;     // 256 bytes of zeros (padding source of the LDS-DMA kernel)
     uint16_t* b30_frag = nullptr;      // block_3_0 weights as 32x32x16 fragments of the pixel-pair GEMM [7][3][64] x 16 B (conv_first.h)
     bool b30_s3 = true;
     uint16_t* s2_frag[4] = {};         // block_1_1 / block_2_1 (layers 0, 3) weights as 16x16x32 A-fragments [Cout/16][4][3][64] x 16 B (conv7_c2_s2_s3_kernel)
@@ -428,7 +428,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128, c->patch_rb5));
             else if (c->s3 && conv_is_s3_layer(l))
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
-                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->zero_page, c->n_planes, c->s3_tile));
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->conv_wfrag[l], c->n_planes, c->s3_tile));
             else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
@@ -521,7 +521,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
     } while (0)
     {
         auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-        for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); }
+        for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); fr(c->conv_wfrag[l]); }
         for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
         fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3);
         fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
@@ -721,6 +721,28 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                 CK(hipMalloc((void**)&c->conv_w16[l], pl.size() * 2));
                 CK(hipMemcpy(c->conv_w16[l], pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
             }
+            if (c->n_planes == 2 && conv_region_layer(l)) {
+                // igemm_region.h: the two weight planes as MFMA fragments in the order the kernel consumes them:
+                // [Cout / 16][Cin / 64 chunks][taps, padded][2 steps][2 planes][64 lanes][8 halves]; lane (r = lane & 15, g = lane >> 4) holds
+                // output channel 16 nt + r, input channels 64 c + 32 st + 8 g .. + 7 of tap t (taps >= KS x KS: the zero-weight padding tap of the K-split form)
+                const int ntap = d.ks * d.ks, ntap_pad = conv_region_taps_padded(l), nchunk = d.cin / 64;
+                std::vector<uint16_t> fr((size_t)(d.cout / 16) * nchunk * ntap_pad * 2 * 2 * 64 * 8, 0);
+                for (int nt = 0; nt < d.cout / 16; nt++)
+                    for (int cc = 0; cc < nchunk; cc++)
+                        for (int t = 0; t < ntap; t++)
+                            for (int st = 0; st < 2; st++)
+                                for (int ln = 0; ln < 64; ln++)
+                                    for (int e = 0; e < 8; e++) {
+                                        const int n = nt * 16 + (ln & 15), ci = 64 * cc + 32 * st + 8 * (ln >> 4) + e;
+                                        uint16_t sp[3];
+                                        wsplit_gemm(w->data[(((size_t)n * d.cin + ci) * d.ks + t / d.ks) * d.ks + t % d.ks], 2, sp[0], sp[1], sp[2]);
+                                        const size_t base = ((((size_t)(nt * nchunk + cc) * ntap_pad + t) * 2 + st) * 2) * 64 * 8;
+                                        fr[base + (size_t)ln * 8 + e] = sp[0];
+                                        fr[base + 64 * 8 + (size_t)ln * 8 + e] = sp[1];
+                                    }
+                CK(hipMalloc((void**)&c->conv_wfrag[l], fr.size() * 2));
+                CK(hipMemcpy(c->conv_wfrag[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+            }
         }
         CK(upload(&c->conv_b[l], std::vector<float>(bi->data, bi->data + d.cout)));
     }
@@ -873,8 +895,6 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipMalloc((void**)&c->x16_b4, 3 * c->x16_plane * 4));
         CK(hipMemset(c->x16_b4, 0, 3 * c->x16_plane * 4));
     }
-    CK(hipMalloc((void**)&c->zero_page, 256));
-    CK(hipMemset(c->zero_page, 0, 256));
     c->ws_floats = (size_t)16 << 20;
     CK(dalloc(&c->ws, c->ws_floats));
     CK(dalloc(&c->hidden, MB * c->n_local * 512));
@@ -965,7 +985,7 @@ void hnet_destroy(hnet_ctx* c) {
     (void)hipSetDevice(c->cfg.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
-    for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->act16[l]); }
+    for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->act[l]); fr(c->conv_w16[l]); fr(c->conv_wfrag[l]); fr(c->act16[l]); }
     for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
     for (int k = 0; k < 4; k++) fr(c->x_in[k]);
     for (int i = 0; i < 2; i++) if (c->g_infer[i]) (void)hipGraphExecDestroy(c->g_infer[i]);
@@ -977,7 +997,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->zero_page); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
+    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1482,7 +1502,7 @@ int hnet_op_conv(hnet_ctx* c, int layer, const float* in, int batch, int h, int 
         } else if (conv_is_s3_layer(layer)) {
             HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, d.cin, h, w, c->stream, c->n_planes));
             HIPCHK(c, launch_conv_s3(layer, p_in, n_in, batch, h, w, c->conv_w16[layer], (size_t)d.cout * conv_padded_k(layer),
-                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->zero_page, c->n_planes, c->s3_tile));
+                                     c->conv_b[layer], p_out, n_out, nullptr, c->stream, nullptr, 0, c->conv_wfrag[layer], c->n_planes, c->s3_tile));
         } else {
             HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, d.cin, h, w, c->stream));
             if (conv_is_first_s2(layer) && c->first_s2 && c->s2_frag[layer] && h == (layer == 0 ? 28 : 56) && w == (layer == 0 ? 40 : 80))

@@ -57,7 +57,7 @@ struct S3Params {
     // heads only (HeadLoaderS3): keep-mask bits [B][n_local][2 heads][640 bytes], bit i of byte j = element 8j+i (NHWC k)
     const uint8_t* mask;
     int n_local;
-    const uint16_t* zeros; // >= 16 bytes of zeros in global memory: source of padding / out-of-range chunks for the LDS-DMA kernel
+    const uint16_t* wfrag; // igemm_region.h layers: the weights as MFMA fragments in consumption order (nullptr: not packed)
     int xcd_remap;         // 1: XCD-aware workgroup -> tile mapping (s3_tile_origin)
     int tile;              // tile-shape experiment of the context (HNET_S3_TILE at hnet_create; 0 = the measured defaults of s3_dispatch.h)
 #ifdef HNET_S3_TRACE

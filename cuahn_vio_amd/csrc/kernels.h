@@ -28,9 +28,12 @@ hipError_t launch_conv(int layer, const float* in, int batch, int h, int w, cons
 // split-bf16 (S3) convolution of the layers with Cin >= 8: in / out16 are [3][B][H][W][C] bf16 planes
 // (plane stride in elements), wplanes [3][Cout][Kp]; out32 != nullptr selects an fp32 [B][Ho][Wo][Cout] output
 bool conv_is_s3_layer(int layer);
+// wfrag (fp16-plane mode, conv_region_layer(layer)): the weights as MFMA fragments in the order igemm_region.h consumes them (packed by hnet_create), or nullptr
+bool conv_region_layer(int layer);            // block_1_2, block_1_3, block_2_4 / 3_5 / 4_6: input region resident in LDS, weights straight to registers
+int conv_region_taps_padded(int layer);       // taps per 64-channel chunk in the packed fragments (the K-split form pads its second half with a zero tap)
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* zeros = nullptr, int n_planes = 3, int tile = 0);
+                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* wfrag = nullptr, int n_planes = 3, int tile = 0);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 bool conv_is_patch32_layer(int layer);    // block_3_2 / block_4_3 at their network size 56x80 (conv_patch32_s2_kernel); same launcher, wfrag [4][9][3][64] x 16 B
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,

@@ -123,6 +123,8 @@ HNET_S3_DISPATCH_INSTANCES(extern, 1)
 HNET_S3_DISPATCH_INSTANCES(extern, 2)
 
 bool conv_is_s3_layer(int layer) { return kConvs[layer].cin >= 8; }
+bool conv_region_layer(int layer) { return layer == 1 || layer == 2 || layer == 6 || layer == 12 || layer == 19; }
+int conv_region_taps_padded(int layer) { return layer == 1 ? 25 : 10; }      // RegionCfg::NTAP_PAD: block_1_2 all 25 taps per wave; the 3 x 3 layers 5 + 5 (K-split)
 bool conv_is_patch_layer(int layer) { return layer == 8 || layer == 15; }   // block_3_1 (5x5), block_4_2 (3x3)
 bool conv_is_patch32_layer(int layer) { return layer == 9 || layer == 16; }   // block_3_2, block_4_3 (3x3, 32 -> 64)
 
@@ -174,8 +176,8 @@ hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_
 
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws, size_t wsn, const uint16_t* zeros, int n_planes, int tile) {
-    return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, zeros, tile);
+                          float* ws, size_t wsn, const uint16_t* wfrag, int n_planes, int tile) {
+    return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, wfrag, tile);
 }
 
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes) {

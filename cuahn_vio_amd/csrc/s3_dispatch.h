@@ -6,6 +6,7 @@
 #include "conv_first.h"
 #include "igemm_s3.h"
 #include "igemm_pipe.h"
+#include "igemm_region.h"
 #include "conv_b4_fused.h"
 #include "conv_b3_fused.h"
 #include "conv_b42_fused.h"
@@ -103,9 +104,39 @@ static bool pipe_ok(const S3Params& p) {
     return false;
 }
 
+// igemm_region.h: the input region of the tile's pairs resident in LDS, the weights straight into registers (layers bound by operand delivery).
+// p.wfrag carries the packed weight fragments (hnet_create; nullptr = not packed: the lean kernels)
+template <class C, bool OUT32>
+static hipError_t run_region(S3Params p, hipStream_t s) {
+    const int rows_tile = C::P * p.Ho * p.Wo;
+    dim3 grid((p.M + rows_tile - 1) / rows_tile, p.N / C::BN, 1);
+    p.k_split = 1;
+    p.Wp = p.wfrag;
+    hipLaunchKernelGGL((igemm_s3_region_kernel<C, OUT32>), grid, dim3(C::NT), C::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+typedef RegionCfg<128, 5, 1, 280, false> RegionCfg12;     // block_1_2: one pair (14 x 20 x 128 in, 7 x 10 out) x 128 channels per workgroup: 256 workgroups at batch 256
+typedef RegionCfg<128, 3, 4, 288, true> RegionCfg13;      // block_1_3: four pairs (7 x 10 x 128 in, 4 x 5 out) x 64 channels, K halves over the wave halves
+typedef RegionCfg<256, 3, 4, 288, true> RegionCfgT;       // block_2_4 / 3_5 / 4_6: the same with 256 input channels
+template <class C>
+static bool region_ok(const S3Params& p) {
+    // (variant 25: the lean kernels, A/B; 21: at any batch, tests)
+    return p.wfrag && p.tile != 20 && p.tile != 25 && (p.M >= 2048 || p.tile == 21) && 2 * C::P * (((p.Ho * p.Wo + 1) & ~1) + (((p.H >> 1) * p.Wo + 1) & ~1)) <= C::RP && C::P * p.Ho * p.Wo <= 80 &&
+           (p.M % (p.Ho * p.Wo)) == 0 && p.W == 2 * p.Wo && ((p.H + 1) >> 1) == p.Ho && p.N % C::BN == 0;
+}
+
 template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
 static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
+    if constexpr (NP == 2 && !OUT32 && CIN == 128 && KS == 5 && COUT == 128) {
+        if (region_ok<RegionCfg12>(p)) return run_region<RegionCfg12, OUT32>(p, s);
+    }
+    if constexpr (NP == 2 && KS == 3 && COUT == 256) {
+        if (p.Ho * p.Wo == 20) {                                  // the 4 x 5 layers
+            if constexpr (CIN == 128) { if (region_ok<RegionCfg13>(p)) return run_region<RegionCfg13, OUT32>(p, s); }
+            if constexpr (CIN == 256) { if (region_ok<RegionCfgT>(p)) return run_region<RegionCfgT, OUT32>(p, s); }
+        }
+    }
     if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
         if (pipe_ok<CIN, KS, COUT>(p)) return p.tile == 23 ? run_pipe<L, PipeCfg140, OUT32>(p, s) : run_pipe<L, PipeCfg144, OUT32>(p, s);
     }
@@ -298,13 +329,13 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
 template <int NP>
 hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                              size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                             float* ws, size_t wsn, const uint16_t* zeros, int tile) {
+                             float* ws, size_t wsn, const uint16_t* wfrag, int tile) {
     if (layer < 0 || layer >= 20 || !conv_is_s3_layer(layer)) return hipErrorInvalidValue;
     const ConvDesc& d = kConvs[layer];
     S3Params p = {};
     p.A = in; p.a_plane = in_plane; p.Wp = wplanes; p.w_plane = w_plane; p.bias = bias;
     p.out16 = out16; p.o_plane = o_plane; p.out32 = out32;
-    p.zeros = zeros;
+    p.wfrag = wfrag;       // igemm_region.h layers: the packed weight fragments (nullptr: the lean kernels)
     p.tile = tile;
     p.H = h; p.W = w;
     p.Ho = conv_out_dim(h, d.ks, d.stride);
@@ -340,6 +371,10 @@ hipError_t conv_kernels_init_device_np() {
         HNET_PIPE_ATTR(L1283, PipeCfg140, false); HNET_PIPE_ATTR(L645, PipeCfg140, false); HNET_PIPE_ATTR(L643, PipeCfg140, false);
         HNET_PIPE_ATTR(L1283, PipeCfg144, false); HNET_PIPE_ATTR(L645, PipeCfg144, false); HNET_PIPE_ATTR(L643, PipeCfg144, false);
 #undef HNET_PIPE_ATTR
+#define HNET_REGION_ATTR(C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_region_kernel<C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
+        HNET_REGION_ATTR(RegionCfg12, false);
+        HNET_REGION_ATTR(RegionCfg13, false); HNET_REGION_ATTR(RegionCfg13, true); HNET_REGION_ATTR(RegionCfgT, false); HNET_REGION_ATTR(RegionCfgT, true);
+#undef HNET_REGION_ATTR
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_heads_pipe_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadsPipeCfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);

@@ -64,3 +64,29 @@ def test_pipe_kernel_vs_oracle_and_lean_kernel(engines, state, layer, batch):
         err = np.abs(got[b] - ref).max()
         assert err < 2e-5 * max(1.0, np.abs(ref).max()), f"{name} pair {b}: {err}"
     assert np.array_equal(got, ref_k), f"{name}: pipelined kernel != lean kernel bitwise (max diff {np.abs(got - ref_k).max()})"
+
+
+REGION_LAYERS = [1, 2, 6, 12, 19]          # block_1_2 (one pair per tile), block_1_3 and block_2_4 / 3_5 / 4_6 (four pairs per tile, K split over the wave halves)
+
+
+@pytest.mark.parametrize("layer", REGION_LAYERS)
+@pytest.mark.parametrize("batch", [1, 3, 5, 8])
+def test_region_kernel_vs_oracle(engines, state, layer, batch):
+    """igemm_s3_region_kernel (csrc/igemm_region.h: the input region of the tile's pairs resident in LDS, weights straight to registers, 64-channel chunk
+    major K order) at the network geometry of every layer it serves, every element against the oracle's conv; against the lean kernel to fp32 rounding
+    (another summation order).  Batches 1, 3, 5: ragged last tile of the four-pair form."""
+    from oracle import pyoracle
+    pipe, lean = engines
+    name, cin, cout, k, s, h, w = _geometry(layer)
+    rng = np.random.default_rng(300 + 7 * layer + batch)
+    x = rng.standard_normal((batch, cin, h, w)).astype(np.float32)
+    prefix = "model_last_block_list.0." if name[6] == "4" else "model_part1."
+    wgt, bias = state[prefix + name + ".0.weight"], state[prefix + name + ".0.bias"]
+    got = pipe.op_conv(layer, x)
+    ref_k = lean.op_conv(layer, x)
+    for b in range(batch):
+        ref = pyoracle.conv_lrelu(x[b], wgt, bias, s)
+        err = np.abs(got[b] - ref).max()
+        assert err < 2e-5 * max(1.0, np.abs(ref).max()), f"{name} pair {b}: {err}"
+    assert np.abs(got - ref_k).max() < 2e-5 * max(1.0, np.abs(ref_k).max())
+    assert not np.array_equal(got, ref_k) or batch == 0, f"{name}: identical to the lean kernel bit for bit - did the region kernel run?"
