@@ -34,7 +34,18 @@
 #include "igemm_s3.h"
 #include "kernels.h"
 
+#ifndef HNET_B4_ABLATE
+#define HNET_B4_ABLATE 0          // tools/trace_b4.hip: 1 no phase 2, 2 no phase 1, 3 no global stores, 4 no phase-1 epilogue arithmetic, 5 no leftover M-tiles (wrong results)
+#endif
+
 namespace hnet {
+
+#ifdef HNET_B4_TRACE            // tools/trace_b4.hip: s_memtime stamps of workgroups 0 - 7, six per tile and wave: [wg][wave][tile][6]
+__device__ unsigned long long* g_b4_trace;
+#define B4_T(k) do { if (blockIdx.x < 8 && lane == 0 && tile_no < 32) g_b4_trace[((blockIdx.x * 4 + wave) * 32 + tile_no) * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define B4_T(k) do { } while (0)
+#endif
 
 template <int TH1_, int THREADS_, int NP_, bool DMA_ = false>
 struct B4Cfg {
@@ -44,7 +55,14 @@ struct B4Cfg {
     static constexpr int PH0 = RH + 6, PW0 = DMA_ ? 80 : 76;  // input patch: (RH + 6) x 76 px (67 + 7 taps + pad); 80 px = 20 chunks of 16 bytes per row for the LDS-DMA
     static constexpr int PROW0 = PW0 * 2;                    // bf16 elements per patch row (2 channels)
     static constexpr int PPLANE = PH0 * PROW0;               // elements per patch plane
-    static constexpr int XH = 34;                            // chunks per (row, parity) of the S3 image (ceil(67/2) = 34)
+    // chunks per (row, parity) of the S3 image: ceil(67 / 2) = 34; fp16-plane mode 40: an image row (2 XH chunks) is then 5 x 256 bytes, so that taps of one
+    // kernel column sit on the same banks and two lane groups can share a conflict-free ds_read_b128 (phase 2, b41_tap() in kernels.h)
+#ifdef HNET_B4_P2B128           // tools/trace_b4.hip: A/B of the two phase-2 read forms (timing only: the library packs the weights for the default)
+    static constexpr bool P2B128 = NP_ == 2 && HNET_B4_P2B128;
+#else
+    static constexpr bool P2B128 = NP_ == 2;
+#endif
+    static constexpr int XH = P2B128 ? 40 : 34;
     static constexpr int PLANE = RH * 2 * XH * 8;            // bf16 elements per plane of the S3 image
     static constexpr int N_MT0 = 2 * RH + (2 * RH + 15) / 16; // block_4_0 M-tiles: RH rows x 2 + the pairs of columns 64..66
     static constexpr int N_MT1 = 2 * TH1;                    // block_4_1 M-tiles: TH1 rows x 2 halves of 16 px
@@ -103,6 +121,18 @@ template <int IMM>
 __device__ __forceinline__ void wr64(uint32_t addr, uint2 v) {
     static_assert(IMM >= 0 && IMM < 65536, "ds offset is 16 bits");
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8 rd128i(uint32_t addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset is 16 bits");
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+// wait until at most N LDS operations are outstanding; the NP fragment registers named cannot be consumed above the statement
+template <int N>
+__device__ __forceinline__ void waitQ(bf16x8 (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
 }
 __device__ __forceinline__ u32x4 rd128(uint32_t addr) {
     u32x4 v;
@@ -206,15 +236,29 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const uint32_t p1t = lds0 + 2 * ((wrow + 6) * PROW0 + (16 * whalf + m) * 4 + 4 * g);
     // phase-1 store: pixel column 2m + dx of the half, channels co0..co0+3, region row wrow (+ HW*j as immediate)
     const uint32_t st1a = img0 + 2 * (((wrow * 2 + dx) * XH + 16 * whalf + m) * 8 + co0);
+    // phase 1, the leftover M-tile of waves 3, 2, 1 (k = 0, 1, 2): slot 16 k + m = region row (16 k + m) / 2 (clamped to the last), pixel pair 32 + (m & 1)
+    static_assert(N_MT0 - N_REG <= WAVES - 1, "one leftover M-tile per wave");
+    const bool has_left = wave >= 1 && N_REG + (WAVES - 1 - wave) < N_MT0;
+    const int rowL = min((16 * (WAVES - 1 - wave) + m) >> 1, RH - 1), pairL = 32 + (m & 1), colL = 2 * pairL + dx;
+    uint32_t pL[3];
+#pragma unroll
+    for (int st = 0; st < 3; st++) pL[st] = lds0 + 2 * ((rowL + 2 * st + (g >> 1)) * PROW0 + pairL * 4 + 8 * (g & 1));
+    const uint32_t pLt = lds0 + 2 * ((rowL + 6) * PROW0 + pairL * 4 + 4 * g);
+    const uint32_t stL = img0 + 2 * (((rowL * 2 + dx) * XH + pairL) * 8 + co0);
     // phase 2, M-tile j: output row wrow + HW*j, half whalf, column 16*whalf + m; tap t = 4*step + g; even groups read the
     // low 8 bytes of the chunk first, odd groups the high 8 bytes (bank-conflict free, see the header); p2b = the other half
     uint32_t p2a[7], p2b[7];
 #pragma unroll
     for (int st = 0; st < 7; st++) {
-        const int t = 4 * st + g;
+        int t = 4 * st + g;
+        if constexpr (C::P2B128) {                                    // the tap table of kernels.h; a group without a tap reads its neighbour's pixels (its weights are zeros)
+            const int tg = g == 0 ? b41_tap(st, 0) : g == 1 ? b41_tap(st, 1) : g == 2 ? b41_tap(st, 2) : b41_tap(st, 3);
+            const int tn = g == 1 ? b41_tap(st, 0) : b41_tap(st, 2);
+            t = tg >= 0 ? tg : tn;
+        }
         const int kh = t / 5, kw = t - kh * 5;
         const int tap = t < 25 ? ((kh * 2 + (kw & 1)) * XH + (kw >> 1)) * 8 : 0;
-        p2a[st] = img0 + 2 * (((2 * wrow) * 2 * XH + 16 * whalf + m) * 8 + tap + 4 * (g & 1));
+        p2a[st] = img0 + 2 * (((2 * wrow) * 2 * XH + 16 * whalf + m) * 8 + tap + (C::P2B128 ? 0 : 4 * (g & 1)));
         p2b[st] = p2a[st] ^ 8u;
     }
     // phase-2 output staging (wave private, overlays the dead patch): write 4 channels of pixel m, read back 16-byte pieces
@@ -295,7 +339,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     }
     const uint32_t gv = (uint32_t)(m * 32 + g * 8);          // DMA: byte offset of this lane's 8-byte piece in a 16-pixel output run
 
+    [[maybe_unused]] int tile_no = -1;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_no++;
+        B4_T(0);
         int b, by, bx;
         tile_origin(tile, b, by, bx);
         const int ty0 = by * TH1, tx0 = bx * TW1;
@@ -306,6 +353,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // ... and everybody else's; the previous tile's phase 2 is done with the image
             asm volatile("" ::: "memory");
+            B4_T(1);
         } else {
             // ---- phase 0: prefetched patch -> bf16 planes in LDS
             __syncthreads();                                     // previous tile's phase 2 is done with the LDS
@@ -328,6 +376,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
 
         // ---- phase 1: block_4_0 over the region, into the S3 image.  Regular M-tiles: fully unrolled, immediate addressing.
         // column validity of this lane's pixel (row validity is wave-uniform per M-tile)
+#if HNET_B4_ABLATE != 2
         const bool col_ok = (unsigned)(Rx0 + whalf * 32 + 2 * m + dx) < (unsigned)W0;
         if constexpr (REUSE && HW == 2) {
             constexpr int R = 2 * NP;                        // reads per 32-deep fragment; a tail fragment is NP reads
@@ -400,8 +449,12 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                     acc += acct;
                     const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
                     uint32_t pa[3], pb[3];
+#if HNET_B4_ABLATE == 4
+                    pa[0] = __builtin_bit_cast(uint32_t, acc[0]); pa[1] = __builtin_bit_cast(uint32_t, acc[1]); pb[0] = __builtin_bit_cast(uint32_t, acc[2]); pb[1] = __builtin_bit_cast(uint32_t, acc[3]) + ok;
+#else
                     s3p::act_split<NP>(acc[0], acc[1], pa, ok);
                     s3p::act_split<NP>(acc[2], acc[3], pb, ok);
+#endif
                     constexpr int JW = HW * j * 2 * XH * 16;
                     static_for<NP>([&](auto pc) {
                         constexpr int pl = decltype(pc)::value;
@@ -472,40 +525,71 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 });
             }
         });
-        // the pixel pairs of columns 64..66 (two per region row) form N_MT0 - N_REG more M-tiles: generic addressing, one per wave
-        for (int mt = N_REG + (WAVES - 1 - wave); mt < N_MT0; mt += WAVES) {
-            const int idx = (mt - N_REG) * 16 + m;
-            const int row = min(idx >> 1, RH - 1), pair = 32 + (idx & 1);
-            const int abase = row * PROW0 + pair * 4;
+        B4_T(2);
+#if HNET_B4_ABLATE != 5
+        // the pixel pairs of columns 64..66 (two per region row) form N_MT0 - N_REG = 3 more M-tiles, one each for waves 3, 2, 1: slot 16 k + m = (region row, pair 32 / 33).
+        // Same immediate-addressed form as the regular tiles on lane-invariant addresses of their own (round 4; until then a loop with per-tile address arithmetic,
+        // reads and MFMAs in lockstep: 1150 cycles per tile for 192 cycles of MFMA - tools/trace_b4.hip)
+        if (has_left) {                                      // wave-uniform
+            bf16x4 f[3][6], ft[3];
+            static_for<3>([&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    f[st][2 * pl] = rd64<pl * PPLANE * 2>(pL[st]);
+                    f[st][2 * pl + 1] = rd64<pl * PPLANE * 2 + 8>(pL[st]);
+                });
+            });
+            static_for<NP>([&](auto pc) {
+                constexpr int pl = decltype(pc)::value;
+                ft[pl] = rd64<pl * PPLANE * 2>(pLt);
+            });
             f32x4_t acc = bv;
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
+            auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
                 bf16x8 a[3];
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++) {
-                    const uint16_t* src = &patch[pl * PPLANE + abase + min(2 * st + (g >> 1), 6) * PROW0 + 8 * (g & 1)];
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(src + 4);
-                    a[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc = b4_mfma<NP>(acc, w, a);
+            };
+            constexpr int R = 2 * NP;
+            waitF<2 * R + NP, NP>(f[0]); __builtin_amdgcn_sched_barrier(0); mm(f[0], w0[0]);
+            waitF<R + NP, NP>(f[1]); __builtin_amdgcn_sched_barrier(0); mm(f[1], w0[1]);
+            waitF<NP, NP>(f[2]); __builtin_amdgcn_sched_barrier(0); mm(f[2], w0[2]);
+            waitT<0, NP>(ft); __builtin_amdgcn_sched_barrier(0);
+            f32x4_t acct = {0.f, 0.f, 0.f, 0.f};         // (own accumulator chain: see the regular tiles)
+            if constexpr (NP == 2) {
+                acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[2]), __builtin_bit_cast(f16x4, ft[1]), acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[1]), __builtin_bit_cast(f16x4, ft[0]), acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, w0t[0]), __builtin_bit_cast(f16x4, ft[0]), acct, 0, 0, 0);
+            } else {
+                if constexpr (NP == 3) {
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[2], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[2], ft[0], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], ft[1], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[1], acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[1], ft[0], acct, 0, 0, 0);
                 }
-                acc = b4_mfma<NP>(acc, w0[st], a);
+                acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], ft[0], acct, 0, 0, 0);
             }
-            const int rrow = idx >> 1, rcol = 2 * (32 + (idx & 1)) + dx;
-            if (rrow < RH && rcol < RW) {
-                const int iy = Ry0 + rrow, ix = Rx0 + rcol;
-                const bool ok = iy >= 0 && iy < H0 && ix >= 0 && ix < W0;
-                uint32_t pa[3], pb[3];
-                s3p::act_split<NP>(acc[0], acc[1], pa, ok);
-                s3p::act_split<NP>(acc[2], acc[3], pb, ok);
-                const int e = ((rrow * 2 + (rcol & 1)) * XH + (rcol >> 1)) * 8 + co0;
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(&img[pl * PLANE + e]) = make_uint2(pa[pl], pb[pl]);
-            }
+            acc += acct;
+            // outside the image = block_4_1's zero padding; slots beyond the region's last row repeat it (same address, same value); column 67 lands in an unread chunk
+            const bool ok = (unsigned)(Ry0 + rowL) < (unsigned)H0 && (unsigned)(Rx0 + colL) < (unsigned)W0;
+            uint32_t pa[3], pb[3];
+            s3p::act_split<NP>(acc[0], acc[1], pa, ok);
+            s3p::act_split<NP>(acc[2], acc[3], pb, ok);
+            static_for<NP>([&](auto pc) {
+                constexpr int pl = decltype(pc)::value;
+                wr64<pl * PLANE * 2>(stL, make_uint2(pa[pl], pb[pl]));
+            });
         }
+#endif
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's asm ds_writes (the barrier's own wait does not count them)
+        B4_T(3);
         if constexpr (DMA) {
             __builtin_amdgcn_s_barrier();                    // raw barrier: a __syncthreads() would also drain the stores of phase 2
             asm volatile("" ::: "memory");
+            B4_T(4);
             if (tile + (int)gridDim.x < n_tiles) dma_issue(tile + gridDim.x);    // the patch is dead: the next tile's copy runs under phase 2
         } else {
             __syncthreads();
@@ -513,10 +597,31 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
 
         // ---- phase 2: block_4_1 from the S3 image; fully unrolled, immediate addressing, three steps of reads in flight
         unsigned char* const obase = reinterpret_cast<unsigned char*>(out16) + (((size_t)b * H1 + ty0 + wrow) * W1 + tx0 + whalf * 16) * 32;
+#if HNET_B4_ABLATE != 1
         static_for<J2>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (wave + WAVES * j < N_MT1) {                  // wave-uniform
                 constexpr int JR = HW * j * 2 * (2 * XH * 16);   // bytes: HW output rows = 2 HW image rows down
+                f32x4_t acc = bv1;
+                if constexpr (C::P2B128) {
+                    // one ds_read_b128 per plane and step (16 bytes = the 8 channels of the lane's tap pixel); four steps in flight
+                    bf16x8 q[7][3];
+                    auto rd = [&](auto sc) {
+                        constexpr int st = decltype(sc)::value;
+                        static_for<NP>([&](auto pc) {
+                            constexpr int pl = decltype(pc)::value;
+                            q[st][pl] = rd128i<JR + pl * PLANE * 2>(p2a[st]);
+                        });
+                    };
+                    rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); rd(std::integral_constant<int, 3>{});
+                    static_for<7>([&](auto sc) {
+                        constexpr int st = decltype(sc)::value;
+                        constexpr int ahead = st + 3 < 7 ? 3 : 6 - st;       // steps in flight behind the one consumed
+                        waitQ<ahead * NP>(q[st]); __builtin_amdgcn_sched_barrier(0);
+                        acc = b4_mfma<NP>(acc, w1[st], q[st]);
+                        if constexpr (st + 4 < 7) rd(std::integral_constant<int, st + 4>{});
+                    });
+                } else {
                 bf16x4 f[7][6];
                 auto rd = [&](auto sc) {
                     constexpr int st = decltype(sc)::value;
@@ -526,7 +631,6 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                         f[st][2 * pl + 1] = rd64<JR + pl * PLANE * 2>(p2b[st]);
                     });
                 };
-                f32x4_t acc = bv1;
                 auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
                     bf16x8 a[3];
 #pragma unroll
@@ -546,14 +650,19 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 waitF<2 * R, NP>(f[4]); __builtin_amdgcn_sched_barrier(0); mm(f[4], w1[4]);
                 waitF<1 * R, NP>(f[5]); __builtin_amdgcn_sched_barrier(0); mm(f[5], w1[5]);
                 waitF<0, NP>(f[6]); __builtin_amdgcn_sched_barrier(0); mm(f[6], w1[6]);
+                }
                 // D (transposed): row 4g + r = cout, column m = output pixel: 8 bytes (4 channels) per lane and plane
                 uint32_t pa[3], pb[3];
                 s3p::act_split<NP>(acc[0], acc[1], pa);
                 s3p::act_split<NP>(acc[2], acc[3], pb);
                 unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
                 if constexpr (DMA) {
+#if HNET_B4_ABLATE == 3
+                    asm volatile("" ::"v"(pa[0]), "v"(pb[0]), "v"(pa[1]), "v"(pb[1]), "v"(orow));
+#else
 #pragma unroll
                     for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(orow + (size_t)pl * o_plane * 2 + gv) = make_uint2(pa[pl], pb[pl]);
+#endif
                 } else {
                     static_for<NP>([&](auto pc) {
                         constexpr int pl = decltype(pc)::value;
@@ -569,6 +678,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 }
             }
         });
+#endif
+        B4_T(5);
     }   // persistent tile loop
 }
 

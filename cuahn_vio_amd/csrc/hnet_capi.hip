@@ -700,12 +700,13 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                 std::vector<uint16_t> fr((size_t)7 * 3 * 64 * 8, 0);
                 for (int st = 0; st < 7; st++)
                     for (int ln = 0; ln < 64; ln++) {
-                        const int n = ln & 15, gg = ln >> 4, t = 4 * st + gg;
-                        if (t >= 25) continue;
+                        // fp16-plane mode: the tap table of kernels.h (lane-group pairs share one ds_read_b128), channels in order
+                        const int n = ln & 15, gg = ln >> 4, t = c->n_planes == 2 ? b41_tap(st, gg) : 4 * st + gg;
+                        if (t < 0 || t >= 25) continue;
                         const int kh = t / 5, kw = t % 5;
                         for (int j = 0; j < 8; j++) {
-                            // odd lane groups read their 16-byte chunk high half first (conv_b4_fused.h): element j = channel (j + 4) % 8
-                            const int ci = (gg & 1) ? (j + 4) % 8 : j;
+                            // three-plane / bf16 modes: odd lane groups read their 16-byte chunk high half first (conv_b4_fused.h): element j = channel (j + 4) % 8
+                            const int ci = (c->n_planes != 2 && (gg & 1)) ? (j + 4) % 8 : j;
                             uint16_t sp[3];
                             wsplit_np(w->data[(((size_t)n * 8 + ci) * 5 + kh) * 5 + kw], c->n_planes, sp[0], sp[1], sp[2]);
                             for (int pl = 0; pl < 3; pl++) fr[(((size_t)st * 3 + pl) * 64 + ln) * 8 + j] = sp[pl];
@@ -839,7 +840,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
     c->patch_rb5 = 5;                  // region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->patch_b128 = true;
-    c->b4_flags = 0;
+    c->b4_flags = c->s3_tile == 26 ? 32 : 0;       // (variant 26: the 7 x 32 tiles of rounds 2 - 3, A/B)
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -1542,7 +1543,7 @@ int hnet_op_block4_fused(hnet_ctx* c, const float* in, int batch, int reverse, f
         HIPCHK(c, launch_f32_nhwc_to_s3pad(d_b, d_p, x_plane, batch, c->n_planes, c->stream));
         x_in = d_p;
     }
-    HIPCHK(c, launch_block4_fused(x_in, x_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, reverse ? 1 : 0,
+    HIPCHK(c, launch_block4_fused(x_in, x_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], p_out, n_out, batch, c->stream, (reverse ? 1 : 0) | (c->b4_flags & 32),
                                   c->n_planes));
     HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 16, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -76,6 +76,14 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
 // The border (never written after the allocation was zeroed) IS the zero padding of block_4_0, and the patch of every tile
 // starts at a column that is a multiple of 4 dwords (16-byte chunks for the LDS-DMA) while staying an odd pixel column.
 constexpr int B4_PADX = 5, B4_PADY = 5, B4_WP = 336, B4_HP = 235;
+// fp16-plane mode, phase 2 of that kernel: filter tap (kh * 5 + kw) of lane group g in MFMA step st; -1 = no tap (zero weights, the group re-reads its neighbour's
+// pixels).  Groups (0, 1) and (2, 3) are served together by ds_read_b128: they hold taps of ONE kernel column, whose pixels are whole image rows (a multiple of
+// 256 bytes) apart - conflict-free; kernel row 4 has no partner (steps 5, 6).  Shared by the kernel's address setup and hnet_create's fragment packing.
+constexpr int b41_tap(int st, int g) {
+    if (st < 5) return g * 5 + st;                               // (kh, kw) = (g, st)
+    if (st == 5) return g == 0 ? 20 : g == 2 ? 21 : -1;          // (4, 0) | - | (4, 1) | -
+    return g == 0 ? 22 : g == 2 ? 23 : g == 3 ? 24 : -1;         // (4, 2) | - | (4, 3) | (4, 4)
+}
 
 // cat(img1, warp(img2,H)) -> AvgPool(k) -> NHWC [B][224/k][320/k][2]; H == nullptr: no warp
 // out_s3 != nullptr (k = 1 only): write the padded bf16 planes above instead (s3_plane = dwords per plane)

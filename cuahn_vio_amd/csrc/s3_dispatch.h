@@ -155,22 +155,32 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
 // block_4_0 + block_4_1 fused (conv_b4_fused.h): x_in = the padded 16-bit planes of kernels.h B4_* (x_plane dwords per plane) -> out16 planes [NP][B][112][160][16].
 // 7 x 32 tiles, two 256-thread workgroups per CU, LDS-DMA staging, phase-1 fragment reuse: the winner of the round-2 / round-3 measurements
 // (8 x 32 / 512 threads, fp32 input without DMA, no fragment reuse and the v2 kernel were removed in round 4; DESIGN.md section 3.4 keeps the table)
+template <int TH1, int NP>
+static hipError_t run_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
+                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
+    typedef B4Cfg<TH1, 256, NP, true> C;
+    const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
+    const int per_cu = std::max(1, std::min(2, std::min(2048 / 256, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
+    const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
+    hipLaunchKernelGGL((block4_fused_kernel<TH1, 256, NP, true, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, x_in, x_plane,
+                       (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+    return hipGetLastError();
+}
 template <int NP>
 hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
 #ifdef HNET_B4_ABLATE   // profiling build only (make ablate): HNET_B4_DBG drops phases of the kernel, results are wrong
     static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
-    flags = (flags & 17) | ((dbg_env & 7) << 1);
+    flags = (flags & 49) | ((dbg_env & 7) << 1);
 #else
-    flags &= 17;
+    flags &= 49;
 #endif
-    typedef B4Cfg<7, 256, NP, true> C;
-    const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
-    const int per_cu = std::max(1, std::min(2, std::min(2048 / 256, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
-    const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
-    hipLaunchKernelGGL((block4_fused_kernel<7, 256, NP, true, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, x_in, x_plane,
-                       (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
-    return hipGetLastError();
+    // fp16-plane mode: 8 x 32 tiles (57 KB of LDS: still two workgroups per CU; 16 phase-2 M-tiles = four per wave exactly, 19 / 16 rows of halo instead of 17 / 14).
+    // flags bit 5 (hnet_config.variant 26): the 7 x 32 tiles of rounds 2 - 3 (A/B); the three-plane modes need them for two workgroups per CU
+    if constexpr (NP == 2) {
+        if (!(flags & 32)) return run_block4_fused<8, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    }
+    return run_block4_fused<7, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
 // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h; fp16-plane mode only): x_in fp32 [B][112][160][2] -> out16 fp16 planes [2][B][56][80][32]
@@ -365,6 +375,7 @@ template <int NP>
 hipError_t conv_kernels_init_device_np() {
     hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if constexpr (NP == 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 256, NP, true>::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<HeadLoaderS3, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
 #define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
         typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;

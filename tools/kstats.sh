@@ -10,7 +10,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = re.sub(r"\(.*$", "", re.sub(r"hnet::", "", re.sub(r"^void ", "", r["Kernel_Name"])))
-    acc[(k, int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
+    acc[(k, int(r.get("Grid_Size") or r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
 rows = sorted(((k, g, len(v), sum(v) / len(v)) for (k, g), v in acc.items() if len(v) >= 5), key=lambda r: -r[3] * r[2])
 for k, g, n, a in rows[:45]:
     print(f"{a:9.1f} us x{n:4d}  grid {g:8d}  {k[:110]}")
