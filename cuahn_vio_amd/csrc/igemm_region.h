@@ -17,8 +17,8 @@
 // products, results agree to fp32 rounding (goldens + element-wise test).  KSPLIT (the 4 x 5 layers, N-tile 64): waves 0 - 3 take the first taps of every
 // chunk, waves 4 - 7 the rest, for the same four N-tiles; the two partial accumulators are added through LDS in a fixed order.
 //
-// LDS: two region buffers [2 planes][RP + 8 rows][64 halves]; a row = one region pixel, 128 bytes = eight 16-byte pieces; rows RP .. RP + 7 are zeros
-// (padding taps and rows beyond M read row RP).  The LDS-DMA fetches any 64 pieces per instruction, so the layout is free; it is chosen for the fragment
+// LDS: two region buffers [2 planes][RP + 16 rows][64 halves]; a row = one region pixel, 128 bytes = eight 16-byte pieces; rows RP .. RP + 15 are zeros
+// (padding taps and rows beyond M read zero row RP + (T & 15): the row of their own bank class, so that a fragment with padding lanes stays conflict-free).  The LDS-DMA fetches any 64 pieces per instruction, so the layout is free; it is chosen for the fragment
 // reads: the pixels are split into the four (y & 1, x & 1) images (a fragment read touches ONE of them: stride 2), pixel (pair, y, x) is row
 //   q = base[image] + pair PS[image] + (y >> 1) Wo + (x >> 1),      T = pair Ho Wo + (y >> 1) Wo + (x >> 1)       (W / 2 = Wo, (H + 1) / 2 = Ho)
 // so that the 16 GEMM rows m .. m + 15 of a fragment (consecutive output pixels, across output rows and pairs) read rows with CONSECUTIVE T, and piece c of
@@ -42,7 +42,7 @@ struct RegionCfg {
     static constexpr int NTAP_PAD = KSPLIT_ ? 2 * TAPS_X : NTAP;             // K-tiles per chunk in the packed weights (taps >= NTAP: zeros)
     static constexpr int DEPTH = 5;                                          // 32-deep STEPS of weight fragments in flight per wave (2.5 K-tiles, 40 VGPRs); divides the 2 TAPS_X steps of a chunk (slot = step % DEPTH in every chunk)
     static_assert((2 * TAPS_X) % DEPTH == 0, "weight-fragment ring");
-    static constexpr int REG_PLANE = (RP + 8) * 64;                          // halves per plane
+    static constexpr int REG_PLANE = (RP + 16) * 64;                         // halves per plane
     static constexpr int REG_BUF = 2 * REG_PLANE;                            // halves per region buffer (two planes)
     static constexpr int LDS_BYTES = 2 * REG_BUF * 2;
     static constexpr int RG = RP / 8;                                        // region DMA groups (8 rows each)
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     const int a_pl = (int)(p.a_plane * 2);
 
     // the zero rows of both buffers (never a DMA target)
-    if (tid < 32) {
+    {   // 16 rows x 128 B x 2 planes x 2 buffers = 512 pieces of 16 bytes
         const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(&smem_r[(tid >> 4) * REG_BUF + ((tid >> 3) & 1) * REG_PLANE + C::RP * 64 + (tid & 7) * 8]) = z;
+        *reinterpret_cast<u32x4*>(&smem_r[(tid >> 8) * REG_BUF + ((tid >> 7) & 1) * REG_PLANE + C::RP * 64 + (tid & 127) * 8]) = z;
     }
 
     // ---- region DMA: groups g = wave, wave + 8, ... (8 region rows x 128 B each)
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     // ---- A fragment addressing
     const int r16 = lane & 15, g16 = lane >> 4;
     int qpair_e[TM], qpair_o[TM], tbase[TM], oy2[TM], ox2[TM];   // per M-tile row of this lane: its pair's first row in the even-y / odd-y images, pair Ho Wo, 2 oy - PAD, 2 ox - PAD
+    uint32_t row_ok = 0;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int ml = i * 16 + r16;                             // row of the tile
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
         qpair_e[i] = pl_ * ps_e;
         qpair_o[i] = pl_ * ps_o;
         tbase[i] = pl_ * R;
-        oy2[i] = ok ? 2 * oy - PAD : -4096;                      // (rows beyond the tile: every tap reads the zero row)
+        oy2[i] = 2 * oy - PAD;
+        row_ok |= ok ? (1u << i) : 0u;                           // (rows beyond the tile read zero rows - of their own bank class: T stays linear in the row)
         ox2[i] = 2 * ox - PAD;
     }
     bf16x8 fa[2][TM][2];
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
             int oy_ = oy2[i];
             asm volatile("" : "+v"(oy_));
             const int y = oy_ + kh, x = ox2[i] + kw;
-            const bool ok = t < NTAP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const bool ok = t < NTAP && ((row_ok >> i) & 1u) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             const int yo = y & 1, xo = x & 1;
             const int tt = (y >> 1) * Wo + (x >> 1);
-            const int q = ok ? (yo ? base2 + qpair_o[i] : qpair_e[i]) + (xo ? (yo ? C::P * ps_o : C::P * ps_e) : 0) + tt : C::RP;
             const int T = tbase[i] + tt;
+            const int q = ok ? (yo ? base2 + qpair_o[i] : qpair_e[i]) + (xo ? (yo ? C::P * ps_o : C::P * ps_e) : 0) + tt : C::RP + (T & 15);
             a_byte[i] = q * 128 + ((g16 ^ (2 * ((T >> 1) & 3))) << 4);
         }
     };

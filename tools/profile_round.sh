@@ -14,3 +14,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $B --steps 2 --warmup 1 > $OUT.write.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- $B --steps 2 --warmup 1 > $OUT.mfma.log 2>&1
 ls -R $OUT | head -40
+# SURVEY 8(d) config 3 (prior-3, 64 pairs, N = 16): MFMA / LDS counters per kernel
+rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/cfg3 -- $B --steps 2 --warmup 1 --variant prior3 --batch 64 --mc 16 > $OUT.cfg3.log 2>&1

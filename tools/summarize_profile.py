@@ -73,18 +73,21 @@ if fe and wr:
         for k in sorted(f):
             cw.writerow([k, f[k][1], f[k][0], w.get(k, (0, 0))[0], round((2 * f[k][0] + w.get(k, (0, 0))[0]) / 1024.0, 1)])
 
-if len(sys.argv) > 2:
-    pm = glob.glob(os.path.join(ROOT, "gpurun_out", sys.argv[2], "**", "*counter_collection.csv"), recursive=True)[0]
+def mfma_lds_table(pass_dir, out_name, what):
+    pm = glob.glob(os.path.join(ROOT, "gpurun_out", pass_dir, "**", "*counter_collection.csv"), recursive=True)
+    if not pm:
+        return
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(pm)):
+    for r in csv.DictReader(open(pm[0])):
         acc[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     best = {}
-    for (k, g), cs in acc.items():          # keep the largest grid of each kernel (the batch-256 launches)
+    for (k, g), cs in acc.items():          # keep the largest grid of each kernel (the full-batch launches)
         if k not in best or g > best[k][0]:
             best[k] = (g, {n: sum(v) / len(v) for n, v in cs.items()}, len(next(iter(cs.values()))))
-    with open(os.path.join(dst, tag + "_pmc_mfma_lds.csv"), "w") as out:
-        out.write("# rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (tools/profile_round.sh), batch 256, averages over the full-batch launches.\n")
+    with open(os.path.join(dst, out_name), "w") as out:
+        out.write("# rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (tools/profile_round.sh), " + what + ", averages over the full-batch launches.\n")
         out.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); lds_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES; conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n")
+        out.write("# csrc_digest: " + digest + "\n")
         cw = csv.writer(out)
         out.write("# valu_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (4 SIMDs x SQ_BUSY_CU_CYCLES); valu_per_mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA (wave instructions).\n")
         cw.writerow(["kernel", "grid_threads", "launches", "mfma_busy", "lds_busy", "lds_conflict_share", "valu_busy", "valu_per_mfma", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"])
@@ -98,4 +101,8 @@ if len(sys.argv) > 2:
                          round(c.get("SQ_ACTIVE_INST_VALU", 0) / busy, 4) if "SQ_ACTIVE_INST_VALU" in c else "",
                          round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"], 2) if c.get("SQ_INSTS_MFMA") else "",
                          int(busy), int(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))])
+
+
+mfma_lds_table(sys.argv[2] if len(sys.argv) > 2 else os.path.join("prof_" + tag, "mfma"), tag + "_pmc_mfma_lds.csv", "batch 256")
+mfma_lds_table(os.path.join("prof_" + tag, "cfg3"), tag + "_cfg3_pmc_mfma_lds.csv", "SURVEY 8(d) config 3: prior-3 (three blocks + EKF prior), 64 pairs, N = 16")
 print("profiles/ updated for", tag)

@@ -32,6 +32,7 @@ int main() {
     auto kern = block4_fused_kernel<B4_TH1, 256, NP, true, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int n_tiles = B * (112 / C::TH1) * (160 / C::TW1);
+    const unsigned grid = std::getenv("B4_GRID") ? std::atoi(std::getenv("B4_GRID")) : 512;      // 256: one workgroup per CU (do the two of a CU overlap?)
 #ifdef HNET_B4_TRACE
     unsigned long long* tr;
     const size_t n = 8 * 4 * 32 * 6;
@@ -41,18 +42,18 @@ int main() {
     hipEvent_t a0, a1;
     CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
     for (int rep = 0; rep < 3; rep++) {
-        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, dim3(512), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
         CK(hipEventRecord(a0));
-        for (int i = 0; i < 10; i++) hipLaunchKernelGGL(kern, dim3(512), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
+        for (int i = 0; i < 10; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
         CK(hipEventRecord(a1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, a0, a1));
-        std::printf("   TH1 %d, phase-2 b128 %d, ablation %d: LDS %d B, %d tiles: %.4f ms per launch\n", B4_TH1, (int)C::P2B128, HNET_B4_ABLATE, C::LDS_BYTES, n_tiles, ms / 10);
+        std::printf("   TH1 %d, phase-2 b128 %d, ablation %d, grid %u: LDS %d B, %d tiles: %.4f ms per launch\n", B4_TH1, (int)C::P2B128, HNET_B4_ABLATE, grid, C::LDS_BYTES, n_tiles, ms / 10);
     }
 #ifdef HNET_B4_TRACE
     {
         CK(hipMemset(tr, 0, n * 8));
-        hipLaunchKernelGGL(kern, dim3(512), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, 0, x, x_plane, (const u32x4*)w0, bias, (const u32x4*)w1, bias, out, o_plane, n_tiles, 0);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> t(n);
         CK(hipMemcpy(t.data(), tr, n * 8, hipMemcpyDeviceToHost));
