@@ -248,8 +248,9 @@ def committed_traffic(kernel_substr, batch):
 
 
 # stage name -> substring of the HIP kernel name in the rocprof tables
-KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "HeadLoaderS3, 128", "block_3_1": "conv_patch_s2_kernel<5",
-                   "block_2_2": "ConvLoaderS3<64, 5, 2, 32>", "block_3_0+3_1": "block3_fused_kernel", "block_4_2+4_3": "block42_fused_kernel"}
+KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "igemm_heads_pipe_kernel", "block_3_1": "conv_patch_s2_kernel<5",
+                   "block_2_2": "igemm_s3_pipe_kernel<hnet::ConvLoaderS3<64, 5, 2, 32>", "block_3_0+3_1": "block3_fused_kernel",
+                   "block_4_2+4_3": "block42_fused_kernel", "block_1_2": "igemm_s3_region_kernel<hnet::RegionCfg<128, 5, 1"}
 # stages whose contraction does not run on the bf16 matrix cores in the split-bf16 mode: the small FCs (fp32 FMAs).  (Round 1 also ran
 # the Cin = 2 first layers of blocks 1 and 2 on the fp32 MFMA; they are bf16x3 kernels since r02_v2, conv_first.h conv7_c2_s2_s3_kernel.)
 FP32_STAGES = ("fc_dlt_b1", "fc_dlt_b2", "fc_dlt_b3", "heads_fc2")
@@ -698,7 +699,7 @@ def run(args, ctx, primary):
         np_arg = {"bf16x3": 3, "f16x2": 2}.get(args.precision)
         ksub = KERNEL_OF_STAGE.get(stages[k][0], "\0")
         if ksub == "block4_fused_kernel" and np_arg:
-            ksub = "block4_fused_kernel<7, 256, %d," % np_arg
+            ksub = "block4_fused_kernel<%d, 256, %d," % (8 if np_arg == 2 else 7, np_arg)
         traffic, traffic_src = committed_traffic(ksub, B) if np_arg else (None, None)
         res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
                            "traffic": traffic, "traffic_source": traffic_src,

@@ -40,9 +40,9 @@
 
 namespace hnet {
 
-#ifdef HNET_B4_TRACE            // tools/trace_b4.hip: s_memtime stamps of workgroups 0 - 7, six per tile and wave: [wg][wave][tile][6]
-__device__ unsigned long long* g_b4_trace;
-#define B4_T(k) do { if (blockIdx.x < 8 && lane == 0 && tile_no < 32) g_b4_trace[((blockIdx.x * 4 + wave) * 32 + tile_no) * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef HNET_B4_TRACE            // tools/trace_b4.hip: cycles per phase (s_memtime), summed in registers over the tiles of a workgroup and written once at the end
+__device__ unsigned long long* g_b4_trace;     // (a store per stamp made the traced waves wait for their LDS-DMA at every stamp: vmcnt(0) in front of the store)
+#define B4_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (tile_no > 1) tr_acc[k] += now_ - tr_prev; tr_prev = now_; } while (0)
 #else
 #define B4_T(k) do { } while (0)
 #endif
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     using namespace b4v3;
     typedef B4Cfg<TH1, THREADS, NP, DMA> C;
     const float* const x_in = reinterpret_cast<const float*>(x_in_v);
-    constexpr int WAVES = C::WAVES, TW1 = C::TW1, RH = C::RH, RW = C::RW, PH0 = C::PH0, PW0 = C::PW0, PROW0 = C::PROW0;
+    constexpr int WAVES = C::WAVES, TW1 = C::TW1, RH = C::RH, PH0 = C::PH0, PW0 = C::PW0, PROW0 = C::PROW0;
     constexpr int PPLANE = C::PPLANE, XH = C::XH, PLANE = C::PLANE, N_MT0 = C::N_MT0, N_MT1 = C::N_MT1;
     constexpr int H0 = 224, W0 = 320, H1 = 112, W1 = 160;
     constexpr int HW = WAVES / 2;                                     // region rows / output rows a wave advances per j
@@ -192,7 +192,6 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     constexpr int J1 = (N_REG + WAVES - 1) / WAVES, J2 = (N_MT1 + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint16_t* patch = reinterpret_cast<uint16_t*>(lds_raw);                    // [NP][PH0][PROW0] bf16
-    uint16_t* img = patch + NP * PPLANE;                                        // S3 image of the block_4_0 region
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
     const uint32_t img0 = lds0 + NP * PPLANE * 2;
 
@@ -270,6 +269,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const uint32_t gvo1 = (uint32_t)(((size_t)(pc1 >> 5) * o_plane + ((pc1 & 31) >> 1) * 16 + (pc1 & 1) * 8) * 2);
 
     const bool reverse = (flags & 1) != 0;
+    const bool o_pad = (flags & 64) != 0;
+    const int o_wp = o_pad ? B42_WP : W1;                             // output row pitch in pixels, pixels per pair, pixel (0, 0)
+    const size_t o_img = o_pad ? B42_IMG : (size_t)H1 * W1;
+    const int o_org = o_pad ? B42_PADY * B42_WP + B42_PADX : 0;
     // XCD-aware tile order (r02_v9).  Slot t = blockIdx.x + k gridDim.x is processed by workgroup blockIdx.x, and consecutive workgroup ids
     // go to consecutive XCDs, each with a private L2: with tile = slot, the 23 x 80-pixel patches of neighbouring tiles - which overlap by
     // 2.05x in total - were fetched by eight different L2s (FETCH_SIZE, corrected x2: 518 MB per launch for 242 MB of input).  Here XCD x
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const uint32_t gv = (uint32_t)(m * 32 + g * 8);          // DMA: byte offset of this lane's 8-byte piece in a 16-pixel output run
 
     [[maybe_unused]] int tile_no = -1;
+    [[maybe_unused]] unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_prev = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_no++;
         B4_T(0);
@@ -596,7 +600,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
         }
 
         // ---- phase 2: block_4_1 from the S3 image; fully unrolled, immediate addressing, three steps of reads in flight
-        unsigned char* const obase = reinterpret_cast<unsigned char*>(out16) + (((size_t)b * H1 + ty0 + wrow) * W1 + tx0 + whalf * 16) * 32;
+        // flags bit 6: the bordered layout of kernels.h B42_* (the fused block_4_2 + block_4_3 kernel copies its patches from it by LDS-DMA)
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(out16) + ((size_t)b * o_img + o_org + (size_t)(ty0 + wrow) * o_wp + tx0 + whalf * 16) * 32;
 #if HNET_B4_ABLATE != 1
         static_for<J2>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 uint32_t pa[3], pb[3];
                 s3p::act_split<NP>(acc[0], acc[1], pa);
                 s3p::act_split<NP>(acc[2], acc[3], pb);
-                unsigned char* const orow = obase + (size_t)(HW * j) * W1 * 32;      // wave-uniform
+                unsigned char* const orow = obase + (size_t)(HW * j) * o_wp * 32;    // wave-uniform
                 if constexpr (DMA) {
 #if HNET_B4_ABLATE == 3
                     asm volatile("" ::"v"(pa[0]), "v"(pb[0]), "v"(pa[1]), "v"(pb[1]), "v"(orow));
@@ -681,6 +686,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
 #endif
         B4_T(5);
     }   // persistent tile loop
+#ifdef HNET_B4_TRACE
+    if (blockIdx.x < 8 && lane == 0) for (int k = 0; k < 6; k++) g_b4_trace[(blockIdx.x * 4 + wave) * 7 + k] = tr_acc[k];
+    if (blockIdx.x < 8 && lane == 0) g_b4_trace[(blockIdx.x * 4 + wave) * 7 + 6] = (unsigned long long)(tile_no - 1);
+#endif
 }
 
 }  // namespace hnet

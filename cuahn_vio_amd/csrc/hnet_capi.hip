@@ -102,6 +102,7 @@ struct hnet_ctx {
     bool fuse_b3 = false;              // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h): fp16-plane mode, HNET_FUSE_B3=0 switches back
     uint16_t* b3f_w0 = nullptr;        // its weights: block_3_0 as [7][2][64] x 16 B fragments (two planes), block_3_1 as [2][13][2][64] x 16 B
     uint16_t* b3f_w1 = nullptr;
+    bool a14_pad = false;              // block_4_1's output (act16[14]) in the bordered layout of kernels.h B42_* (fused block-4 kernel -> LDS-DMA of the fused block_4_2 + 4_3 kernel)
     bool fuse_b42 = false;             // block_4_2 + block_4_3 in one kernel (conv_b42_fused.h): fp16-plane mode, HNET_FUSE_B42=0 switches back
     uint16_t* b42_w2 = nullptr;        // its weights: [2][5][2][64] x 16 B and [4][9][2][64] x 16 B fragments
     uint16_t* b42_w3 = nullptr;
@@ -390,16 +391,16 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         const size_t MB = (size_t)g.max_batch;
         for (int l = first[blk]; l <= last[blk]; l++) {
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
-                const size_t cnt1 = c->act_count[14];
+                const size_t cnt1 = c->a14_pad ? B42_IMG * 16 : c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
                 STAGE(launch_block4_fused(b4_dma ? (const void*)x16 : (const void*)in, c->x16_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16,
-                                          MB * cnt1, B, s, c->b4_flags, c->n_planes));
+                                          MB * cnt1, B, s, c->b4_flags | (c->a14_pad ? 64 : 0), c->n_planes));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
                 continue;
             }
-            if (c->fuse_b42 && l == 15 && c->n_planes == 2 && c->b42_w2 && c->b42_w3 && in16 && h == 112 && w == 160) {   // block_4_2 + block_4_3 in one launch
+            if (c->fuse_b42 && c->a14_pad && l == 15 && c->n_planes == 2 && c->b42_w2 && c->b42_w3 && in16 && h == 112 && w == 160) {   // block_4_2 + block_4_3 in one launch
                 const size_t cnt1 = c->act_count[16];
                 uint16_t* o16b = c->act16[16] + P0 * cnt1;
                 STAGE(launch_block42_fused(in16, in_plane, c->b42_w2, c->conv_b[15], c->b42_w3, c->conv_b[16], o16b, MB * cnt1, B, s, c->n_planes));
@@ -838,6 +839,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b3 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B3);
     c->fuse_b42 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B42);
     c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
+    c->a14_pad = c->fuse_b4 && c->fuse_b42;
     c->patch_rb5 = 5;                  // region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->patch_b128 = true;
     c->b4_flags = c->s3_tile == 26 ? 32 : 0;       // (variant 26: the 7 x 32 tiles of rounds 2 - 3, A/B)
@@ -872,6 +874,11 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
             c->act_c[l] = kConvs[l].cout; c->act_h[l] = h; c->act_w[l] = w;
             c->act_count[l] = (size_t)h * w * kConvs[l].cout;
             if (c->fuse_b4 && l == 13) continue;                   // block_4_0's output lives in LDS only (conv_b4_fused.h): 880 MB at batch 256 saved
+            if (c->s3 && l == 14 && c->a14_pad) {                  // two bordered fp16 planes, or (after a demotion to split-bf16) three plain ones; the border stays zero
+                const size_t bytes = std::max((size_t)3 * MB * c->act_count[l], (size_t)2 * MB * B42_IMG * 16) * 2;
+                CK(hipMalloc((void**)&c->act16[l], bytes));
+                CK(hipMemset(c->act16[l], 0, bytes));
+            } else
             if (c->s3 && l != last[blk]) CK(hipMalloc((void**)&c->act16[l], 3 * MB * c->act_count[l] * 2));   // feeds a conv: S3 planes
             else CK(dalloc(&c->act[l], MB * c->act_count[l]));
         }
@@ -1143,7 +1150,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     Blob b;
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;
-    c->fuse_b3 = c->fuse_b42 = false;    // the fused block-3 / block_4_2+4_3 kernels exist for the fp16 planes only (their layers' buffers stay allocated)
+    c->fuse_b3 = c->fuse_b42 = c->a14_pad = false;    // the fused block-3 / block_4_2+4_3 kernels exist for the fp16 planes only (their layers' buffers stay allocated; act16[14] goes back to the plain layout)
     c->cfg.precision = HNET_PREC_BF16X3;
     const int rc = upload_weights(c, b);
     if (rc != HNET_OK) return fail(c, rc, "re-packing the weights for HNET_PREC_BF16X3");
@@ -1563,7 +1570,12 @@ int hnet_op_block42_fused(hnet_ctx* c, const float* in, int batch, float* out) {
     HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_in, 3 * n_in + 32)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
     HIPCHK(c, launch_nchw_f32_to_nhwc_s3(d_a, p_in, n_in, batch, 16, h1, w1, c->stream, c->n_planes));
-    HIPCHK(c, launch_block42_fused(p_in, n_in, c->b42_w2, c->conv_b[15], c->b42_w3, c->conv_b[16], p_out, n_out, batch, c->stream, c->n_planes));
+    uint16_t* p_pad = nullptr;                     // the kernel's input layout: planes with a zero border (kernels.h B42_*)
+    const size_t n_pad = (size_t)batch * B42_IMG * 16;
+    HIPCHK(c, t.alloc(&p_pad, 2 * n_pad));
+    HIPCHK(c, hipMemsetAsync(p_pad, 0, 2 * n_pad * 2, c->stream));
+    HIPCHK(c, launch_s3_repitch(p_in, n_in, p_pad, n_pad, batch, h1, w1, 16, B42_HP, B42_WP, B42_PADY, B42_PADX, true, c->stream, 2));
+    HIPCHK(c, launch_block42_fused(p_pad, n_pad, c->b42_w2, c->conv_b[15], c->b42_w3, c->conv_b[16], p_out, n_out, batch, c->stream, c->n_planes));
     HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 64, h1 / 4, w1 / 4, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));
@@ -1643,7 +1655,16 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         uint16_t* tmp = nullptr;
         HIPCHK(c, t.alloc(&tmp, 3 * n));
         const size_t n14 = c->act_count[14];
-        HIPCHK(c, launch_conv_patch(15, c->act16[14] + (size_t)pair * n14, (size_t)c->cfg.max_batch * n14, 1, c->act_h[14], c->act_w[14], c->patch_frag[15],
+        const uint16_t* a14 = c->act16[14] + (size_t)pair * n14;
+        size_t a14_plane = (size_t)c->cfg.max_batch * n14;
+        if (c->a14_pad) {                          // bordered layout -> a plain copy of this pair
+            uint16_t* plain = nullptr;
+            HIPCHK(c, t.alloc(&plain, 2 * n14));
+            HIPCHK(c, launch_s3_repitch(c->act16[14] + (size_t)pair * B42_IMG * 16, (size_t)c->cfg.max_batch * B42_IMG * 16, plain, n14, 1, c->act_h[14], c->act_w[14], 16,
+                                        B42_HP, B42_WP, B42_PADY, B42_PADX, false, c->stream, 2));
+            a14 = plain; a14_plane = n14;
+        }
+        HIPCHK(c, launch_conv_patch(15, a14, a14_plane, 1, c->act_h[14], c->act_w[14], c->patch_frag[15],
                                     c->conv_b[15], tmp, n, c->stream, c->n_planes, c->patch_b128, c->patch_rb5));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[15], c->act_h[15], c->act_w[15], c->stream, c->n_planes));
     } else if (c->fuse_b3 && layer == 7) {   // the fused block-3 kernel keeps block_3_0's output in LDS: recompute it unfused for inspection
@@ -1651,6 +1672,12 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
         HIPCHK(c, t.alloc(&tmp, 3 * n));
         HIPCHK(c, launch_conv_first_s3(c->x_in[2] + (size_t)pair * (NPIX / 4) * 2, c->b30_frag, c->conv_b[7], tmp, n, 1, IMG_H / 2, IMG_W / 2, c->stream, c->n_planes));
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(tmp, n, d_t, 1, c->act_c[7], c->act_h[7], c->act_w[7], c->stream, c->n_planes));
+    } else if (layer == 14 && c->a14_pad) {        // bordered layout -> a plain copy of this pair
+        uint16_t* plain = nullptr;
+        HIPCHK(c, t.alloc(&plain, 2 * n));
+        HIPCHK(c, launch_s3_repitch(c->act16[14] + (size_t)pair * B42_IMG * 16, (size_t)c->cfg.max_batch * B42_IMG * 16, plain, n, 1, c->act_h[14], c->act_w[14], 16,
+                                    B42_HP, B42_WP, B42_PADY, B42_PADX, false, c->stream, 2));
+        HIPCHK(c, launch_nhwc_s3_to_nchw_f32(plain, n, d_t, 1, c->act_c[layer], c->act_h[layer], c->act_w[layer], c->stream, 2));
     } else if (c->act16[layer])
         HIPCHK(c, launch_nhwc_s3_to_nchw_f32(c->act16[layer] + (size_t)pair * n, (size_t)c->cfg.max_batch * n, d_t, 1, c->act_c[layer],
                                              c->act_h[layer], c->act_w[layer], c->stream,

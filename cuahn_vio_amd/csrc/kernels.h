@@ -47,6 +47,7 @@ inline bool conv_is_first_s2(int layer) { return layer == 0 || layer == 3; }
 hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag, const float* bias, uint16_t* out16, size_t o_plane, int batch,
                                 hipStream_t s, int n_planes = 3);
 // block_4_0 + block_4_1 in one launch (conv_b4_fused.h): x_in = the padded 16-bit planes B4_* below (x_plane dwords per plane)
+// flags: bit 0 walk the tiles from the end, bit 4 plain tile order, bit 5 the 7 x 32 tiles of rounds 2 - 3, bit 6 write the bordered B42_* layout (fp16-plane mode)
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */, int n_planes = 3);
 // block_3_0 + block_3_1 in one launch (conv_b3_fused.h), fp16-plane mode (n_planes == 2) only: x_in fp32 NHWC [B][112][160][2] (the block's prep output),
@@ -76,6 +77,15 @@ hipError_t launch_heads_fc1(const float* feat, int batch, int n_local, int s_beg
 // The border (never written after the allocation was zeroed) IS the zero padding of block_4_0, and the patch of every tile
 // starts at a column that is a multiple of 4 dwords (16-byte chunks for the LDS-DMA) while staying an odd pixel column.
 constexpr int B4_PADX = 5, B4_PADY = 5, B4_WP = 336, B4_HP = 235;
+// Input of the fused block_4_2 + block_4_3 kernel (conv_b42_fused.h, round 4: LDS-DMA staging) = output of the fused block-4 kernel in the fp16-plane mode:
+// block_4_1's map as fp16 planes with a zero border, [plane][B][B42_HP][B42_WP][16 ch]; pixel (x, y) at row y + B42_PADY, column x + B42_PADX.  The border (never
+// written after the allocation was zeroed) IS block_4_2's zero padding: the 19 x 35-pixel patch of every tile lies inside the array, no bounds logic in the copy.
+constexpr int B42_PADX = 3, B42_PADY = 3, B42_WP = 164, B42_HP = 115;
+constexpr size_t B42_IMG = (size_t)B42_HP * B42_WP;             // pixels per pair and plane
+// fp16 / bf16 planes [np][B][h][w][c] (src_plane elements per plane) <-> the same with a border: dst pixel (x, y) of src at (y + pady) wp + x + padx of an hp x wp image.
+// to_padded = false copies the interior back.  c a multiple of 8.  (inspection / test paths; the forward writes the padded form directly)
+hipError_t launch_s3_repitch(const uint16_t* src, size_t src_plane, uint16_t* dst, size_t dst_plane, int batch, int h, int w, int c, int hp, int wp, int pady,
+                             int padx, bool to_padded, hipStream_t s, int n_planes);
 // fp16-plane mode, phase 2 of that kernel: filter tap (kh * 5 + kw) of lane group g in MFMA step st; -1 = no tap (zero weights, the group re-reads its neighbour's
 // pixels).  Groups (0, 1) and (2, 3) are served together by ds_read_b128: they hold taps of ONE kernel column, whose pixels are whole image rows (a multiple of
 // 256 bytes) apart - conflict-free; kernel row 4 has no partner (steps 5, 6).  Shared by the kernel's address setup and hnet_create's fragment packing.

@@ -180,6 +180,32 @@ hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int ba
     return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, wfrag, tile);
 }
 
+// 16-byte chunks of [np][B][h][w][c] planes to / from the interior of a bordered [np][B][hp][wp][c] array
+__global__ void s3_repitch_kernel(const uint16_t* __restrict__ src, size_t src_plane, uint16_t* __restrict__ dst, size_t dst_plane, int batch, int h, int w, int cch,
+                                  int hp, int wp, int pady, int padx, int to_padded, int n_planes) {
+    const long n = (long)n_planes * batch * h * w * cch;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = (int)(i % cch);
+    long r = i / cch;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h); r /= h;
+    const int b = (int)(r % batch);
+    const int pl = (int)(r / batch);
+    const size_t plain = (size_t)pl * (to_padded ? src_plane : dst_plane) + ((((size_t)b * h + y) * w + x) * cch + ch) * 8;
+    const size_t padded = (size_t)pl * (to_padded ? dst_plane : src_plane) + ((((size_t)b * hp + y + pady) * wp + x + padx) * cch + ch) * 8;
+    if (to_padded) *reinterpret_cast<u32x4*>(dst + padded) = *reinterpret_cast<const u32x4*>(src + plain);
+    else *reinterpret_cast<u32x4*>(dst + plain) = *reinterpret_cast<const u32x4*>(src + padded);
+}
+hipError_t launch_s3_repitch(const uint16_t* src, size_t src_plane, uint16_t* dst, size_t dst_plane, int batch, int h, int w, int c, int hp, int wp, int pady,
+                             int padx, bool to_padded, hipStream_t s, int n_planes) {
+    if (c % 8) return hipErrorInvalidValue;
+    const long n = (long)n_planes * batch * h * w * (c / 8);
+    hipLaunchKernelGGL(s3_repitch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_plane, dst, dst_plane, batch, h, w, c / 8, hp, wp, pady, padx,
+                       to_padded ? 1 : 0, n_planes);
+    return hipGetLastError();
+}
+
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes) {
     const long n = (long)batch * c * h * w;
     hipLaunchKernelGGL(nchw_f32_to_nhwc_s3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, o_plane, batch, c, h * w, n_planes);

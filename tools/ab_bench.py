@@ -38,7 +38,8 @@ def main():
         env = json.loads(v)
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
-        engs.append(HnetEngine(blob, variant=a.variant, mc_samples=a.mc, dropout_p=0.05, mc_seed=1, max_batch=B, precision=a.precision))
+        # (AB_DROPOUT_P inside a variant's JSON: the MC-dropout probability of that engine - data-dependence of the heads GEMM, not a library switch)
+        engs.append(HnetEngine(blob, variant=a.variant, mc_samples=a.mc, dropout_p=float(env.get("AB_DROPOUT_P", 0.05)), mc_seed=1, max_batch=B, precision=a.precision))
         for k, o in old.items():
             if o is None: del os.environ[k]
             else: os.environ[k] = o

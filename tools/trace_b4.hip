@@ -35,7 +35,7 @@ int main() {
     const unsigned grid = std::getenv("B4_GRID") ? std::atoi(std::getenv("B4_GRID")) : 512;      // 256: one workgroup per CU (do the two of a CU overlap?)
 #ifdef HNET_B4_TRACE
     unsigned long long* tr;
-    const size_t n = 8 * 4 * 32 * 6;
+    const size_t n = 8 * 4 * 7;
     CK(hipMalloc(&tr, n * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_b4_trace), &tr, sizeof(tr)));
 #endif
@@ -57,21 +57,16 @@ int main() {
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> t(n);
         CK(hipMemcpy(t.data(), tr, n * 8, hipMemcpyDeviceToHost));
-        std::printf("s_memtime ticks (100 MHz domain x clock ratio; relative numbers), average over tiles 4..30 of a workgroup\n");
-        std::printf("wg wave | wait patch+barrier | phase 1 regular | leftover+drain | barrier | phase 2 | total per tile\n");
+        std::printf("shader clocks per tile (sums over the tiles of a workgroup, from its third tile on, / tiles)\n");
+        std::printf("wg wave | loop top | wait patch+barrier | phase 1 regular | leftover+drain | barrier | phase 2 | total per tile\n");
         for (int wg = 0; wg < 8; wg++)
             for (int w = 0; w < 4; w++) {
-                double ph[6] = {};
-                int cnt = 0;
-                for (int tl = 4; tl < 30; tl++) {
-                    const unsigned long long* a = &t[((size_t)(wg * 4 + w) * 32 + tl) * 6];
-                    const unsigned long long* nx = a + 6;
-                    if (!a[5] || !nx[0]) continue;
-                    for (int k = 0; k < 5; k++) ph[k] += (double)(a[k + 1] - a[k]);
-                    ph[5] += (double)(nx[0] - a[0]);
-                    cnt++;
-                }
-                if (cnt) std::printf("%2d %4d | %8.0f | %8.0f | %8.0f | %8.0f | %8.0f | %8.0f\n", wg, w, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, ph[5] / cnt);
+                const unsigned long long* a = &t[(size_t)(wg * 4 + w) * 7];
+                const double cnt = (double)a[6];
+                if (cnt < 1) continue;
+                double tot = 0;
+                for (int k = 0; k < 6; k++) tot += (double)a[k];
+                std::printf("%2d %4d | %6.0f | %8.0f | %8.0f | %8.0f | %8.0f | %8.0f | %8.0f\n", wg, w, a[0] / cnt, a[1] / cnt, a[2] / cnt, a[3] / cnt, a[4] / cnt, a[5] / cnt, tot / cnt);
             }
     }
 #endif
