@@ -32,6 +32,13 @@
 
 namespace hnet {
 
+#ifdef HNET_B3_TRACE            // tools/trace_b3.hip: cycles per phase (s_memtime), summed in registers over the tiles of a workgroup and written once at the end
+__device__ unsigned long long* g_b3_trace;
+#define B3_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (tile_no > 1) tr_acc[k] += now_ - tr_prev; tr_prev = now_; } while (0)
+#else
+#define B3_T(k) do { } while (0)
+#endif
+
 struct B3Cfg {
     static constexpr int TH = 8, TW = 16, THREADS = 256;
     static constexpr int H0 = 112, W0 = 160, H1 = 56, W1 = 80, C0 = 16, C1 = 32;
@@ -47,7 +54,8 @@ struct B3Cfg {
     static constexpr int IPLANEB = RH * IROWB;
     static constexpr int NP = 2;
     static constexpr int LDS_BYTES = NP * (PPLANEB + IPLANEB);   // patch + image (the kernel adds W0_BYTES of weight fragments behind them)
-    static constexpr int W0_BYTES = 7 * 2 * 64 * 16;
+    static constexpr int SPARE_BYTES = 64;                       // target of the stores of lanes that hold no pixel (phase-1 epilogue)
+    static constexpr int W0_BYTES = 7 * 3 * 64 * 16;             // block_3_0's fragments in the three-plane fp16 form (one accumulator per value: s3_mfma16)
     static constexpr int TILES_X = W1 / TW, TILES_Y = H1 / TH;   // 5 x 7 tiles per pair
     static constexpr int N_MT0 = 12;                             // phase-1 M-tiles: 10 pairs of rows + 2 tiles for the pixel pairs of columns 32..34
     static constexpr int NSTEP1 = 13;                            // phase-2 K steps (two taps each; the 26th tap has zero weights)
@@ -79,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
     // block_3_1's 104 registers stay; block_3_0's fragments (14 x 1 KiB) live in LDS and are read per kernel row (the two sets together
     // with both phases' accumulators do not fit 256 registers: 33 dwords of scratch in the first version)
     f16x8 w1[C::NSTEP1][2];
-    u32x4* const w0s = reinterpret_cast<u32x4*>(lds_raw + C::LDS_BYTES);     // [7][2][64] x 16 B, lane-linear
-    for (int i = tid; i < 7 * 2 * 64; i += 256) w0s[i] = w0frag[i];
+    u32x4* const w0s = reinterpret_cast<u32x4*>(lds_raw + C::LDS_BYTES);     // [7][3][64] x 16 B, lane-linear
+    for (int i = tid; i < 7 * 3 * 64; i += 256) w0s[i] = w0frag[i];
     const int nt = wave & 1;                                            // phase 2: this wave's half of the 32 output channels
 #pragma unroll
     for (int st = 0; st < C::NSTEP1; st++)
@@ -91,21 +99,26 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
     const int pcol = lane & 31, hh = lane >> 5, prow = pcol >> 4, pair = pcol & 15;
     // D row (r & 3) + 8 (r >> 2) + 4 hh = n: group q = r >> 2 holds channels 8 (q & 1) + 4 hh + i: its four biases = one 16-byte LDS read
     __shared__ __attribute__((aligned(16))) float bias0s[16];
-    if (tid < 16) bias0s[tid] = bias0[tid];
+    if (tid < 16) bias0s[tid] = bias0[tid] * S3_F16_SCALE;             // the accumulator carries 4096 x the sum (one-accumulator form)
     // phase-2 lane roles (16x16x32 transposed: D row 4 g + r = output channel, D column m = pixel of the output row)
     const int m = lane & 15, g = lane >> 4;
-    float bv1[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) bv1[r] = bias1[16 * nt + 4 * g + r];
+    __shared__ __attribute__((aligned(16))) float bias1s[32];           // (read per output row: four registers less across phase 1)
+    if (tid < 32) bias1s[tid] = bias1[tid];
     // lane part of the phase-2 read addresses: pixel column 2 m (+ kw), channel half g & 1; the tap of step st is t = 2 st + (g >> 1) = (kh, kw):
     // its offset is one of two compile-time constants per step (p2tap), selected by g >> 1  (t = 25 has zero weights: any valid address)
     // the two 16-byte chunks of a pixel are SWAPPED where (x / 2 >> 2) & 1 (bank model, tools/lds_bank_model.py: the 16 lanes of a phase-1 store group
     // then hit 2 instead of 4 addresses per bank, the phase-2 reads stay conflict free): the lane offset depends on the tap's kw >> 1 = 0, 1, 2
-    const uint32_t p2l0 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ ((m >> 2) & 1)));
-    const uint32_t p2l1 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ (((m + 1) >> 2) & 1)));
-    const uint32_t p2l2 = (uint32_t)(m * 32 + 16 * ((g & 1) ^ (((m + 2) >> 2) & 1)));
-    const bool ghi = (g >> 1) != 0;
-    auto p2tap = [](int t) constexpr { const int tt = t < 24 ? t : 24; const int kh = tt / 5, kw = tt - 5 * kh; return kh * C::IROWB + ((kw & 1) * C::XH + (kw >> 1)) * 32; };
+    // phase 1: this lane's patch address for the three M-tiles of its wave (mt = wave + 4 j): region row and pixel pair as in the epilogue
+    uint32_t p1a[C::N_MT0 / 4];                                          // byte offsets into lds_raw (32-bit: registers are short in phase 1)
+#pragma unroll
+    for (int j = 0; j < C::N_MT0 / 4; j++) {
+        const int mt = wave + 4 * j;
+        int row, pr2;
+        if (mt < 10) { row = mt < 8 ? mt + 8 * prow : 2 * mt + prow; pr2 = pair; }
+        else { const int idx = (mt - 10) * 32 + pcol; row = idx >> 1; pr2 = 16 + (idx & 1); }
+        const int rrow = row < RH ? row : RH - 1;                       // (rows beyond the region: reads stay inside the patch, nothing is stored)
+        p1a[j] = (uint32_t)(rrow * PROWB + pr2 * 8 + 16 * hh);
+    }
     int hi4 = 8;                                                        // opaque byte offset: two ds_read_b64 instead of one ds_read2_b64 (conv_first.h)
     asm volatile("" : "+v"(hi4));
 
@@ -137,7 +150,11 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
     };
     if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
 
+    [[maybe_unused]] int tile_no = -1;
+    [[maybe_unused]] unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_prev = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_no++;
+        B3_T(0);
         int b, ty, tx;
         tile_origin(tile, b, ty, tx);
         const int ty0 = ty * TH, tx0 = tx * TW;
@@ -158,87 +175,166 @@ __global__ __launch_bounds__(256, 2) void block3_fused_kernel(const float* __res
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phases 1 and 2
+        B3_T(1);
 
         // ---- phase 1: block_3_0 over the region -> LDS image.  M-tile mt < 8: region rows mt, mt + 8, pixel pairs 0..15; mt = 8: rows 16, 17;
-        //      mt = 9: row 18 (+ an unused one); mt = 10, 11: the pairs 16, 17 (columns 32..35) of all rows, 32 (row, pair) combinations each
-#pragma unroll 1
-        for (int j = 0; j < C::N_MT0 / 4; j++) {
-            const int mt = wave + 4 * j;                                // wave-uniform
-            int row, pr2;                                               // this lane's region row and pixel pair
-            if (mt < 10) { row = mt < 8 ? mt + 8 * prow : 2 * mt + prow; pr2 = pair; }
-            else { const int idx = (mt - 10) * 32 + pcol; row = idx >> 1; pr2 = 16 + (idx & 1); }
-            const bool row_ok = row < RH;
-            const int rrow = row_ok ? row : RH - 1;                     // (rows beyond the region: reads stay inside the patch, nothing is stored)
-            f32x16 hi, lo;
+        //      mt = 9: row 18 (+ an unused one); mt = 10, 11: the pairs 16, 17 (columns 32..35) of all rows, 32 (row, pair) combinations each.
+        // Software pipeline over the 3 x 7 kernel-row steps of a wave (round 4; compiled as a loop a step was "six reads, lgkmcnt(0), three MFMAs" and the
+        // epilogue of an M-tile - 120 vector instructions - ran with nothing beside it: 2900 cycles per M-tile for 672 cycles of MFMA, tools/trace_b3.hip):
+        // a ring of three steps (activation fragment pair + the three weight fragments, read from LDS), step s + 2 is read while step s multiplies; one
+        // accumulator per value (the three-plane form of s3_mfma16: the accumulator carries 4096 x the sum), two accumulator sets, so that the epilogue of
+        // M-tile j sits in the shadows of the MFMAs of M-tile j + 1.
+        {
+            constexpr int NJ = C::N_MT0 / 4, NS1 = 7 * NJ, RING = 3, RINGW = 2;
+            bf16x4_t fal[RING][2], fah[RING][2];                         // 8 fp16 = 4 taps x 2 ch per plane, as two 8-byte reads
+            f16x8 fw[RINGW][3];                                          // weight fragments: one step ahead (registers), activations two
+            f32x16 acc[2];
+            auto rdA = [&](int sg) {
+                const int j = sg / 7, kh = sg - 7 * j, sl = sg % RING;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4_m16 bq = *reinterpret_cast<const f32x4_m16*>(&bias0s[8 * (q & 1) + 4 * hh]);
+                for (int pl = 0; pl < 2; pl++) {
+                    const unsigned char* src = patch + p1a[j] + pl * PPLANEB + kh * PROWB;
+                    fal[sl][pl] = *reinterpret_cast<const bf16x4_t*>(src);
+                    fah[sl][pl] = *reinterpret_cast<const bf16x4_t*>(src + hi4);
+                }
+            };
+            auto rdW = [&](int sg) {
+                const int kh = sg % 7;
 #pragma unroll
-                for (int i = 0; i < 4; i++) { hi[4 * q + i] = bq[i]; lo[4 * q + i] = 0.f; }
-            }
-            const unsigned char* abase = patch + rrow * PROWB + pr2 * 8 + 16 * hh;
+                for (int pl = 0; pl < 3; pl++) fw[sg % RINGW][pl] = __builtin_bit_cast(f16x8, w0s[(kh * 3 + pl) * 64 + lane]);
+            };
+            auto epi1 = [&](int j) {
+                const int set = j & 1;
+                const int mt = wave + 4 * j;                            // wave-uniform
+                int row, pr2;                                           // this lane's region row and pixel pair
+                if (mt < 10) { row = mt < 8 ? mt + 8 * prow : 2 * mt + prow; pr2 = pair; }
+                else { const int idx = (mt - 10) * 32 + pcol; row = idx >> 1; pr2 = 16 + (idx & 1); }
+                const bool row_ok = row < RH;
+                // D row 8 q + 4 hh + i = (dx = q >> 1, co = 8 (q & 1) + 4 hh + i): a lane holds four consecutive channels of pixel 2 pr2 + dx
+                const int iy = Ry0 + row;
 #pragma unroll
-            for (int kh = 0; kh < 7; kh++) {
+                for (int q = 0; q < 4; q++) {
+                    const int dx = q >> 1, col = 2 * pr2 + dx;
+                    const bool ok = (unsigned)iy < (unsigned)H0 && (unsigned)(Rx0 + col) < (unsigned)W0;
+                    uint32_t pa[3], pb[3];
+                    s3p::act_split<2>(acc[set][4 * q], acc[set][4 * q + 1], pa, ok);
+                    s3p::act_split<2>(acc[set][4 * q + 2], acc[set][4 * q + 3], pb, ok);
+                    // (no branch - it would end the scheduling region the epilogue is interleaved in: lanes without a pixel store to a spare slot behind the weights)
+                    const bool st_ok = row_ok && pr2 < XH;
+                    unsigned char* dst = st_ok ? img + ((row * 2 + dx) * XH + pr2) * 32 + 16 * ((q & 1) ^ ((pr2 >> 2) & 1)) + 8 * hh
+                                               : lds_raw + C::LDS_BYTES + C::W0_BYTES + 8 * hh - IPLANEB * 0;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);
+                    *reinterpret_cast<uint2*>(st_ok ? dst + IPLANEB : dst + 16) = make_uint2(pa[1], pb[1]);
+                }
+            };
+            rdA(0); rdW(0); rdA(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sg = 0; sg < NS1; sg++) {
+                const int j = sg / 7, kh = sg - 7 * j, set = j & 1, sl = sg % RING;
+                if (kh == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f32x4_m16 bq = *reinterpret_cast<const f32x4_m16*>(&bias0s[8 * (q & 1) + 4 * hh]);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) acc[set][4 * q + i] = bq[i];
+                    }
+                }
+                if (sg + 2 < NS1) rdA(sg + 2);
+                if (sg + 1 < NS1) rdW(sg + 1);
                 f16x8 a[2];
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++) {                        // 8 fp16 = 4 taps x 2 ch, 8-byte aligned
-                    const unsigned char* src = abase + pl * PPLANEB + kh * PROWB;
-                    const bf16x4_t l4 = *reinterpret_cast<const bf16x4_t*>(src);
-                    const bf16x4_t h4 = *reinterpret_cast<const bf16x4_t*>(src + hi4);
-                    a[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-                const f16x8 wk0 = __builtin_bit_cast(f16x8, w0s[(kh * 2 + 0) * 64 + lane]), wk1 = __builtin_bit_cast(f16x8, w0s[(kh * 2 + 1) * 64 + lane]);
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk0, a[1], lo, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk1, a[0], lo, 0, 0, 0);
-                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(wk0, a[0], hi, 0, 0, 0);
-            }
-            // D row 8 q + 4 hh + i = (dx = q >> 1, co = 8 (q & 1) + 4 hh + i): a lane holds four consecutive channels of pixel 2 pr2 + dx
-            const int iy = Ry0 + row;
+                for (int pl = 0; pl < 2; pl++) a[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(fal[sl][pl], fah[sl][pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[sg % RINGW][2], a[1], acc[set], 0, 0, 0);       // W2 A1 + W1 A0 + W0 A0 = 4096 a w, smallest first
+                acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[sg % RINGW][1], a[0], acc[set], 0, 0, 0);
+                acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[sg % RINGW][0], a[0], acc[set], 0, 0, 0);
+                if (kh == 0 && j > 0) epi1(j - 1);                      // scheduled into the shadows of this M-tile's MFMAs (groups below)
+                if (sg + 2 < NS1) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+                else if (sg + 1 < NS1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int dx = q >> 1, col = 2 * pr2 + dx;
-                const bool ok = (unsigned)iy < (unsigned)H0 && (unsigned)(Rx0 + col) < (unsigned)W0;
-                // u = 4096 hi + lo is the accumulator of the one-accumulator form (4096 x the sum): the packed LeakyReLU + split of s3p::act_split
-                uint32_t pa[3], pb[3];
-                s3p::act_split<2>(fmaf(hi[4 * q], S3_F16_SCALE, lo[4 * q]), fmaf(hi[4 * q + 1], S3_F16_SCALE, lo[4 * q + 1]), pa, ok);
-                s3p::act_split<2>(fmaf(hi[4 * q + 2], S3_F16_SCALE, lo[4 * q + 2]), fmaf(hi[4 * q + 3], S3_F16_SCALE, lo[4 * q + 3]), pb, ok);
-                if (row_ok && pr2 < XH) {
-                    unsigned char* dst = img + ((row * 2 + dx) * XH + pr2) * 32 + 16 * ((q & 1) ^ ((pr2 >> 2) & 1)) + 8 * hh;
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);
-                    *reinterpret_cast<uint2*>(dst + IPLANEB) = make_uint2(pa[1], pb[1]);
+                for (int q = 0; q < 3; q++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (j > 0) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                 }
+                if (j > 0 && kh > 0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                if (kh == 6) __builtin_amdgcn_sched_barrier(0);
             }
+            epi1(NJ - 1);
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + gridDim.x);   // in flight during phase 2 (its ten registers are not live in phase 1, which is short of them)
+        B3_T(2);
 
-        // ---- phase 2: block_3_1 from the LDS image.  This wave: channels 16 nt .. + 15, output rows (wave >> 1) + 2 j (j = 0..3), one row
-        //      (M-tile) at a time: the weights of all 13 steps sit in registers
-#pragma unroll 1
-        for (int j = 0; j < 4; j++) {
-            const int oy = (wave >> 1) + 2 * j;
-            f32x4_m16 hi = f32x4_m16{bv1[0], bv1[1], bv1[2], bv1[3]}, lo = f32x4_m16{0.f, 0.f, 0.f, 0.f};
-            const unsigned char* ibase = img + (2 * oy) * IROWB;             // image row 2 oy; the lane's pixel column and (swapped) channel half: p2l*
-#pragma unroll
-            for (int st = 0; st < C::NSTEP1; st++) {
-                const int tA = 2 * st < 24 ? 2 * st : 24, tB = 2 * st + 1 < 24 ? 2 * st + 1 : 24;   // (compile-time after unrolling)
-                const int kA = (tA % 5) >> 1, kB = (tB % 5) >> 1;
-                const uint32_t off = ghi ? (uint32_t)p2tap(tB) + (kB == 0 ? p2l0 : kB == 1 ? p2l1 : p2l2) : (uint32_t)p2tap(tA) + (kA == 0 ? p2l0 : kA == 1 ? p2l1 : p2l2);
-                const f16x8 a0 = *reinterpret_cast<const f16x8*>(ibase + off);
-                const f16x8 a1 = *reinterpret_cast<const f16x8*>(ibase + off + IPLANEB);
-                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a1, lo, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][1], a0, lo, 0, 0, 0);
-                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], a0, hi, 0, 0, 0);
+        // ---- phase 2: block_3_1 from the LDS image.  This wave: channels 16 nt .. + 15, output rows (wave >> 1) + 2 j (j = 0..3), one row (M-tile) at a time: the
+        //      weights of all 13 steps sit in registers.  Software pipeline (round 4; compiled as a loop every step was "two reads, lgkmcnt(0), three MFMAs": ~180
+        //      cycles for 48 cycles of MFMA): a ring of four fragment pairs, the pair of step s + 4 is read into the slot step s has just consumed - across the four
+        //      M-tiles - and every address is a lane-invariant register (p2a[step]) plus an instruction immediate (row, plane).
+        {
+            constexpr int NS = C::NSTEP1, RING = 4, NMT = 4;
+            // the thirteen lane addresses are rebuilt per tile (13 x 4 vector instructions): kept across the tile loop they cost phase 1 thirteen registers it does not have
+            int zero_op = 0;
+            asm volatile("" : "+v"(zero_op));
+            auto p2tap = [](int t) constexpr { const int tt = t < 24 ? t : 24; const int kh = tt / 5, kw = tt - 5 * kh; return kh * C::IROWB + ((kw & 1) * C::XH + (kw >> 1)) * 32; };
+            const unsigned char* p2a[C::NSTEP1];                                // step st: lane groups 0, 1 read tap 2 st, groups 2, 3 tap 2 st + 1 (tap 25 has zero weights)
+            {
+                const bool ghi = (g >> 1) != 0;
+        #pragma unroll
+                for (int st = 0; st < C::NSTEP1; st++) {
+                    const int tA = 2 * st < 24 ? 2 * st : 24, tB = 2 * st + 1 < 24 ? 2 * st + 1 : 24;
+                    const int kw = ghi ? tB % 5 : tA % 5;
+                    const uint32_t lanepart = (uint32_t)(m * 32 + 16 * ((g & 1) ^ (((m + (kw >> 1)) >> 2) & 1)));
+                    p2a[st] = img + (2 * (wave >> 1)) * IROWB + zero_op + (ghi ? p2tap(tB) : p2tap(tA)) + lanepart;
+                }
             }
-            // D (transposed): row 4 g + r = output channel 16 nt + 4 g + r, column m = pixel: 8 bytes (4 channels) per lane and plane
-            uint32_t pa[3], pb[3];
-            s3p::act_split<2>(fmaf(hi[0], S3_F16_SCALE, lo[0]), fmaf(hi[1], S3_F16_SCALE, lo[1]), pa);
-            s3p::act_split<2>(fmaf(hi[2], S3_F16_SCALE, lo[2]), fmaf(hi[3], S3_F16_SCALE, lo[3]), pb);
-            uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
-            *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
-            *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);
+            f16x8 fb[RING][2];
+            f32x4_m16 hi2[2], lo2[2];
+            auto rd2 = [&](int sg) {                                         // sg = 13 j + st
+                const int j = sg / NS, st = sg - NS * j;
+                const unsigned char* src = p2a[st] + (4 * j) * IROWB;         // image row 2 (oy = (wave >> 1) + 2 j): the wave's part is in p2a
+                fb[sg % RING][0] = *reinterpret_cast<const f16x8*>(src);
+                fb[sg % RING][1] = *reinterpret_cast<const f16x8*>(src + IPLANEB);
+            };
+            auto epi2 = [&](int j) {
+                const int set = j & 1;
+                const int oy = (wave >> 1) + 2 * j;
+                // D (transposed): row 4 g + r = output channel 16 nt + 4 g + r, column m = pixel: 8 bytes (4 channels) per lane and plane
+                uint32_t pa[3], pb[3];
+                s3p::act_split<2>(fmaf(hi2[set][0], S3_F16_SCALE, lo2[set][0]), fmaf(hi2[set][1], S3_F16_SCALE, lo2[set][1]), pa);
+                s3p::act_split<2>(fmaf(hi2[set][2], S3_F16_SCALE, lo2[set][2]), fmaf(hi2[set][3], S3_F16_SCALE, lo2[set][3]), pb);
+                uint16_t* o = out16 + ((((size_t)b * H1 + ty0 + oy) * W1 + tx0 + m) * C::C1 + 16 * nt + 4 * g);
+                *reinterpret_cast<uint2*>(o) = make_uint2(pa[0], pb[0]);
+                *reinterpret_cast<uint2*>(o + o_plane) = make_uint2(pa[1], pb[1]);
+            };
+#pragma unroll
+            for (int sg = 0; sg < RING; sg++) rd2(sg);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NMT; j++) {
+                const int set = j & 1;
+                hi2[set] = *reinterpret_cast<const f32x4_m16*>(&bias1s[16 * nt + 4 * g]);
+                lo2[set] = f32x4_m16{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < NS; st++) {
+                    const int sg = NS * j + st;
+                    lo2[set] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], fb[sg % RING][1], lo2[set], 0, 0, 0);
+                    lo2[set] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][1], fb[sg % RING][0], lo2[set], 0, 0, 0);
+                    hi2[set] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[st][0], fb[sg % RING][0], hi2[set], 0, 0, 0);
+                    if (sg + RING < NS * NMT) rd2(sg + RING);
+                    if (j > 0 && st == 0) epi2(j - 1);                      // the previous row's epilogue sits in the shadows of this row's first MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    if (sg + RING < NS * NMT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (j > 0 && st < 8) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            epi2(NMT - 1);
         }
+        B3_T(3);
     }   // persistent tile loop
+#ifdef HNET_B3_TRACE
+    if (blockIdx.x < 8 && lane == 0) for (int k = 0; k < 4; k++) g_b3_trace[(blockIdx.x * 4 + wave) * 5 + k] = tr_acc[k];
+    if (blockIdx.x < 8 && lane == 0) g_b3_trace[(blockIdx.x * 4 + wave) * 5 + 4] = (unsigned long long)(tile_no - 1);
+#endif
 }
 
 }  // namespace hnet

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void block42_fused_kernel(const uint16_t* _
                 uint32_t pa[3], pb[3];
                 s3p::act_split<2>(fmaf(hi[set][0], S3_F16_SCALE, lo[set][0]), fmaf(hi[set][1], S3_F16_SCALE, lo[set][1]), pa, ok);
                 s3p::act_split<2>(fmaf(hi[set][2], S3_F16_SCALE, lo[set][2]), fmaf(hi[set][3], S3_F16_SCALE, lo[set][3]), pb, ok);
-                if (reg || m < RH) {
+                {   // (no branch - it would end the scheduling region: the lanes m >= RH of the column-16 M-tile repeat row RH - 1, same address, same value)
                     const int xh = col >> 1;
                     unsigned char* dst = img + row * IROWB + ((col & 1) * XHR + xh) * 64 + 16 * ((2 * nt1 + (g >> 1) + ((xh >> 1) & 3)) & 3) + 8 * (g & 1);
                     *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pb[0]);

@@ -412,7 +412,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             if (c->fuse_b3 && l == 7 && c->n_planes == 2 && c->b3f_w0 && c->b3f_w1 && h == 112 && w == 160) {   // block_3_0 + block_3_1 in one launch
                 const size_t cnt1 = c->act_count[8];
                 uint16_t* o16b = c->act16[8] + P0 * cnt1;
-                STAGE(launch_block3_fused(in, c->b3f_w0, c->conv_b[7], c->b3f_w1, c->conv_b[8], o16b, MB * cnt1, B, s, c->n_planes));
+                STAGE(launch_block3_fused(in, c->b30_frag, c->conv_b[7], c->b3f_w1, c->conv_b[8], o16b, MB * cnt1, B, s, c->n_planes));
                 in = nullptr; in16 = o16b; in_plane = MB * cnt1;
                 h = c->act_h[8]; w = c->act_w[8];
                 l = 8;
@@ -1594,7 +1594,7 @@ int hnet_op_block3_fused(hnet_ctx* c, const float* in, int batch, float* out) {
     HIPCHK(c, t.alloc(&d_a, n_in)); HIPCHK(c, t.alloc(&d_b, n_in)); HIPCHK(c, t.alloc(&d_d, n_out)); HIPCHK(c, t.alloc(&p_out, 3 * n_out + 32));
     HIPCHK(c, hipMemcpy(d_a, in, n_in * 4, hipMemcpyHostToDevice));
     HIPCHK(c, launch_nchw_to_nhwc(d_a, d_b, batch, 2, h0, w0, c->stream));
-    HIPCHK(c, launch_block3_fused(d_b, c->b3f_w0, c->conv_b[7], c->b3f_w1, c->conv_b[8], p_out, n_out, batch, c->stream, c->n_planes));
+    HIPCHK(c, launch_block3_fused(d_b, c->b30_frag, c->conv_b[7], c->b3f_w1, c->conv_b[8], p_out, n_out, batch, c->stream, c->n_planes));
     HIPCHK(c, launch_nhwc_s3_to_nchw_f32(p_out, n_out, d_d, batch, 32, h0 / 2, w0 / 2, c->stream, c->n_planes));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_d, n_out * 4, hipMemcpyDeviceToHost));

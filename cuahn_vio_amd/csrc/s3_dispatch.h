@@ -190,7 +190,7 @@ hipError_t launch_block3_fused_np(const float* x_in, const void* w0frag, const f
     if constexpr (NP != 2) return hipErrorInvalidValue;
     else {
         const int n_tiles = batch * B3Cfg::TILES_X * B3Cfg::TILES_Y;
-        hipLaunchKernelGGL(block3_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
+        hipLaunchKernelGGL(block3_fused_kernel<NP>, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES + B3Cfg::SPARE_BYTES, s, x_in, (const u32x4*)w0frag, bias0,
                            (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles);
         return hipGetLastError();
     }
@@ -388,7 +388,7 @@ hipError_t conv_kernels_init_device_np() {
 #undef HNET_REGION_ATTR
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_heads_pipe_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadsPipeCfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES + B3Cfg::SPARE_BYTES);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
