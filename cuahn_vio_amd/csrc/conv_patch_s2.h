@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
                 }
                 acc = s3_mfma16<NP>(acc, wv[st], a);
             }
+            // schedule (round 4): the M-tile's fragment reads first, then its MFMAs - left to itself the scheduler put every step's reads directly in front of its
+            // MFMAs and waited lgkmcnt(0) per step (conv_b42_fused.h has the measurement)
+            __builtin_amdgcn_sched_group_barrier(0x100, NP * NSTEP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (NP == 3 ? 6 : NP == 2 ? 3 : 1) * NSTEP, 0);
             // D (transposed): row 4g + r = cout 16 nt + 4g + r, column m = pixel: 8 bytes per lane and plane straight to global memory
             // (forming whole 128-byte lines through LDS first, the four waves' quarters together, measured 0.1028 vs 0.1004 ms: not worth
             // the two extra barriers per tile)
@@ -343,6 +347,142 @@ __global__ __launch_bounds__(256, 2) void conv_patch32_s2_kernel(const uint16_t*
             uint16_t* o = ob + (size_t)(oy * Wo + ox) * 64;
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4, fp16-plane mode: the same layer with the NEXT tile's region in flight during the MFMA phase.  conv_patch32_s2_kernel loads a
+// tile's 47 KB region and waits for it before every MFMA phase: 15 700 cycles per tile for 2160 cycles of MFMA (0.055 ms at batch 256, two
+// workgroups per CU cover only part of each other's waits).  Here the 21 buffer loads of tile t + 1 are issued right after tile t's region
+// has been written to LDS and stay in flight (84 registers) under tile t's MFMAs.  To afford them the weights are held in the two-plane /
+// two-accumulator form (planes 2 = W0 and 1 = W1 of the packed one-accumulator fragments: 72 registers instead of 108; hi += W0 A0,
+// lo += W0 A1 + W1 A0, result 4096 hi + lo - the arithmetic of the fused kernels) and the fragment reads of an M-tile are scheduled in two groups.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void conv_patch32_s2_pf_kernel(const uint16_t* __restrict__ in, size_t i_plane,
+                                                                     const u32x4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                     uint16_t* __restrict__ out16, size_t o_plane, int n_tiles, int reverse) {
+    static_assert(NP == 2, "fp16-plane mode");
+    typedef Patch32Cfg<NP> C;
+    constexpr int TH = C::TH, TW = C::TW, MT = C::MT, RH = C::RH, RW = C::RW, XH = C::XH, ROW = C::ROW, PLANE = C::PLANE, NSTEP = C::NSTEP;
+    constexpr int H = 56, W = 80, Ho = 28, Wo = 40, tiles_x = Wo / TW, tiles_y = Ho / TH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint16_t* img = reinterpret_cast<uint16_t*>(lds_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int nt = wave;
+
+    f16x8 wv[NSTEP][2];                                  // [step][W0, W1]
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+        wv[st][0] = __builtin_bit_cast(f16x8, wfrag[((nt * NSTEP + st) * 3 + 2) * 64 + lane]);
+        wv[st][1] = __builtin_bit_cast(f16x8, wfrag[((nt * NSTEP + st) * 3 + 1) * 64 + lane]);
+    }
+    f32x4_p bv;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bv[r] = bias[nt * 16 + 4 * g + r];
+
+    auto tap_elem = [](int t) constexpr {
+        const int kh = t / 3, kw = t - kh * 3;
+        return kh * ROW + ((kw & 1) * 4 * XH + (kw >> 1) * 2) * 8;
+    };
+    const int goff = ((g >> 1) * XH * 2 + (g & 1)) * 8;
+    constexpr int ROW_ITEMS = NP * RW * 4, ITEMS = (ROW_ITEMS + 63) / 64;
+    constexpr int ROWS_PER_WAVE = (RH + 3) / 4;
+
+    auto origin = [&](int tile, int& b, int& ty0, int& tx0) {
+        int bid = s3p::xcd_tile(reverse ? n_tiles - 1 - tile : tile, n_tiles, gridDim.x);
+        const int bx = bid % tiles_x; bid /= tiles_x;
+        const int by = bid % tiles_y;
+        b = bid / tiles_y;
+        ty0 = by * TH; tx0 = bx * TW;
+    };
+    // the region of a tile: [plane][row][column][channel quarter] items of 16 bytes; a wave takes whole region rows (wave + 4 rr), a lane the items lane + 64 q of a row
+    u32x4 buf[ROWS_PER_WAVE][ITEMS];
+    auto issue_loads = [&](int tile) {
+        int b, ty0, tx0;
+        origin(tile, b, ty0, tx0);
+        const int Ry0 = 2 * ty0 - 1, Rx0 = 2 * tx0 - 1;
+        int lv = lane;
+        asm volatile("" : "+v"(lv));                             // the item arithmetic is formed per tile: nothing of it lives across the MFMA phase
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)b * H * W * 32), 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
+            const int pr = wave + 4 * rr;
+            const int iy = Ry0 + pr;
+            const bool row_ok = pr < RH && iy >= 0 && iy < H;
+            const int soff = row_ok ? (iy * W + Rx0) * 64 : 0;      // bytes; Rx0 = -1 for the left tile: the column test below covers it
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const int item = lv + 64 * q;
+                const int it = item < ROW_ITEMS ? item : 0;
+                const int pl = it / (RW * 4), rem = it - pl * (RW * 4), pc = rem >> 2, cq = rem & 3;
+                const uint32_t goff_b = (uint32_t)((pl * i_plane + cq * 8 + (size_t)pc * 32) * 2);
+                const int ix = Rx0 + pc;
+                const bool ok = row_ok && ix >= 0 && ix < W;      // out of the image: an offset beyond the descriptor's range reads zeros
+                buf[rr][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? goff_b + (uint32_t)soff : S3_OOB, 0, 0));
+            }
+        }
+    };
+    auto write_lds = [&]() {
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; rr++) {
+            const int pr = wave + 4 * rr;
+#pragma unroll
+            for (int q = 0; q < ITEMS; q++) {
+                const int item = lv + 64 * q;
+                const int it = item < ROW_ITEMS ? item : 0;
+                const int pl = it / (RW * 4), rem = it - pl * (RW * 4), pc = rem >> 2, cq = rem & 3;
+                const int loff = pl * PLANE + ((pc & 1) * 4 * XH + ((cq >> 1) * XH + (pc >> 1)) * 2 + (cq & 1)) * 8;
+                if (pr < RH && item < ROW_ITEMS) *reinterpret_cast<u32x4*>(&img[pr * ROW + loff]) = buf[rr][q];
+            }
+        }
+    };
+
+    if ((int)blockIdx.x < n_tiles) issue_loads(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int b, ty0, tx0;
+        origin(tile, b, ty0, tx0);
+        __syncthreads();                                         // the previous tile's MFMA phase is done with the region
+        write_lds();
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) issue_loads(tile + gridDim.x);      // in flight during the MFMA phase
+        __builtin_amdgcn_sched_barrier(0);
+
+        uint16_t* const ob = out16 + ((size_t)b * Ho * Wo + (size_t)ty0 * Wo + tx0) * 64 + nt * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            const int pp = 16 * j + m, oy = pp / TW, ox = pp - oy * TW;
+            const int base = 2 * oy * ROW + ox * 16 + goff;
+            f32x4_p hi = bv, lo = f32x4_p{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(&img[base + tap_elem(st)]);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(&img[PLANE + base + tap_elem(st)]);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[st][0], a1, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[st][1], a0, lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[st][0], a0, hi, 0, 0, 0);
+            }
+            // the reads of steps 0 - 4, then MFMAs with the reads of steps 5 - 8 between them (two fragment groups of 40 + 32 registers)
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+            uint32_t pa[3], pb[3];
+            s3p::act_split<NP>(fmaf(hi[0], S3_F16_SCALE, lo[0]), fmaf(hi[1], S3_F16_SCALE, lo[1]), pa);
+            s3p::act_split<NP>(fmaf(hi[2], S3_F16_SCALE, lo[2]), fmaf(hi[3], S3_F16_SCALE, lo[3]), pb);
+            uint16_t* o = ob + (size_t)(oy * Wo + ox) * 64;
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

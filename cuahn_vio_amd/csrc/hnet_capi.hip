@@ -840,7 +840,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b42 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B42);
     c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
     c->a14_pad = c->fuse_b4 && c->fuse_b42;
-    c->patch_rb5 = 5;                  // region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
+    c->patch_rb5 = c->s3_tile == 27 ? -32 : 5;   // (variant 27: block_3_2 on the patch kernel without prefetch, A/B)  region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->patch_b128 = true;
     c->b4_flags = c->s3_tile == 26 ? 32 : 0;       // (variant 26: the 7 x 32 tiles of rounds 2 - 3, A/B)
     c->n_local = g.mc_sample_end - g.mc_sample_begin;

@@ -290,6 +290,13 @@ hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, i
         typedef Patch32Cfg<NP> C;
         const int n_tiles = batch * (28 / C::TH) * (40 / C::TW);
         constexpr int rev = 3;      // (bit 2 = conv_patch32: forward walk)
+        if constexpr (NP == 2) {     // the next tile's region in flight under the MFMAs (rb5 = -32: the round-2 / 3 kernel, A/B)
+            if (rb5 != -32) {
+                hipLaunchKernelGGL((conv_patch32_s2_pf_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
+                                   (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((conv_patch32_s2_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
                            (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
         return hipGetLastError();
