@@ -412,19 +412,15 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
             for (int st = 0; st < 4; st++) {
                 acc = s3_mfma16<NP>(acc, wv[t][st], a[st]);
             }
-            // D (transposed): row 4g + r = channel 4g + r of n-tile wave + 4t, column m = pixel: 8 bytes per lane and plane
-            uint16_t sp[3][4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = s3p::act<NP>(acc[r]);
-                s3p::split1<NP>(v, sp[0][r], sp[1][r], sp[2][r]);
-            }
+            // D (transposed): row 4g + r = channel 4g + r of n-tile wave + 4t, column m = pixel: 8 bytes per lane and plane.  The packed LeakyReLU + split of the
+            // GEMM epilogues (round 4; one value at a time it was twice the vector instructions - and this kernel's vector issue is as long as its stores)
+            uint32_t pa[3], pb[3];
+            s3p::act_split<NP>(acc[0], acc[1], pa);
+            s3p::act_split<NP>(acc[2], acc[3], pb);
             if (store) {
                 uint16_t* o = out16 + opix * COUT + (wave + 4 * t) * 16 + 4 * g;
 #pragma unroll
-                for (int pl = 0; pl < NP; pl++)
-                    *reinterpret_cast<uint2*>(o + pl * o_plane) =
-                        make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
+                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
             }
         }
     }
