@@ -405,18 +405,39 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
             // than 2 R + NP = 15 (NP = 3) operations are outstanding when a wait is issued (this tile's LDS stores included, which only makes
             // a wait conservative: LDS operations complete in order)
             rdF(std::integral_constant<int, 0>{}); rdF(std::integral_constant<int, 1>{});
+            // Round 4: the epilogue of tile j - 1 (bias is in the accumulator: 2 adds, LeakyReLU + plane split of four values, NP stores: ~26 vector instructions
+            // that used to run with nothing beside them) is issued between the first six MFMAs of tile j - two accumulator sets, selected by j & 1.
+            f32x4_t accs[2], accts[2];
+            auto epi = [&](auto jc) {                        // the epilogue proper of tile j: accs / accts [j & 1] -> the S3 image
+                constexpr int j = decltype(jc)::value;
+                f32x4_t acc = accs[j & 1] + accts[j & 1];
+                const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
+                uint32_t pa[3], pb[3];
+#if HNET_B4_ABLATE == 4
+                pa[0] = __builtin_bit_cast(uint32_t, acc[0]); pa[1] = __builtin_bit_cast(uint32_t, acc[1]); pb[0] = __builtin_bit_cast(uint32_t, acc[2]); pb[1] = __builtin_bit_cast(uint32_t, acc[3]) + ok;
+#else
+                s3p::act_split<NP>(acc[0], acc[1], pa, ok);
+                s3p::act_split<NP>(acc[2], acc[3], pb, ok);
+#endif
+                constexpr int JW = HW * j * 2 * XH * 16;
+                static_for<NP>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    wr64<JW + pl * PLANE * 2>(st1a, make_uint2(pa[pl], pb[pl]));
+                });
+            };
             static_for<J1>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if (wave + WAVES * j < N_REG) {              // wave-uniform
+                constexpr bool all_waves = WAVES * (j + 1) <= N_REG;     // tile j exists for every wave
+                if (all_waves || wave + WAVES * j < N_REG) {             // wave-uniform
                     // the next tile exists for every wave (compile time) / for some waves only (then nothing is prefetched and the waits
                     // below are the conservative ones: waiting for fewer outstanding operations than there are is always correct)
                     constexpr bool next_all = WAVES * (j + 2) <= N_REG;
-                    f32x4_t acc = bv;
+                    accs[j & 1] = bv;
                     auto mm = [&](bf16x4 (&fr)[6], const bf16x8 (&w)[3]) {
                         bf16x8 a[3];
 #pragma unroll
                         for (int pl = 0; pl < NP; pl++) a[pl] = __builtin_shufflevector(fr[2 * pl], fr[2 * pl + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc = b4_mfma<NP>(acc, w, a);
+                        accs[j & 1] = b4_mfma<NP>(accs[j & 1], w, a);
                     };
                     constexpr bool pre = j > 0 && WAVES * (j + 1) <= N_REG;      // F[j + 2], T[j] were prefetched by tile j - 1
                     if constexpr (j == 0) {
@@ -431,6 +452,15 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                         __builtin_amdgcn_sched_barrier(0);   // one tile at a time: without it the scheduler interleaves tiles and runs out of registers
                         mm(F[j], w0[0]);
                         mm(F[j + 1], w0[1]);
+                        epi(std::integral_constant<int, j - 1>{});
+                        // the previous tile's epilogue in the shadows of these MFMAs (an MFMA holds the vector issue for 8 of its 16 cycles), its stores behind them.
+                        // (Its LDS stores are issued behind this tile's reads: the counted waits below only get more conservative by them.)
+                        constexpr int NM = 2 * (NP == 3 ? 6 : NP == 2 ? 3 : 1);
+#pragma unroll
+                        for (int q = 0; q < NM; q++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, (26 + NM - 1) / NM, 0);
+                        }
                     }
                     waitF<(next_all ? R : 0) + NP, NP>(F[j + 2]); __builtin_amdgcn_sched_barrier(0); mm(F[j + 2], w0[2]);
                     if constexpr (next_all) rdT(std::integral_constant<int, j + 1>{});
@@ -450,20 +480,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                         }
                         acct = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0t[0], T[j][0], acct, 0, 0, 0);
                     }
-                    acc += acct;
-                    const bool ok = col_ok && (unsigned)(Ry0 + wrow + HW * j) < (unsigned)H0;
-                    uint32_t pa[3], pb[3];
-#if HNET_B4_ABLATE == 4
-                    pa[0] = __builtin_bit_cast(uint32_t, acc[0]); pa[1] = __builtin_bit_cast(uint32_t, acc[1]); pb[0] = __builtin_bit_cast(uint32_t, acc[2]); pb[1] = __builtin_bit_cast(uint32_t, acc[3]) + ok;
-#else
-                    s3p::act_split<NP>(acc[0], acc[1], pa, ok);
-                    s3p::act_split<NP>(acc[2], acc[3], pb, ok);
-#endif
-                    constexpr int JW = HW * j * 2 * XH * 16;
-                    static_for<NP>([&](auto pc) {
-                        constexpr int pl = decltype(pc)::value;
-                        wr64<JW + pl * PLANE * 2>(st1a, make_uint2(pa[pl], pb[pl]));
-                    });
+                    accts[j & 1] = acct;
+                    if constexpr (j == J1 - 1) epi(std::integral_constant<int, j>{});           // the last tile: nothing to hide behind
+                } else {
+                    if constexpr (j > 0) epi(std::integral_constant<int, j - 1>{});             // this wave has no tile j: finish its last one
                 }
             });
         } else
