@@ -42,8 +42,8 @@ PRECISIONS = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100 = 0.14 s at batch 256: the chip needs ~30 ms under load to settle its clock)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--mc", type=int, default=32, help="MC-dropout samples N")
     ap.add_argument("--variant", default="full", choices=["full", "prior3", "prior2", "prior1"])
@@ -605,7 +605,7 @@ def run(args, ctx, primary):
     extras = primary and not args.no_extras and not stream_mode and not mc_mode
     sustained = None
     if extras and args.sustain_seconds > 0:
-        # the timed region above is K = 20 steps = 34 ms: burst clocks.  The same step back to back for >= 1.5 s, outside `value`:
+        # the timed region above is short (K steps, 0.14 s by default; 34 ms with --steps 20: the chip is still settling its clock).  The same step back to back for >= 1.5 s, outside `value`:
         n_sus = max(args.steps, int(np.ceil(args.sustain_seconds * 1e3 / ms_per_step)))
         t0 = time.perf_counter()
         for i in range(n_sus):
