@@ -795,6 +795,9 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
     if ((size_t)g.max_batch * std::max((size_t)g.mc_samples * 1280, (size_t)4 * 5120) + 1024 >= ((size_t)1 << 32)) return HNET_ERR_CAPACITY;   // 32-bit indices of the keep-bit kernel (s3_dispatch.h)
+    // the LDS-DMA / buffer-load kernels address a plane of an activation with 31-bit byte offsets (a buffer descriptor covers 2 GiB; an offset beyond it reads zeros,
+    // silently): the largest plane is block_4_1's bordered map, B42_IMG x 16 channels x 2 bytes = 603 520 bytes per pair -> 3 558 pairs.  Larger batches: several calls.
+    if ((size_t)g.max_batch * B42_IMG * 32 >= ((size_t)1 << 31)) return HNET_ERR_CAPACITY;
     if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
         return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;

@@ -34,7 +34,7 @@ enum {
     HNET_ERR_BAD_WEIGHTS = 2,     /* missing / malformed HNETW001 blob */
     HNET_ERR_DEVICE = 3,          /* HIP runtime error (hnet_last_error has the text) */
     HNET_ERR_NOT_READY = 4,       /* fewer than two images pushed (HomographyNet.cpp:155-158) */
-    HNET_ERR_CAPACITY = 5,        /* batch larger than max_batch */
+    HNET_ERR_CAPACITY = 5,        /* batch larger than max_batch; hnet_create: max_batch beyond what the kernels address (3 558 frame pairs per context) */
     HNET_ERR_UNSUPPORTED = 6
 };
 

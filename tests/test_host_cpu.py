@@ -146,3 +146,21 @@ def test_pth_tar_checkpoint_round_trip(tmp_path, state, blob):
     torch.save({"state_dict": bad}, tmp_path / "bad.pth.tar")
     with pytest.raises(KeyError):
         weights.convert_checkpoint(str(tmp_path / "bad.pth.tar"), str(tmp_path / "bad.hnw"))
+
+
+def test_create_refuses_a_max_batch_beyond_the_kernels_31_bit_plane_offsets():
+    """hnet_create validates the configuration before it touches the device: 3 558 pairs is what a 2 GiB buffer descriptor holds of the largest
+    activation plane (block_4_1's bordered map, kernels.h B42_*); a larger max_batch must be refused, not silently read as zeros"""
+    import ctypes as C
+    from cuahn_vio_amd import _capi
+    L = _capi.lib()
+    cfg = _capi.Config()
+    L.hnet_default_config(C.byref(cfg))
+    cfg.max_batch = 4000
+    h = C.c_void_p()
+    junk = (C.c_ubyte * 16)()
+    rc = L.hnet_create_from_memory(C.byref(cfg), junk, 16, C.byref(h))
+    assert rc == 5 and not h.value          # HNET_ERR_CAPACITY, before the blob is parsed or a device is touched
+    cfg.max_batch = 3000
+    rc = L.hnet_create_from_memory(C.byref(cfg), junk, 16, C.byref(h))
+    assert rc not in (0, 5) and not h.value  # (the junk blob is what is wrong now)
