@@ -98,7 +98,10 @@ typedef PipeCfg<3, 2, 3, 4, 140> PipeCfg144;     // 144 x 128, 768 threads (thre
 template <int CIN, int KS, int COUT>
 static bool pipe_ok(const S3Params& p) {
     const int rows = p.Ho * p.Wo;                 // GEMM rows per pair
-    if ((p.M < 2048 && p.tile != 21) || p.tile == 20) return false;     // (HNET_S3_TILE=20: the four-wave lean kernels, A/B; 21: this kernel at any M, tests)
+    // one workgroup per CU: it pays from three quarters of a round of tiles on (measured, prior-3 / N = 16, ms pipelined / lean: batch 64 - 64 tiles of the
+    // 128 -> 256 layers 0.0349 / 0.0244, 128 tiles of the 64 -> 128 ones 0.0446 / 0.0427; batch 128 - 128 tiles 0.0355 / 0.0320, 256 tiles 0.0502 / 0.0657)
+    const long tiles = (long)((p.M + 139) / 140) * (p.N / 128);
+    if ((tiles < 192 && p.tile != 21) || p.tile == 20) return false;    // (HNET_S3_TILE=20: the four-wave lean kernels, A/B; 21: this kernel at any M, tests)
     if (CIN == 128 && KS == 3 && COUT == 256 && rows % 70 == 0) return true;
     if (CIN == 64 && COUT == 128 && rows % 140 == 0) return true;
     return false;
@@ -121,7 +124,9 @@ typedef RegionCfg<256, 3, 4, 288, true> RegionCfgT;       // block_2_4 / 3_5 / 4
 template <class C>
 static bool region_ok(const S3Params& p) {
     // (variant 25: the lean kernels, A/B; 21: at any batch, tests)
-    return p.wfrag && p.tile != 20 && p.tile != 25 && (p.M >= 2048 || p.tile == 21) && 2 * C::P * (((p.Ho * p.Wo + 1) & ~1) + (((p.H >> 1) * p.Wo + 1) & ~1)) <= C::RP && C::P * p.Ho * p.Wo <= 80 &&
+    // (a one-workgroup-per-CU kernel as well: from three quarters of a round on - batch 128, 128 workgroups of the 4 x 5 layers: 0.0318 against 0.0235 ms lean)
+    const long wgs = (long)((p.M + C::P * p.Ho * p.Wo - 1) / (C::P * p.Ho * p.Wo)) * (p.N / C::BN);
+    return p.wfrag && p.tile != 20 && p.tile != 25 && (wgs >= 192 || p.tile == 21) && 2 * C::P * (((p.Ho * p.Wo + 1) & ~1) + (((p.H >> 1) * p.Wo + 1) & ~1)) <= C::RP && C::P * p.Ho * p.Wo <= 80 &&
            (p.M % (p.Ho * p.Wo)) == 0 && p.W == 2 * p.Wo && ((p.H + 1) >> 1) == p.Ho && p.N % C::BN == 0;
 }
 
