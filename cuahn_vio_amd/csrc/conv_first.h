@@ -374,16 +374,33 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
 
     // ---- stage the band: input rows 2 oy0 - 3 .. + PH, columns -3 .. + PW, zero outside the image, split into planes
     const float* inb = in + (size_t)b * H * W * 2;
-    for (int i = tid; i < PH * PW; i += 256) {
-        const int pr = i / PW, pc = i - pr * PW;
-        const int iy = 2 * oy0 - 3 + pr, ix = pc - 3;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float2 f = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
-        uint16_t a[3], c[3];
-        s3p::split1<NP>(ok ? f.x : 0.f, a[0], a[1], a[2]);
-        s3p::split1<NP>(ok ? f.y : 0.f, c[0], c[1], c[2]);
+    {
+        // all of a thread's pixels in flight before the first one is consumed (round 4: written as one loop, every load was followed by vmcnt(0) - up to seven
+        // dependent global round trips per workgroup, most of the kernel's time)
+        constexpr int NPX = (PH * PW + 255) / 256;
+        float2 f[NPX];
+        uint32_t okb = 0;
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + i * 2]) = (uint32_t)a[pl] | ((uint32_t)c[pl] << 16);
+        for (int q = 0; q < NPX; q++) {
+            const int i = min(tid + 256 * q, PH * PW - 1);
+            const int pr = i / PW, pc = i - pr * PW;
+            const int iy = 2 * oy0 - 3 + pr, ix = pc - 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            f[q] = *reinterpret_cast<const float2*>(inb + (ok ? ((size_t)iy * W + ix) * 2 : 0));
+            okb |= ok ? (1u << q) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NPX; q++) {
+            const int i = tid + 256 * q;
+            if (i < PH * PW) {
+                const bool ok = (okb >> q) & 1u;
+                uint16_t a[3], c[3];
+                s3p::split1<NP>(ok ? f[q].x : 0.f, a[0], a[1], a[2]);
+                s3p::split1<NP>(ok ? f[q].y : 0.f, c[0], c[1], c[2]);
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + i * 2]) = (uint32_t)a[pl] | ((uint32_t)c[pl] << 16);
+            }
+        }
     }
     __syncthreads();
 
