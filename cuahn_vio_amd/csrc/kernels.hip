@@ -289,7 +289,7 @@ __device__ __forceinline__ void fc_dlt_block(const float* __restrict__ f, const 
     float acc[8];
 #pragma unroll
     for (int o = 0; o < 8; o++) acc[o] = 0.0f;
-#pragma unroll 4
+#pragma unroll 10    // (90 loads in flight: two dependent round trips instead of five; the order of the FMAs is unchanged)
     for (int i = 0; i < 20; i++) {
         const int k = tid + 256 * i;
         const float x = f[k];
@@ -837,12 +837,18 @@ __device__ __forceinline__ void heads_fc2_chunk(const float* __restrict__ hidden
     const int sl = d >> 4, o = d & 15, head = o >> 3, oi = o & 7;
     const float* hrow = hid + sl * 512 + head * 256 + part * 64;
     const float* wrow = w2s + (head * 8 + oi) * 256 + part * 64;
-    const int rot = (o & 7) * 4 + part;
+    // 16-byte LDS reads (round 4: one value at a time the loop was 128 ds_read_b32 + the index arithmetic per thread); the start is rotated per (output, quarter)
+    // so that the threads of a wave - which read rows 1 KB apart - do not all start on one bank
+    const int rot = ((o & 7) * 4 + part) & 15;
     float acc = 0.0f;
 #pragma unroll 8
-    for (int j = 0; j < 64; j++) {
-        const int jj = (j + rot) & 63;
-        acc = fmaf(hrow[jj], wrow[jj], acc);
+    for (int j = 0; j < 16; j++) {
+        const int jj = ((j + rot) & 15) * 4;
+        const float4 hv = *reinterpret_cast<const float4*>(hrow + jj), wv = *reinterpret_cast<const float4*>(wrow + jj);
+        acc = fmaf(hv.x, wv.x, acc);
+        acc = fmaf(hv.y, wv.y, acc);
+        acc = fmaf(hv.z, wv.z, acc);
+        acc = fmaf(hv.w, wv.w, acc);
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
@@ -859,8 +865,8 @@ __global__ __launch_bounds__(256) void heads_fc2_kernel(const float* __restrict_
                                                         uint32_t thr, float scale, uint64_t mc_seed, uint64_t pair_seq0,
                                                         const uint64_t* __restrict__ seq_dev, const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ mean_s, float* __restrict__ logvar_s, uint32_t* __restrict__ flag) {
-    __shared__ float w2s[4096];                  // [2][8][256]
-    __shared__ float hid[FC2_CHUNK * 512];       // after dropout
+    __shared__ __attribute__((aligned(16))) float w2s[4096];                  // [2][8][256]
+    __shared__ __attribute__((aligned(16))) float hid[FC2_CHUNK * 512];       // after dropout
     __shared__ uint32_t pre_row[FC2_CHUNK * 2];
     const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
     const int b = blockIdx.x / n_chunks, c0 = (blockIdx.x % n_chunks) * FC2_CHUNK;
@@ -968,8 +974,8 @@ __global__ __launch_bounds__(1024) void heads_fc2_finish_kernel(const float* __r
                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                                 const float* __restrict__ H1, float* __restrict__ mean, float* __restrict__ cov,
                                                                 float* __restrict__ Htot, uint32_t* __restrict__ flag, int mean_stride, int cov_stride) {
-    __shared__ float w2s[4096];
-    __shared__ float hid[4][FC2_CHUNK * 512];
+    __shared__ __attribute__((aligned(16))) float w2s[4096];
+    __shared__ __attribute__((aligned(16))) float hid[4][FC2_CHUNK * 512];
     __shared__ uint32_t pre_row[4][FC2_CHUNK * 2];
     __shared__ float ms_l[FC2M_MAX_N * 8], lv_l[FC2M_MAX_N * 8];
     const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
