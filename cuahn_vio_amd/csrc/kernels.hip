@@ -495,6 +495,22 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
         for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
     }
     float s1 = 0.0f, s2 = 0.0f;
+    if constexpr (!WARP && K == 8 && sizeof(PIX) == 1) {
+        // block 1 of the full model (no warp, 8 x 8 pool, u8 images): the eight pixels of a window row are ONE aligned 8-byte load per image (round 4; as 32 byte
+        // loads + 32 table look-ups per lane the kernel ran at half the memory rate with 54 % of its LDS cycles bank conflicts).  Same values (u8_to_unit is
+        // bit-identical to the table), same order of the sums.
+#pragma unroll
+        for (int rr = 0; rr < RPL; rr++) {
+            const int v = oy * K + j * RPL + rr;
+            const uint2 q1 = *reinterpret_cast<const uint2*>(i1 + v * IMG_W + ox * K), q2 = *reinterpret_cast<const uint2*>(i2 + v * IMG_W + ox * K);
+#pragma unroll
+            for (int a = 0; a < K; a++) {
+                const uint32_t w1 = a < 4 ? q1.x : q1.y, w2 = a < 4 ? q2.x : q2.y;
+                s1 += u8_to_unit((float)((w1 >> (8 * (a & 3))) & 255u));
+                s2 += u8_to_unit((float)((w2 >> (8 * (a & 3))) & 255u));
+            }
+        }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < RPL; rr++) {
         const int v = oy * K + j * RPL + rr;
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
             s1 += PixRead<PIX>::get(i1, v * IMG_W + u, lut);
             s2 += WARP ? warp_sample<PIX>(i2, h, u, v, lut) : PixRead<PIX>::get(i2, v * IMG_W + u, lut);
         }
+    }
     }
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) {
