@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# HNET_LIB_PATH: another build of the SAME library (the -DHNET_B4_ABLATE profiling build of tools/b4_ablate.sh); never a fallback
+# HNET_LIB_PATH: another build of the SAME library (same-box A/B of two source states with tools/ab_bench.py); never a fallback
 LIB_PATH = os.environ.get("HNET_LIB_PATH") or os.path.join(_PKG, "libhnet_hip.so")
 
 HNET_OK = 0

@@ -174,12 +174,7 @@ static hipError_t run_block4_fused(const void* x_in, size_t x_plane, const void*
 template <int NP>
 hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
-#ifdef HNET_B4_ABLATE   // profiling build only (make ablate): HNET_B4_DBG drops phases of the kernel, results are wrong
-    static const int dbg_env = std::getenv("HNET_B4_DBG") ? std::atoi(std::getenv("HNET_B4_DBG")) : 0;
-    flags = (flags & 113) | ((dbg_env & 7) << 1);
-#else
     flags &= 113;
-#endif
     // fp16-plane mode: 8 x 32 tiles (57 KB of LDS: still two workgroups per CU; 16 phase-2 M-tiles = four per wave exactly, 19 / 16 rows of halo instead of 17 / 14).
     // flags bit 5 (hnet_config.variant 26): the 7 x 32 tiles of rounds 2 - 3 (A/B); the three-plane modes need them for two workgroups per CU
     if constexpr (NP == 2) {
