@@ -420,7 +420,6 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
                 const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(src + 4);
                 a[st][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-        const bool store = mt * 16 + m < NPIX_T;
         const size_t opix = ((size_t)b * HO + oy0 + oy) * WO + ox;
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -434,12 +433,16 @@ __global__ __launch_bounds__(256) void conv7_c2_s2_s3_kernel(const float* __rest
             uint32_t pa[3], pb[3];
             s3p::act_split<NP>(acc[0], acc[1], pa);
             s3p::act_split<NP>(acc[2], acc[3], pb);
-            if (store) {
+            {   // (no branch - it would end the scheduling region: lanes beyond the band repeat its last pixel, same address, same value)
                 uint16_t* o = out16 + opix * COUT + (wave + 4 * t) * 16 + 4 * g;
 #pragma unroll
                 for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint2*>(o + pl * o_plane) = make_uint2(pa[pl], pb[pl]);
             }
         }
+        // all of the M-tile's fragment reads first (the two 8-byte halves of a fragment are one ds_read2_b64), then its MFMAs: left to itself the scheduler put
+        // every read in front of its MFMA with a wait - eight LDS round trips per M-tile
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NTW * 4 * (NP == 3 ? 6 : NP == 2 ? 3 : 1), 0);
     }
 }
 
