@@ -4,6 +4,7 @@
 // (cuahn_ros/homography_network/src/HomographyNet.cpp) without libtorch: weights come from an HNETW001
 // blob, the forward is a fixed sequence of HIP kernel launches on one stream over persistent buffers.
 #include "../../include/hnet.h"
+#include "../../include/hnet_rng.h"
 #include "geom.h"
 #include "kernels.h"
 #include "s3_format.h"
@@ -124,8 +125,9 @@ struct hnet_ctx {
     float* x_in[4] = {};
     float* act[20] = {};
     int act_c[20], act_h[20], act_w[20];
-    float* ws = nullptr;               // split-K partial sums (igemm.h), 64 MB
+    float* ws = nullptr;               // split-K partial sums (igemm.h), 64 MB, followed by the SPLITK_TICKETS tile counters of the latency path (kernels.h LatIO)
     size_t ws_floats = 0;
+    bool lat_tail = true;              // round 5: split-K tiles of the 4 x 5 layers finished by their last-arriving workgroup, heads FC1 of small batches as one launch (heads_lat.h); variant 30 = off
     float *hidden = nullptr, *Hm = nullptr, *Htot = nullptr, *mean_s = nullptr, *logvar_s = nullptr;
     float *d_mean = nullptr, *d_cov = nullptr, *d_err = nullptr, *d_prior = nullptr;
     uint8_t* d_err_u8 = nullptr;
@@ -356,6 +358,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // `pend` holds what the next prep has to evaluate; the homographies alternate between Hm and Hm2 (a workgroup stores the new one while
     // others still read the old one).
     const bool small = c->fuse_small && B <= 8;
+    // the keep bits of the heads depend on the seeds only: on the latency path they are drawn by surplus workgroups of block 4's prep launch (FcArgs::mask)
+    const bool mask_in_prep = small && c->lat_tail && c->s3 && heads_fc1_one_launch(B, c->n_local, c->n_planes);
+    bool mask_ready = false;
     FcArgs pend = {};
     bool have_pend = false;
     float* Hcur = Hm;                              // buffer holding the homography so far
@@ -374,6 +379,13 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         if (have_pend) {
             if (prep_fc_supported(a.prev, a.curr, 8 >> blk, x16 != nullptr)) {
                 pend.H_out = pend.feat ? Hnext : Hcur;                                // the prior's DLT has no input homography: it may land in Hcur
+                if (blk == 3 && mask_in_prep) {
+                    pend.mask = c->head_mask + P0 * c->n_local * 2 * 640;
+                    pend.mask_blocks = (int)(((size_t)B * c->n_local * 2 * 160 + 255) / 256);
+                    pend.n_local = c->n_local; pend.s_begin = c->s_begin; pend.thr = hnet_drop_threshold(g.dropout_p);
+                    pend.mc_seed = g.mc_seed; pend.pair_seq0 = a.seq0; pend.seq_dev = a.seq_dev;
+                    mask_ready = true;
+                }
                 STAGE(launch_prep_fc(a.prev, a.curr, a.pix_fmt, pend, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
                 if (pend.feat) std::swap(Hcur, Hnext);
             } else {                                                                  // (unaligned images / K = 8: the separate launches)
@@ -427,10 +439,11 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_conv_first_s2(l, in, c->s2_frag[l], c->conv_b[l], o16, MB * cnt, B, s, c->n_planes));
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128, c->patch_rb5));
-            else if (c->s3 && conv_is_s3_layer(l))
+            else if (c->s3 && conv_is_s3_layer(l)) {
+                LatIO lat = {c->lat_tail && ws ? reinterpret_cast<uint32_t*>(c->ws + c->ws_floats) : nullptr};
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
-                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->conv_wfrag[l], c->n_planes, c->s3_tile));
-            else
+                                     c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->conv_wfrag[l], c->n_planes, c->s3_tile, &lat));
+            } else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
             in16 = o16;
@@ -448,9 +461,12 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // block 4 heads (:272-282) and output assembly (:310-317)
     const float* feat = c->act[19] + P0 * 5120;
     float* hidden = c->hidden + P0 * c->n_local * 512;
-    if (c->s3)
+    if (c->s3) {
+        LatIO lat_h = {nullptr, mask_ready};
         STAGE(launch_heads_fc1_s3(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1_16, c->b1, hidden,
-                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes, c->s3_tile));
+                                  c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes,
+                                  c->s3_tile, small && c->lat_tail && c->n_planes == 2 ? &lat_h : nullptr));
+    }
     else
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
     if (a.partial) {
@@ -842,6 +858,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->fuse_b3 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B3);
     c->fuse_b42 = c->n_planes == 2 && !(g.variant & HNET_VARIANT_UNFUSED_B42);
     c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
+    c->lat_tail = c->s3_tile != 30;                // (30: the splitk_reduce* launches and the split-K heads of rounds 1 - 4, A/B and bitwise tests)
     c->a14_pad = c->fuse_b4 && c->fuse_b42;
     c->patch_rb5 = c->s3_tile == 27 ? -32 : 5;   // (variant 27: block_3_2 on the patch kernel without prefetch, A/B)  region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
     c->patch_b128 = true;
@@ -907,7 +924,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipMemset(c->x16_b4, 0, 3 * c->x16_plane * 4));
     }
     c->ws_floats = (size_t)16 << 20;
-    CK(dalloc(&c->ws, c->ws_floats));
+    CK(dalloc(&c->ws, c->ws_floats + SPLITK_TICKETS));      // + the tile counters of the split-K launches (kernels.h): zero between launches
+    CK(hipMemset(c->ws + c->ws_floats, 0, SPLITK_TICKETS * sizeof(uint32_t)));
     CK(dalloc(&c->hidden, MB * c->n_local * 512));
     if (c->s3) {
         CK(hipMalloc((void**)&c->feat16, 3 * MB * 5120 * 2));

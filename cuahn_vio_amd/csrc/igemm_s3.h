@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include "igemm.h"
 #include "s3_format.h"
+#include "heads_mask.h"
 
 namespace hnet {
 
@@ -60,10 +61,16 @@ struct S3Params {
     const uint16_t* wfrag; // igemm_region.h layers: the weights as MFMA fragments in consumption order (nullptr: not packed)
     int xcd_remap;         // 1: XCD-aware workgroup -> tile mapping (s3_tile_origin)
     int tile;              // tile-shape experiment of the context (HNET_S3_TILE at hnet_create; 0 = the measured defaults of s3_dispatch.h)
+    uint32_t* tickets;     // split-K launches of igemm_s3_lean_kernel (round 5): one zeroed word per (M, N) tile; the LAST of the k_split workgroups of a
+                           // tile to arrive sums the partials (s3_splitk_last_arriver) - no splitk_reduce* launch.  nullptr: raw partials only
 #ifdef HNET_S3_TRACE
     unsigned long long* trace;   // tools/trace_s3.hip only: [block < 8][wave][S3T_SLOTS] s_memtime stamps
 #endif
 };
+
+// cache policy of the buffer loads / stores that exchange split-K partials between workgroups on different XCDs (each XCD has a private,
+// mutually non-coherent L2): sc0 | sc1 = system scope - the store is written through to memory, the load does not hit a stale L2 line
+constexpr int S3_CPOL_SYSTEM = 1 | 16;
 
 // phase timestamps of the K loop for tools/trace_s3.hip (compiled out of the library)
 #ifdef HNET_S3_TRACE
@@ -289,7 +296,11 @@ __device__ __forceinline__ void s3_epilogue_m16(f32x4_m16 (&acc16)[TM16][TN16], 
 #pragma unroll
                         for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
                     }
-                    *reinterpret_cast<f32x4_e*>(dst + (size_t)m * p.N + n) = v;
+                    if (p.k_split > 1 && p.tickets)       // read by the tile's last arriver on another XCD: written through to memory (s3_splitk_last_arriver)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 0x7FFFFFF0, 0x00020000),
+                                                               (uint32_t)(((size_t)m * p.N + n) * 4), 0, S3_CPOL_SYSTEM);
+                    else
+                        *reinterpret_cast<f32x4_e*>(dst + (size_t)m * p.N + n) = v;
                 }
             }
         }
@@ -723,6 +734,56 @@ __device__ __forceinline__ int s3_swz_m16(int row, int chunk) {
     return CH == 4 ? (chunk ^ (((row >> 3) & 1) * 3)) * 8 : (chunk ^ ((row >> 1) & 7)) * 8;   // bf16 elements
 }
 
+// Split-K without a second launch (round 5, latency path).  Every workgroup of a split-K launch has written its raw fp32 partial tile to
+// p.partial[z]; the k_split workgroups of one (M, N) tile then take a ticket from the tile's counter, and the one that draws the LAST ticket
+// adds the partials in z order, applies bias + LeakyReLU and writes the layer output - the arithmetic of splitk_reduce_kernel /
+// splitk_reduce_s3_kernel element for element (same bits), without their launch (4 - 6 us per layer at batch 1, twelve layers per forward).
+// Memory ordering WITHOUT agent-scope fences: a __threadfence() here is an L2 write-back + invalidate on this eight-XCD part and costs more than
+// the launch it saves (measured: block_2_2 13.0 -> 20.5 us, forward 0.211 -> 0.251 ms).  Instead the partials are stored and loaded with the
+// system-scope cache policy (S3_CPOL_SYSTEM: written through to memory / never served from a stale L2 line), every wave waits for the
+// acknowledgement of its own stores (vmcnt 0) before the workgroup barrier, and only then thread 0 performs the agent-scope atomic; the last
+// arriver's loads are issued after the atomic has returned.  The counter is left at zero for the next launch (stream ordered).
+template <bool OUT32, int NP>
+__device__ __forceinline__ void s3_splitk_last_arriver(const S3Params& p, int m0, int n0, int bm, int bn, uint32_t* lds_word) {
+    typedef float f32x4_e __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's partial stores have been acknowledged by memory
+    __syncthreads();
+    uint32_t* ticket = p.tickets + (blockIdx.x + blockIdx.y * gridDim.x);
+    if (tid == 0) *lds_word = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*lds_word != (uint32_t)(p.k_split - 1)) return;      // (workgroup-uniform)
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, 0x7FFFFFF0, 0x00020000);
+    const int rows = min(bm, p.M - m0), cq = min(bn, p.N - n0) >> 2;      // N is a multiple of 4 for every layer
+    const uint32_t stride = (uint32_t)((size_t)p.M * p.N * 4);             // bytes per partial plane (the workspace is far below 2 GB)
+    for (int i = tid; i < rows * cq; i += blockDim.x) {
+        const int r = i / cq, q = i - r * cq;
+        const size_t e = (size_t)(m0 + r) * p.N + n0 + 4 * q;
+        f32x4_e s = __builtin_bit_cast(f32x4_e, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)(e * 4), 0, S3_CPOL_SYSTEM));
+#pragma unroll 8
+        for (int z = 1; z < p.k_split; z++) {
+            const f32x4_e t = __builtin_bit_cast(f32x4_e, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)(e * 4), z * stride, S3_CPOL_SYSTEM));
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        const f32x4_e b = *reinterpret_cast<const f32x4_e*>(p.bias + n0 + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const float v = s[k] + b[k]; s[k] = v > 0.0f ? v : v * 0.1f; }
+        if (OUT32) {
+            *reinterpret_cast<f32x4_e*>(p.out32 + e) = s;
+        } else {
+            uint16_t pl[3][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) split_np(s[k], NP, pl[0][k], pl[1][k], pl[2][k]);
+#pragma unroll
+            for (int q3 = 0; q3 < 3; q3++)
+                if (q3 < 2 || NP != 2)       // (the plain-bf16 mode writes three planes like splitk_reduce_s3_kernel; only plane 0 is read)
+                    *reinterpret_cast<uint2*>(p.out16 + q3 * p.o_plane + e) =
+                        make_uint2((uint32_t)pl[q3][0] | ((uint32_t)pl[q3][1] << 16), (uint32_t)pl[q3][2] | ((uint32_t)pl[q3][3] << 16));
+        }
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // (launch bounds: the 128 x 128 tiles hold 64 x 64 per wave - 128 accumulator registers in the fp16 mode; asking for two waves per SIMD keeps
 // them at <= 256 registers, 226 without scratch, where the default heuristic took 264 and with it half of the occupancy)
 template <class L, int BM, int BN, int WGM, bool OUT32, int BKT = 64, int NP = 3>
@@ -883,6 +944,10 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 64 ? 2 : 1)) void igemm_s3_le
             for (int j = 0; j < TN16; j++) acc16[i][j] += acc16l[i][j] * S3_F16_INV;
     }
     s3_epilogue_m16<TM16, TN16, OUT32, NP, false>(acc16, p, smem + wave * (3 * 32 * 32), m0 + wm * WM, n0 + wn * WN, lane);
+    if (p.k_split > 1 && p.tickets) {            // (uniform; the epilogue above wrote raw partials and used no LDS)
+        __syncthreads();                         // every wave has left the tiles: smem[0] can carry the ticket
+        s3_splitk_last_arriver<OUT32, NP>(p, m0, n0, BM, BN, reinterpret_cast<uint32_t*>(smem));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1047,7 +1112,7 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
     const size_t nfeat = (size_t)batch * 5120;
     const size_t nmask = (size_t)batch * n_local * 2 * 640;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nfeat) {
+    if (feat16 && i < nfeat) {         // (feat16 == nullptr: the keep bits only - heads_fc1_lat_kernel splits the features itself)
         uint16_t a, b, c;
         split_np(feat[i] * scale, np, a, b, c);
         feat16[i] = a; feat16[f_plane + i] = b;
@@ -1061,29 +1126,20 @@ static __global__ __launch_bounds__(256) void heads_prep_kernel(const float* __r
     // K-tile-major layout (ktile_layout = 1, igemm_heads_pipe_kernel: [2 heads][80 K-tiles][M rows][8 bytes]): consecutive threads are the two
     // halves of consecutive ROWS of one K-tile (coalesced 4-byte stores), every thread forms its own row prefix.
     __shared__ uint32_t pre_row[3];
-    const uint32_t i0 = blockIdx.x * 1024u, row0 = i0 / 640u, rem0 = i0 - row0 * 640u;
-    if (threadIdx.x < 3 && !ktile_layout) {
-        const uint32_t row = row0 + threadIdx.x;                      // rows beyond the end are never read
-        const uint32_t head = row & 1u, t = row >> 1;
-        const uint32_t b = t / (uint32_t)n_local, sm = t - b * (uint32_t)n_local;
-        pre_row[threadIdx.x] = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b), 2u * head, (uint32_t)s_begin + sm);
+    if (!ktile_layout) {                                              // (uniform) the row-major layout: heads_mask.h
+        heads_mask_block(blockIdx.x, batch, n_local, s_begin, thr, mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull), mask, pre_row);
+        return;
     }
-    __syncthreads();
     if (4 * i < nmask) {                                              // nmask is a multiple of 640: the four bytes are all in or all out
         uint32_t pre, oidx;
         int chunk;                                                    // multiple of 4: the four bytes lie in one row and in one pixel's channel run
-        if (ktile_layout) {
+        {
             const uint32_t M = (uint32_t)batch * (uint32_t)n_local, g = (uint32_t)i, half = g & 1u, t = g >> 1;
             const uint32_t q = t / M, m = t - q * M, head = q / 80u, it = q - head * 80u;
             const uint32_t b = m / (uint32_t)n_local, sm = m - b * (uint32_t)n_local;
             pre = hnet_mask_prefix(hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b), 2u * head, (uint32_t)s_begin + sm);
             chunk = (int)(it * 8u + half * 4u);
             oidx = (q * M + m) * 2u + half;
-        } else {
-            const uint32_t off = rem0 + 4u * threadIdx.x, wrap = (off >= 640u ? 1u : 0u) + (off >= 1280u ? 1u : 0u);
-            chunk = (int)(off - 640u * wrap);
-            pre = pre_row[wrap];
-            oidx = (uint32_t)i;
         }
         const int k0 = chunk * 8, pix = k0 >> 8, c0 = k0 & 255;
         // hnet_mask_keep(pre, element, thr) for the 32 elements (c0 + e) * 20 + pix: element * 0xc2b2ae35 + 0x27d4eb2f (hnet_rng.h,

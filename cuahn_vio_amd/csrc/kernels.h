@@ -31,9 +31,18 @@ bool conv_is_s3_layer(int layer);
 // wfrag (fp16-plane mode, conv_region_layer(layer)): the weights as MFMA fragments in the order igemm_region.h consumes them (packed by hnet_create), or nullptr
 bool conv_region_layer(int layer);            // block_1_2, block_1_3, block_2_4 / 3_5 / 4_6: input region resident in LDS, weights straight to registers
 int conv_region_taps_padded(int layer);       // taps per 64-channel chunk in the packed fragments (the K-split form pads its second half with a zero tap)
+// Round 5: optional extras of launch_conv_s3 / launch_heads_fc1_s3 for the split-K launches of small batches.
+// tickets: SPLITK_TICKETS zeroed 32-bit counters; a split-K tile of at most 40 GEMM rows is then finished by its last-arriving workgroup (igemm_s3.h
+// s3_splitk_last_arriver: same sums in the same order as splitk_reduce*: same bits) and the counters are left at zero; launches sharing them are stream ordered.
+constexpr int SPLITK_TICKETS = 4096;
+struct LatIO {
+    uint32_t* tickets;        // nullptr: splitk_reduce* launches
+    bool mask_ready;          // launch_heads_fc1_s3: the keep bits have been written already (by the surplus workgroups of block 4's prep launch, FcArgs::mask)
+};
+bool heads_fc1_one_launch(int batch, int n_local, int n_planes);      // whether launch_heads_fc1_s3 with a LatIO takes the one-launch kernel of heads_lat.h
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* wfrag = nullptr, int n_planes = 3, int tile = 0);
+                          float* ws = nullptr, size_t ws_floats = 0, const uint16_t* wfrag = nullptr, int n_planes = 3, int tile = 0, LatIO* lat = nullptr);
 bool conv_is_patch_layer(int layer);      // block_3_1 / block_4_2 (conv_patch_s2.h), split-bf16 mode
 bool conv_is_patch32_layer(int layer);    // block_3_2 / block_4_3 at their network size 56x80 (conv_patch32_s2_kernel); same launcher, wfrag [4][9][3][64] x 16 B
 hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int batch, int h, int w, const void* wfrag,
@@ -63,7 +72,8 @@ hipError_t conv_kernels_init_device();
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
-                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3, int tile = 0);
+                               float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3, int tile = 0,
+                               LatIO* lat = nullptr /* non-null, fp16-plane mode, batch <= 8, n_local <= 64: the one-launch kernel of heads_lat.h */);
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 
@@ -111,6 +121,13 @@ struct FcArgs {
     const float* H_in;      // [B][9] homography so far (nullptr: identity)
     const float* prior;     // [B][8] corner-offset prior: H = DLT(p4 + prior); used when feat == nullptr
     float* H_out;           // [B][9]: written by the first workgroup of each pair (a buffer other than H_in)
+    // round 5 (block 4's launch on the latency path): mask_blocks surplus workgroups at the end of the grid draw the keep bits of the heads' first dropout beside
+    // the warp (heads_mask.h; they depend on the seeds only) - mask == nullptr: none
+    uint8_t* mask;          // [B][n_local][2][640]
+    int mask_blocks, n_local, s_begin;
+    uint32_t thr;           // hnet_drop_threshold(p)
+    uint64_t mc_seed, pair_seq0;
+    const uint64_t* seq_dev;
 };
 bool prep_fc_supported(const void* img1, const void* img2, int k, bool has_out_s3);
 hipError_t launch_prep_fc(const void* img1, const void* img2, int pix_fmt, const FcArgs& fc, int k, float* out, int batch, hipStream_t s,

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include "kernels.h"
+#include "heads_mask.h"
 #include "geom.h"
 #include "s3_format.h"
 #include "../../include/hnet.h"
@@ -344,9 +345,20 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
                                                               FcArgs fc = FcArgs{}) {
     __shared__ __attribute__((aligned(16))) float reg[WT_CAP];
     constexpr int TX = IMG_W / WT_W, TY = IMG_H / WT_H, HO = IMG_H / K, WO = IMG_W / K;
+    unsigned n_main = gridDim.x;
+    if constexpr (FC) {
+        if (fc.mask) {      // the surplus workgroups of the grid: keep bits of the heads (FcArgs::mask)
+            n_main -= (unsigned)fc.mask_blocks;
+            if (blockIdx.x >= n_main) {
+                heads_mask_block(blockIdx.x - n_main, (int)(n_main / (TX * TY)), fc.n_local, fc.s_begin, fc.thr, fc.mc_seed, fc.pair_seq0 + (fc.seq_dev ? *fc.seq_dev : 0ull),
+                                 fc.mask, reinterpret_cast<uint32_t*>(reg));
+                return;
+            }
+        }
+    }
     // XCD-aware tile order: consecutive workgroup ids run on different XCDs (private L2s) and the staged boxes of neighbouring tiles
     // overlap: with tile = workgroup id the warped image was fetched 2.4 times (FETCH_SIZE x 2: 89 MB for 37 MB of images)
-    int bid = ((gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    int bid = ((n_main & 7) == 0) ? (int)((blockIdx.x & 7) * (n_main >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
     const int tx = bid % TX; bid /= TX;
     const int ty = bid % TY;
     const int b = bid / TY;
@@ -675,7 +687,7 @@ bool prep_fc_supported(const void* img1, const void* img2, int k, bool has_out_s
 template <typename PIX>
 static hipError_t prep_fc_dispatch(const PIX* i1, const PIX* i2, const FcArgs& fc, int k, float* out, int batch, hipStream_t s, uint32_t* out_s3,
                                    size_t s3_plane, int n_planes, bool exact) {
-    const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H);
+    const unsigned blocks = (unsigned)batch * (IMG_W / WT_W) * (IMG_H / WT_H) + (fc.mask ? (unsigned)fc.mask_blocks : 0u);
 #define HNET_TILED_FC(KK, S3)                                                                                                                        \
     if (exact) hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, S3, true, true>), dim3(blocks), dim3(256), 0, s, i1, i2, (const float*)nullptr, out, out_s3, s3_plane, n_planes, fc); \
     else hipLaunchKernelGGL((prep_warp_tiled_kernel<PIX, KK, S3, false, true>), dim3(blocks), dim3(256), 0, s, i1, i2, (const float*)nullptr, out, out_s3, s3_plane, n_planes, fc);
@@ -833,19 +845,22 @@ constexpr int FC2_CHUNK = 4;
 // one chunk (up to FC2_CHUNK samples) of one pair by 256 threads (t = 0..255 inside the chunk's thread group); w2s [2][8][256] already staged;
 // hid / pre_row: this group's LDS slices.  Every thread of the workgroup must call it (workgroup barriers inside); nc <= 0: nothing stored.
 // The per-sample results go to mean_o / logvar_o [n_local][8] of the pair (global memory, or LDS in the merged kernel).
+// pre: the thread's FC2_CHUNK * 512 / 256 = 8 elements of the chunk (i = t, t + 256, ...) loaded ahead of time (nullptr: loaded here)
 __device__ __forceinline__ void heads_fc2_chunk(const float* __restrict__ hidden_b, int n_local, int s_begin, int c0, int nc, int t, uint32_t thr,
                                                 float scale, uint64_t key, const float* w2s, const float* __restrict__ b2, float* hid,
-                                                uint32_t* pre_row, float* mean_o, float* logvar_o, uint32_t* __restrict__ flag) {
+                                                uint32_t* pre_row, float* mean_o, float* logvar_o, uint32_t* __restrict__ flag, const float* pre = nullptr) {
     // the hash prefix of a (sample, head) row - four hnet_mix32 - once per row, not once per element
     if (t < FC2_CHUNK * 2) pre_row[t] = hnet_mask_prefix(key, (uint32_t)(2 * (t & 1) + 1), (uint32_t)(s_begin + c0 + (t >> 1)));
     __syncthreads();
-    for (int i = t; i < FC2_CHUNK * 512; i += 256) {
+#pragma unroll
+    for (int k = 0; k < FC2_CHUNK * 512 / 256; k++) {
+        const int i = t + 256 * k;
         const int sl = i >> 9, col = i & 511, head = col >> 8, j = col & 255;
         float v = 0.0f;
         if (sl < nc) {
-            const uint32_t pre = pre_row[sl * 2 + head];
-            const float x = hidden_b[(size_t)(c0 + sl) * 512 + col];
-            v = hnet_mask_keep(pre, (uint32_t)j, thr) ? x * scale : 0.0f;
+            const uint32_t prefix = pre_row[sl * 2 + head];
+            const float x = pre ? pre[k] : hidden_b[(size_t)(c0 + sl) * 512 + col];
+            v = hnet_mask_keep(prefix, (uint32_t)j, thr) ? x * scale : 0.0f;
         }
         hid[i] = v;
     }
@@ -995,17 +1010,43 @@ __global__ __launch_bounds__(1024) void heads_fc2_finish_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float hid[4][FC2_CHUNK * 512];
     __shared__ uint32_t pre_row[4][FC2_CHUNK * 2];
     __shared__ float ms_l[FC2M_MAX_N * 8], lv_l[FC2M_MAX_N * 8];
+    __shared__ float h1_l[9];
     const int b = blockIdx.x, tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
-    for (int i = tid; i < 4096; i += 1024) w2s[i] = w2[i];
-    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + (seq_dev ? *seq_dev : 0ull) + (uint64_t)b);
+    // round 5: every global load of the kernel is issued before the first dependent instruction - the sequence number, the weights, the homography
+    // and the thread's hidden activations of the first two rounds (all of them up to N = 32) - instead of one memory round trip per step
+    // (15.3 -> ... us at batch 1; same values, same arithmetic)
+    const float* hidden_b = hidden + (size_t)b * n_local * 512;
     const int n_chunks = (n_local + FC2_CHUNK - 1) / FC2_CHUNK;
-    for (int r = 0; r * 4 < n_chunks; r++) {                       // (the first barrier inside heads_fc2_chunk also covers the w2s fill)
+    const uint64_t seqv = seq_dev ? *seq_dev : 0ull;
+    float w2r[4], hpre[2][FC2_CHUNK * 512 / 256];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w2r[k] = w2[tid + 1024 * k];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int c0 = (r * 4 + grp) * FC2_CHUNK, nc = min(FC2_CHUNK, n_local - c0);
+#pragma unroll
+        for (int k = 0; k < FC2_CHUNK * 512 / 256; k++) {
+            const int i = t + 256 * k, sl = i >> 9;
+            hpre[r][k] = sl < nc ? hidden_b[(size_t)(c0 + sl) * 512 + (i & 511)] : 0.0f;
+        }
+    }
+    if (tid < 9) h1_l[tid] = H1[b * 9 + tid];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w2s[tid + 1024 * k] = w2r[k];
+    const uint64_t key = hnet_pair_key(mc_seed, pair_seq0 + seqv + (uint64_t)b);
+    // (the first barrier inside heads_fc2_chunk also covers the w2s / h1_l fill)
+    heads_fc2_chunk(hidden_b, n_local, s_begin, grp * FC2_CHUNK, min(FC2_CHUNK, n_local - grp * FC2_CHUNK), t, thr, scale, key, w2s, b2, hid[grp],
+                    pre_row[grp], ms_l, lv_l, nullptr, hpre[0]);
+    if (n_chunks > 4)
+        heads_fc2_chunk(hidden_b, n_local, s_begin, (4 + grp) * FC2_CHUNK, min(FC2_CHUNK, n_local - (4 + grp) * FC2_CHUNK), t, thr, scale, key, w2s, b2, hid[grp],
+                        pre_row[grp], ms_l, lv_l, nullptr, hpre[1]);
+    for (int r = 2; r * 4 < n_chunks; r++) {
         const int c0 = (r * 4 + grp) * FC2_CHUNK;
-        heads_fc2_chunk(hidden + (size_t)b * n_local * 512, n_local, s_begin, c0, min(FC2_CHUNK, n_local - c0), t, thr, scale, key, w2s, b2, hid[grp],
+        heads_fc2_chunk(hidden_b, n_local, s_begin, c0, min(FC2_CHUNK, n_local - c0), t, thr, scale, key, w2s, b2, hid[grp],
                         pre_row[grp], ms_l, lv_l, nullptr);
     }
     __syncthreads();
-    if (tid < 64) mc_finish_wave(ms_l, lv_l, n_local, H1 + b * 9, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride, Htot ? Htot + b * 9 : nullptr, flag, tid);
+    if (tid < 64) mc_finish_wave(ms_l, lv_l, n_local, h1_l, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride, Htot ? Htot + b * 9 : nullptr, flag, tid);
 }
 hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, int s_begin, float p, uint64_t mc_seed, uint64_t pair_seq0, const float* w2,
                                    const float* b2, const float* H1, float* mean, float* cov, float* Htot, hipStream_t s, const uint64_t* seq_dev,

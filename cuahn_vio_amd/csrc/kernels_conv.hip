@@ -170,14 +170,16 @@ hipError_t launch_conv_patch(int layer, const uint16_t* in, size_t i_plane, int 
 hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
-                               const uint64_t* seq_dev, int n_planes, int tile) {
-    return HNET_NP(launch_heads_fc1_s3_np, feat, batch, n_local, s_begin, p_drop, mc_seed, pair_seq0, w1planes, b1, hidden, feat16, f_plane, mask, s, ws, wsn, seq_dev, tile);
+                               const uint64_t* seq_dev, int n_planes, int tile, LatIO* lat) {
+    return HNET_NP(launch_heads_fc1_s3_np, feat, batch, n_local, s_begin, p_drop, mc_seed, pair_seq0, w1planes, b1, hidden, feat16, f_plane, mask, s, ws, wsn, seq_dev, tile, lat);
 }
+
+bool heads_fc1_one_launch(int batch, int n_local, int n_planes) { return n_planes == 2 && batch <= 8 && n_local <= 16 * HL_MAXG; }
 
 hipError_t launch_conv_s3(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                           size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                          float* ws, size_t wsn, const uint16_t* wfrag, int n_planes, int tile) {
-    return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, wfrag, tile);
+                          float* ws, size_t wsn, const uint16_t* wfrag, int n_planes, int tile, LatIO* lat) {
+    return HNET_NP(launch_conv_s3_np, layer, in, in_plane, batch, h, w, wplanes, w_plane, bias, out16, o_plane, out32, s, ws, wsn, wfrag, tile, lat);
 }
 
 // 16-byte chunks of [np][B][h][w][c] planes to / from the interior of a bordered [np][B][hp][wp][c] array

@@ -7,6 +7,7 @@
 #include "igemm_s3.h"
 #include "igemm_pipe.h"
 #include "igemm_region.h"
+#include "heads_lat.h"
 #include "conv_b4_fused.h"
 #include "conv_b3_fused.h"
 #include "conv_b42_fused.h"
@@ -39,7 +40,7 @@ constexpr int LEAN8_LDS_BYTES = 2 * (2 * 128 * 64 + 2 * 128 * 64) * 2 + 256 * 16
 
 // LEAN8: the eight-wave double-buffered kernel (igemm_s3_lean8_kernel; 128 x 128 tiles, fp16-plane mode, layers whose K-tiles hold 64 channels)
 template <class L, int BM, int BN, int WGM, bool OUT32, int NP, bool LEAN8 = false>
-static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats) {
+static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats, LatIO* lat = nullptr) {
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, 1);
     const long tiles = (long)grid.x * grid.y;
     const int n_iter = (p.Kp + IG_BK - 1) / IG_BK;
@@ -53,6 +54,11 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     p.k_split = split;
     p.partial = ws;
     grid.z = split;
+    // round 5: a split-K launch of the lean kernels with at most 40 GEMM rows (the 4 x 5 layers of one or two pairs) is finished by the last workgroup of
+    // each tile to arrive (lat->tickets, igemm_s3.h s3_splitk_last_arriver) instead of a splitk_reduce* launch: 13.3 -> 11.3 us per layer at batch 1.  From 70
+    // rows on, one workgroup summing a 64 x 64 tile is slower than the reduce launch that spreads it (block_2_2 12.9 -> 16.1 us): those keep the launch.
+    // hnet_config.variant 30: the reduce launches everywhere (A/B, bitwise tests)
+    uint32_t* const tickets = split > 1 && lat && lat->tickets && p.M <= 40 && tiles <= SPLITK_TICKETS ? lat->tickets : nullptr;
     // XCD-aware tile mapping (igemm_s3.h): -2..-4 % on the >= 64-channel layers, +3 % on the 32-channel ones -> wide taps only
     p.xcd_remap = L::WIDE_TAPS ? 1 : 0;
 
@@ -66,13 +72,16 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats)
     // staging, the LDS-DMA ring (igemm_s3_dma_kernel), 96 / 64x128 / 128x64 tiles for the 128-channel layers, the eight-wave kernel on the conv layers.
     if constexpr (NP != 1 && BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS) {      // (plain bf16, reported only: the register-staged kernel throughout)
         if constexpr (L::template lean_ok<64>()) {
+            p.tickets = tickets;
             hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 64, NP>), grid, dim3(256), 0, s, p);
-            return finish_split(p, split, ws, s);
+            return tickets ? hipGetLastError() : finish_split(p, split, ws, s);
         }
     }
-    if constexpr (NP != 1 && L::template lean_ok<32>())
+    if constexpr (NP != 1 && L::template lean_ok<32>()) {
+        p.tickets = tickets;
         hipLaunchKernelGGL((igemm_s3_lean_kernel<L, BM, BN, WGM, OUT32, 32, NP>), grid, dim3(256), 0, s, p);
-    else if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS)
+        if (tickets) return hipGetLastError();
+    } else if constexpr (BM * BN <= 128 * 64 && L::SEGMENT >= 32 && L::WIDE_TAPS)
         hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 64, 16, NP>), grid, dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((igemm_s3_kernel<L, BM, BN, WGM, OUT32, 1, 32, 16, NP>), grid, dim3(256), 0, s, p);
@@ -131,7 +140,7 @@ static bool region_ok(const S3Params& p) {
 }
 
 template <int CIN, int KS, int STRIDE, int SEG, int COUT, bool OUT32, int NP>
-static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn) {
+static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_t wsn, LatIO* lat) {
     typedef ConvLoaderS3<CIN, KS, STRIDE, SEG> L;
     if constexpr (NP == 2 && !OUT32 && CIN == 128 && KS == 5 && COUT == 128) {
         if (region_ok<RegionCfg12>(p)) return run_region<RegionCfg12, OUT32>(p, s);
@@ -145,7 +154,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
     if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
         if (pipe_ok<CIN, KS, COUT>(p)) return p.tile == 23 ? run_pipe<L, PipeCfg140, OUT32>(p, s) : run_pipe<L, PipeCfg144, OUT32>(p, s);
     }
-    if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn);
+    if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn, lat);
     else {
         // long-K layers amortise a bigger tile (measured at batch 256): 256 -> 256 3x3 (K 2304) 128 x 64; 128 -> 128 5x5 (K 3200, N = 128: the im2col tile
         // staged once for all of N) 128 x 128 - in the fp16 mode from M = 8192 (64 x 64 / 128 x 128 at batch 64: 0.0291 / 0.0344, 128: 0.0537 / 0.0448,
@@ -153,7 +162,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         const bool big_m = p.M >= 4096;
         if constexpr (CIN == 256) { if (big_m) return run_s3<L, 128, 64, 2, OUT32, NP>(p, s, ws, wsn); }
         if constexpr (CIN == 128 && KS == 5) { if (NP == 2 ? p.M >= 8192 : big_m) return run_s3<L, 128, 128, 2, OUT32, NP>(p, s, ws, wsn); }
-        return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn);
+        return run_s3<L, 64, 64, 2, OUT32, NP>(p, s, ws, wsn, lat);
     }
 }
 
@@ -310,7 +319,25 @@ template <int NP>
 hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int s_begin, float p_drop, uint64_t mc_seed,
                                   uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                   uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s, float* ws, size_t wsn,
-                                  const uint64_t* seq_dev, int tile) {
+                                  const uint64_t* seq_dev, int tile, LatIO* lat) {
+    if constexpr (NP == 2) {
+        // latency path (round 5): keep bits, then ONE launch that owns four hidden units per workgroup over the whole K (heads_lat.h) instead of
+        // feature planes + split-K GEMM + reduce
+        if (lat && batch <= 8 && n_local <= 16 * HL_MAXG) {
+            if (!lat->mask_ready) {
+                const size_t nmw = (size_t)batch * n_local * 2 * 160;
+                hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nmw + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
+                                   hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, (uint16_t*)nullptr, f_plane, mask, NP, 0);
+            }
+            if (n_local <= 32)
+                hipLaunchKernelGGL(heads_fc1_lat_kernel<2>, dim3(512 / HL_UN, (unsigned)batch), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
+                                   n_local, 1.0f / (1.0f - p_drop), hidden);
+            else
+                hipLaunchKernelGGL(heads_fc1_lat_kernel<HL_MAXG>, dim3(512 / HL_UN, (unsigned)batch), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
+                                   n_local, 1.0f / (1.0f - p_drop), hidden);
+            return hipGetLastError();
+        }
+    }
     const size_t nwork = std::max((size_t)batch * 5120, (size_t)batch * n_local * 2 * 160);      // one feature element, four mask bytes per thread
     // heads_prep_kernel forms its byte and row indices in 32 bits (i0 = blockIdx.x * 1024, row = i0 / 640): refuse what would wrap
     // (batch x n_local beyond ~3.3 M rows, or more than ~200 k pairs; hnet_create rejects such a max_batch x N as well)
@@ -346,7 +373,7 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
 template <int NP>
 hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int batch, int h, int w, const uint16_t* wplanes,
                              size_t w_plane, const float* bias, uint16_t* out16, size_t o_plane, float* out32, hipStream_t s,
-                             float* ws, size_t wsn, const uint16_t* wfrag, int tile) {
+                             float* ws, size_t wsn, const uint16_t* wfrag, int tile, LatIO* lat) {
     if (layer < 0 || layer >= 20 || !conv_is_s3_layer(layer)) return hipErrorInvalidValue;
     const ConvDesc& d = kConvs[layer];
     S3Params p = {};
@@ -362,17 +389,17 @@ hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int
     p.Kp = conv_padded_k(layer);
     const bool o32 = out32 != nullptr;
     switch (layer) {
-        case 1:  return run_conv_s3<128, 5, 2, 32, 128, false, NP>(p, s, ws, wsn);
+        case 1:  return run_conv_s3<128, 5, 2, 32, 128, false, NP>(p, s, ws, wsn, lat);
         case 2: case 5: case 11: case 18:
-            return o32 ? run_conv_s3<128, 3, 2, 32, 256, true, NP>(p, s, ws, wsn) : run_conv_s3<128, 3, 2, 32, 256, false, NP>(p, s, ws, wsn);
-        case 4:  return run_conv_s3<64, 5, 2, 32, 128, false, NP>(p, s, ws, wsn);
+            return o32 ? run_conv_s3<128, 3, 2, 32, 256, true, NP>(p, s, ws, wsn, lat) : run_conv_s3<128, 3, 2, 32, 256, false, NP>(p, s, ws, wsn, lat);
+        case 4:  return run_conv_s3<64, 5, 2, 32, 128, false, NP>(p, s, ws, wsn, lat);
         case 6: case 12: case 19:
-            return o32 ? run_conv_s3<256, 3, 2, 32, 256, true, NP>(p, s, ws, wsn) : run_conv_s3<256, 3, 2, 32, 256, false, NP>(p, s, ws, wsn);
-        case 8:  return run_conv_s3<16, 5, 2, 16, 32, false, NP>(p, s, ws, wsn);
-        case 9: case 16: return run_conv_s3<32, 3, 2, 32, 64, false, NP>(p, s, ws, wsn);
-        case 10: case 17: return run_conv_s3<64, 3, 2, 32, 128, false, NP>(p, s, ws, wsn);
-        case 14: return run_conv_s3<8, 5, 2, 8, 16, false, NP>(p, s, ws, wsn);
-        case 15: return run_conv_s3<16, 3, 2, 16, 32, false, NP>(p, s, ws, wsn);
+            return o32 ? run_conv_s3<256, 3, 2, 32, 256, true, NP>(p, s, ws, wsn, lat) : run_conv_s3<256, 3, 2, 32, 256, false, NP>(p, s, ws, wsn, lat);
+        case 8:  return run_conv_s3<16, 5, 2, 16, 32, false, NP>(p, s, ws, wsn, lat);
+        case 9: case 16: return run_conv_s3<32, 3, 2, 32, 64, false, NP>(p, s, ws, wsn, lat);
+        case 10: case 17: return run_conv_s3<64, 3, 2, 32, 128, false, NP>(p, s, ws, wsn, lat);
+        case 14: return run_conv_s3<8, 5, 2, 8, 16, false, NP>(p, s, ws, wsn, lat);
+        case 15: return run_conv_s3<16, 3, 2, 16, 32, false, NP>(p, s, ws, wsn, lat);
     }
     return hipErrorInvalidValue;
 }
@@ -394,6 +421,8 @@ hipError_t conv_kernels_init_device_np() {
         HNET_REGION_ATTR(RegionCfg13, false); HNET_REGION_ATTR(RegionCfg13, true); HNET_REGION_ATTR(RegionCfgT, false); HNET_REGION_ATTR(RegionCfgT, true);
 #undef HNET_REGION_ATTR
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_heads_pipe_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadsPipeCfg::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)heads_fc1_lat_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)heads_fc1_lat_kernel<HL_MAXG>, hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES + B3Cfg::SPARE_BYTES);
     }
@@ -418,9 +447,9 @@ hipError_t conv_kernels_init_device_np() {
                                                     size_t, hipStream_t, bool, int);                                                           \
     KW template hipError_t launch_heads_fc1_s3_np<NP>(const float*, int, int, int, float, uint64_t, uint64_t, const uint16_t*,           \
                                                       const float*, float*, uint16_t*, size_t, uint8_t*, hipStream_t, float*, size_t,    \
-                                                      const uint64_t*, int);                                                             \
+                                                      const uint64_t*, int, LatIO*);                                                     \
     KW template hipError_t launch_conv_s3_np<NP>(int, const uint16_t*, size_t, int, int, int, const uint16_t*, size_t, const float*,     \
-                                                 uint16_t*, size_t, float*, hipStream_t, float*, size_t, const uint16_t*, int);          \
+                                                 uint16_t*, size_t, float*, hipStream_t, float*, size_t, const uint16_t*, int, LatIO*);  \
     KW template hipError_t conv_kernels_init_device_np<NP>();
 
 }  // namespace hnet
