@@ -70,6 +70,10 @@ def parse(argv=None):
                     help="skip the additional measurements of the default run (sustained window, other arithmetic modes, configs 3 / 5, "
                          "reference launch default latency)")
     ap.add_argument("--sustain-seconds", type=float, default=1.6, help="length of the sustained window of the default run")
+    ap.add_argument("--contexts", type=int, default=1, metavar="NC",
+                    help="independent steps issued round-robin on NC contexts, each with its own HIP stream and buffers (--mode pairs, one GPU): the launch chain of "
+                         "one step runs under the kernels of the others; what a server with independent mid-size batches does (the default run reports BASELINE "
+                         "configs 3 and 5's per-GPU shape both ways)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
@@ -413,8 +417,10 @@ def sub_run(base, ctx, **over):
     for k, v in over.items():
         setattr(a, k, v)
     r, ok = run(a, ctx, primary=False)
-    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err")
+    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms")
     out = {k: r[k] for k in keep if k in r}
+    if getattr(a, "contexts", 1) > 1:
+        out["contexts"] = a.contexts
     out["passed"] = bool(ok)
     out["workload"] = r["config"]["workload"]
     out["precision"] = r["config"]["precision"]
@@ -476,6 +482,17 @@ def run(args, ctx, primary):
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
+    # --contexts NC: step i runs on context i % NC (own stream, own activation buffers, own output record; the inputs are read-only and shared)
+    NC = max(1, int(getattr(args, "contexts", 1) or 1))
+    if NC > 1 and (collective or mc_mode or args.mode == "stream"):
+        raise SystemExit("--contexts: single-GPU --mode pairs only")
+    engs, streams, outs = [eng], [stream], [out]
+    for _ in range(NC - 1):
+        engs.append(HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec))
+        streams.append(torch.cuda.Stream(dev))
+        outs.append(torch.zeros(B, 72, device=dev))
+    if NC > 1:
+        out_of_step = lambda i: outs[i % NC]
     if mc_mode:
         n_loc = shard[1] - shard[0]
         ms_loc, lv_loc = torch.zeros(B, n_loc, 8, device=dev), torch.zeros(B, n_loc, 8, device=dev)
@@ -575,7 +592,8 @@ def run(args, ctx, primary):
             return
         if og is not None:
             og.acquire(i, stream)
-        eng.infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None, sp)
+        engs[i % NC].infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None,
+                                               streams[i % NC].cuda_stream)
         if og is not None:
             og.submit(i, stream)
 
@@ -629,7 +647,7 @@ def run(args, ctx, primary):
         "dtype": dtype_label, "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
                                f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
-                   "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision,
+                   "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision, "contexts": NC,
                    "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
                                    if mc_mode else
                                    (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if collective else "single GPU")),
@@ -637,6 +655,8 @@ def run(args, ctx, primary):
         "mc_preds_per_s": round(value * n_mc, 1),
         "rccl_ranks": dist.get_world_size() if collective else 1, "backend": backend,
     }
+    if NC > 1:
+        res["config"]["workload"] += f"; independent steps round-robin on {NC} contexts / HIP streams"
     if replay is not None:
         res["config"]["workload"] += f"; frames rendered along UZH-FPV {replay['name']} (tests/golden/replay_{args.replay}.npz), priors from the EKF mean propagation"
         res["config"]["sequence"] = replay["name"]
@@ -675,6 +695,13 @@ def run(args, ctx, primary):
         res["verify"] = {"against": "oracle/ (CPU restatement, double accumulation)", "slots_per_rank": slots, "step": last,
                          "gate_px": gate_px if gated else None, "passed": bool(ok)}
 
+    if rank == 0 and not primary and getattr(args, "latency_probe", False) and not mc_mode and not stream_mode:
+        # BASELINE config 2 per arithmetic mode ("single frame pair ... bf16"): the batch-1 device latency of THIS configuration (graph replay, 200 after 20)
+        e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank, precision=prec)
+        e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 20)
+        per, _tot = e1.time_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 200)
+        res["latency_batch1_ms"] = {"p50": round(float(np.percentile(per, 50)), 4), "p95": round(float(np.percentile(per, 95)), 4)}
+        e1.close()
     if rank == 0 and primary and not mc_mode and not stream_mode:
         # ---- roofline of the dominant kernel: per-launch HIP events on the stream the kernels run on.
         # executed FLOP = 2 x MACs x (MFMAs per MAC): three fp16 MFMAs stand behind every MAC of the default mode, six bf16 ones in split-bf16;
@@ -734,12 +761,15 @@ def run(args, ctx, primary):
             e1.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 5)
             l_ms = e1.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, 1, 0, mean.data_ptr(), cov.data_ptr(), 50)
             l_st = e1.stages()
-            rows, fl_total = latency_floor([n for n, _ in l_st], [float(f) for _, f in l_st], [1e3 * float(m) for m in l_ms], n_mc, mfma_per_mac, peak_tf)
+            l_k = e1.stage_kernels()
+            rows, fl_total = latency_floor([n for n, _ in l_st], [float(f) for _, f in l_st], [1e3 * float(m) for m in l_ms], n_mc, mfma_per_mac, peak_tf, l_k)
             res["latency_batch1_ms"]["per_launch_us"] = rows
             res["latency_batch1_ms"]["launches"] = len(rows)
+            res["latency_batch1_ms"]["kernels"] = int(sum(l_k))
             res["latency_batch1_ms"]["sum_of_launches_us"] = round(float(sum(r["us"] for r in rows)), 1)
             res["latency_batch1_ms"]["floor_us"] = round(fl_total, 1)
-            res["latency_batch1_ms"]["floor_definition"] = ("sum over the launches of max(compulsory bytes / 8 TB/s, issued FLOP / dense peak, 1.45 us kernel boundary); "
+            res["latency_batch1_ms"]["floor_definition"] = ("sum over the launches of max(compulsory bytes / 8 TB/s, issued FLOP / dense peak, 1.45 us kernel boundary) + 1.45 us "
+                                                            "for every further kernel of a launch (a split-K layer's reduce kernel; `kernels` = hnet_stage_kernels); "
                                                             "per-launch times are event to event (they include the boundary in front of the launch)")
             res["latency_batch1_ms"]["p50_over_floor"] = round(1e3 * res["latency_batch1_ms"]["p50"] / fl_total, 2)
             e1.close()
@@ -772,13 +802,33 @@ def run(args, ctx, primary):
             for pm in ("bf16x3", "fp32", "bf16"):
                 if pm != args.precision:
                     time.sleep(1.0)
-                    res["modes"][pm] = sub_run(args, ctx, precision=pm, no_extras=True)
+                    res["modes"][pm] = sub_run(args, ctx, precision=pm, no_extras=True, latency_probe=True)      # + BASELINE config 2 in that mode (batch-1 latency)
+
+            def both_ways(**kw):
+                # Mid-size batches leave the chip waiting on their own launch chain (25 dependent launches of 8 - 20 us each): a deployment with INDEPENDENT
+                # steps - config 3's batches, config 5's per-GPU share of a streamed sequence - issues them round-robin on a few contexts / HIP streams so that one
+                # step's chain runs under the others' kernels.  `value` = that with TWO contexts (tools/pipeline_ctx_bench.py measured 1 / 2 / 3 / 4: three or four are
+                # faster still on a quiet box, 178 - 182 k pairs/s at 64 pairs, but not reliably so); the one-context figure of rounds 1 - 4 stays beside it.
+                one = sub_run(args, ctx, contexts=1, **kw)
+                # (a child process, like the streamed configuration: which hardware queues two streams get depends on every stream the process created before;
+                # after the other sub-runs the in-process figure was 125 k pairs/s where the same command alone gives 174 - 177 k)
+                pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "2", "--steps", "60", "--warmup", "10",
+                                 "--precision", str(args.precision), "--no-extras", "--no-cpu-baseline", "--no-latency"])
+                if "error" in pip:
+                    err = pip["error"]
+                    pip = sub_run(args, ctx, contexts=2, steps=60, warmup=10, **kw)
+                    pip["process"] = "in process (child run failed: " + err + ")"
+                pip["contexts"] = 2
+                pip["single_context"] = {k: one[k] for k in ("value", "ms_per_step", "steps", "max_px_err", "passed") if k in one}
+                pip["passed"] = bool(pip["passed"] and one["passed"])
+                return pip
+
             res["configs"] = {
-                "config3_prior3_b64_n16": sub_run(args, ctx, variant="prior3", batch=64, mc=16, no_extras=True),
+                "config3_prior3_b64_n16": both_ways(variant="prior3", batch=64, mc=16, no_extras=True),
                 "config4_mc_n32_one_pair": sub_run(args, ctx, mode="mc", batch=1, no_extras=True),
                 "config5_replay_stream_prior3_b256": None,
 
-                "config5_shape_32_pairs_per_gpu": sub_run(args, ctx, variant="prior3", batch=32, mc=16, no_extras=True),
+                "config5_shape_32_pairs_per_gpu": both_ways(variant="prior3", batch=32, mc=16, no_extras=True),
             }
             # (40 steps after 10: the first H2D copies out of freshly pinned buffers run at a fraction of the link rate)
             stream_argv = ["--mode", "stream", "--replay", "indoor_forward_7", "--variant", "prior3", "--mc", "16", "--batch", str(args.batch),
@@ -800,7 +850,8 @@ def run(args, ctx, primary):
     if stream_mode and use_thread:
         up_q.put(None)
         up_thread.join()
-    eng.close()
+    for e_ in engs:
+        e_.close()
     return res, ok
 
 
@@ -837,7 +888,7 @@ def parity_from_table(root):
     return out
 
 
-def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_tf):
+def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_tf, stage_kernels=None):
     """SURVEY.md section 8(d), batch 1: "report as us, plus % of the sum of per-kernel roofline times".  Per launch of the latency path:
     floor = max(compulsory bytes / 8 TB/s, issued FLOP / the instruction's dense peak, 1.45 us) - 1.45 us is what MI355X_MICROARCH.md prices a dependent
     kernel boundary at.  Bytes = weights (4 B per element in the two-plane fp16 form, fp32 for the small FCs) + the layer's input and output activations
@@ -853,7 +904,9 @@ def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_t
         geo[name] = 4.0 * (cout * cin * k * k + h * w * cin + ho * wo * cout)
         h, w = ho, wo
     rows, total_floor = [], 0.0
-    for n, fl, us in zip(stage_names, stage_flops, stage_us):
+    if stage_kernels is None:
+        stage_kernels = [1] * len(stage_names)
+    for n, fl, us, nk in zip(stage_names, stage_flops, stage_us, stage_kernels):
         by = 0.0
         for part in n.replace("fc_dlt+", "fc_dlt_bX+").replace("prior_dlt+", "").split("+"):
             part = part.strip()
@@ -874,9 +927,10 @@ def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_t
                 by += 2 * 224 * 320 + 224 * 320
         mf = 1 if (n.startswith("fc_dlt") and "prep" not in n) or n.startswith("heads_fc2") else mfma_per_mac
         t_b, t_f = by / 8e12 * 1e6, fl * mf / ((peak_tf if mf > 1 else 157.3) * 1e12) * 1e6
-        fl_us = max(t_b, t_f, 1.45)
+        fl_us = max(t_b, t_f, 1.45) + 1.45 * (max(1, int(nk)) - 1)       # every further kernel of the launch is one more dependent boundary
         total_floor += fl_us
-        rows.append({"launch": n, "us": round(float(us), 2), "floor_us": round(float(fl_us), 2), "bound": "boundary" if fl_us == 1.45 else ("hbm" if t_b >= t_f else "mfma")})
+        rows.append({"launch": n, "us": round(float(us), 2), "kernels": int(nk), "floor_us": round(float(fl_us), 2),
+                     "bound": "boundary" if max(t_b, t_f) <= 1.45 else ("hbm" if t_b >= t_f else "mfma")})
     return rows, float(total_floor)
 
 

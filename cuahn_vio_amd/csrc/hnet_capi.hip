@@ -69,7 +69,7 @@ bool parse_blob(const uint8_t* p, size_t len, Blob& out) {
     return true;
 }
 
-struct Stage { std::string name; double flops_per_pair; };
+struct Stage { std::string name; double flops_per_pair; int kernels = 1; };      // kernels: what the launch of the last forward consisted of (hnet_stage_kernels)
 
 }  // namespace
 
@@ -334,6 +334,7 @@ struct FwdArgs {
 #define STAGE(call)                                                                                         \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
+        stage_i++;                                                                                          \
         if (e_ != hipSuccess) return fail(c, HNET_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
         if (!c->prof_ev.empty() && c->prof_pos < c->prof_ev.size()) {                                       \
             e_ = hipEventRecord(c->prof_ev[c->prof_pos++], s);                                              \
@@ -358,6 +359,8 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // `pend` holds what the next prep has to evaluate; the homographies alternate between Hm and Hm2 (a workgroup stores the new one while
     // others still read the old one).
     const bool small = c->fuse_small && B <= 8;
+    size_t stage_i = 0;                            // launches so far (index into c->stages when that list describes this forward)
+    auto set_kernels = [&](int k) { if (stage_i >= 1 && stage_i <= c->stages.size()) c->stages[stage_i - 1].kernels = k; };
     // the keep bits of the heads depend on the seeds only: on the latency path they are drawn by surplus workgroups of block 4's prep launch (FcArgs::mask)
     const bool mask_in_prep = small && c->lat_tail && c->s3 && heads_fc1_one_launch(B, c->n_local, c->n_planes);
     bool mask_ready = false;
@@ -440,9 +443,10 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             else if (c->use_patch && (conv_is_patch_layer(l) || (c->use_patch32 && conv_is_patch32_layer(l) && h == 56 && w == 80)))
                 STAGE(launch_conv_patch(l, in16, in_plane, B, h, w, c->patch_frag[l], c->conv_b[l], o16, MB * cnt, s, c->n_planes, c->patch_b128, c->patch_rb5));
             else if (c->s3 && conv_is_s3_layer(l)) {
-                LatIO lat = {c->lat_tail && ws ? reinterpret_cast<uint32_t*>(c->ws + c->ws_floats) : nullptr};
+                LatIO lat = {c->lat_tail && ws ? reinterpret_cast<uint32_t*>(c->ws + c->ws_floats) : nullptr, 1, false, false};
                 STAGE(launch_conv_s3(l, in16, in_plane, B, h, w, c->conv_w16[l], (size_t)kConvs[l].cout * conv_padded_k(l),
                                      c->conv_b[l], o16, MB * cnt, o16 ? nullptr : o, s, ws, wsn, c->conv_wfrag[l], c->n_planes, c->s3_tile, &lat));
+                set_kernels(lat.kernels);
             } else
                 STAGE(launch_conv(l, in, B, h, w, c->conv_w[l], c->conv_b[l], o, s, ws, wsn, o16, MB * cnt));
             in = o;
@@ -462,10 +466,11 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     const float* feat = c->act[19] + P0 * 5120;
     float* hidden = c->hidden + P0 * c->n_local * 512;
     if (c->s3) {
-        LatIO lat_h = {nullptr, mask_ready};
+        LatIO lat_h = {nullptr, 1, small && c->lat_tail && c->n_planes == 2, mask_ready};
         STAGE(launch_heads_fc1_s3(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1_16, c->b1, hidden,
                                   c->feat16 + P0 * 5120, (size_t)g.max_batch * 5120, c->head_mask + P0 * c->n_local * 2 * 640, s, ws, wsn, a.seq_dev, c->n_planes,
-                                  c->s3_tile, small && c->lat_tail && c->n_planes == 2 ? &lat_h : nullptr));
+                                  c->s3_tile, &lat_h));
+        set_kernels(lat_h.kernels);
     }
     else
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
@@ -1442,6 +1447,7 @@ int hnet_time_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, 
 /* ---- per-stage (per kernel launch) device timing with HIP events on the context stream ---- */
 int hnet_stage_count(const hnet_ctx* c) { return c ? (int)c->stages.size() : 0; }
 const char* hnet_stage_name(const hnet_ctx* c, int i) { return (c && i >= 0 && i < (int)c->stages.size()) ? c->stages[i].name.c_str() : ""; }
+int hnet_stage_kernels(const hnet_ctx* c, int i) { return (c && i >= 0 && i < (int)c->stages.size()) ? c->stages[i].kernels : 0; }
 double hnet_stage_flops_per_pair(const hnet_ctx* c, int i) { return (c && i >= 0 && i < (int)c->stages.size()) ? c->stages[i].flops_per_pair : 0.0; }
 
 int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,

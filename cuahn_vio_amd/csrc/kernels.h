@@ -37,6 +37,8 @@ int conv_region_taps_padded(int layer);       // taps per 64-channel chunk in th
 constexpr int SPLITK_TICKETS = 4096;
 struct LatIO {
     uint32_t* tickets;        // nullptr: splitk_reduce* launches
+    int kernels;              // result: kernels this call launched (a split-K layer with a splitk_reduce* launch: 2; the heads' first FC: 1 - 3)
+    bool heads_one_launch;    // launch_heads_fc1_s3: take the one-launch kernel of heads_lat.h where it applies (heads_fc1_one_launch)
     bool mask_ready;          // launch_heads_fc1_s3: the keep bits have been written already (by the surplus workgroups of block 4's prep launch, FcArgs::mask)
 };
 bool heads_fc1_one_launch(int batch, int n_local, int n_planes);      // whether launch_heads_fc1_s3 with a LatIO takes the one-launch kernel of heads_lat.h
@@ -73,7 +75,7 @@ hipError_t launch_heads_fc1_s3(const float* feat, int batch, int n_local, int s_
                                uint64_t pair_seq0, const uint16_t* w1planes, const float* b1, float* hidden,
                                uint16_t* feat16, size_t f_plane, uint8_t* mask, hipStream_t s,
                                float* ws = nullptr, size_t ws_floats = 0, const uint64_t* seq_dev = nullptr, int n_planes = 3, int tile = 0,
-                               LatIO* lat = nullptr /* non-null, fp16-plane mode, batch <= 8, n_local <= 64: the one-launch kernel of heads_lat.h */);
+                               LatIO* lat = nullptr /* lat->heads_one_launch, fp16-plane mode, batch <= 8, n_local <= 64: the one-launch kernel of heads_lat.h */);
 hipError_t launch_nchw_f32_to_nhwc_s3(const float* in, uint16_t* out, size_t o_plane, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 hipError_t launch_nhwc_s3_to_nchw_f32(const uint16_t* in, size_t i_plane, float* out, int batch, int c, int h, int w, hipStream_t s, int n_planes = 3);
 

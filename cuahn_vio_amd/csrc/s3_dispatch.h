@@ -34,7 +34,7 @@ static hipError_t finish_split_impl(const S3Params& p, int split, float* ws, hip
     }
     return hipGetLastError();
 }
-#define finish_split(p, split, ws, s) finish_split_impl<OUT32, NP>(p, split, ws, s)
+#define finish_split(p, split, ws, s) (((split) > 1 && lat) ? (void)(lat->kernels = 2) : (void)0, finish_split_impl<OUT32, NP>(p, split, ws, s))
 
 constexpr int LEAN8_LDS_BYTES = 2 * (2 * 128 * 64 + 2 * 128 * 64) * 2 + 256 * 16;      // igemm_s3_lean8_kernel: two buffers of tiles + the mask table
 
@@ -54,6 +54,7 @@ static hipError_t run_s3(S3Params p, hipStream_t s, float* ws, size_t ws_floats,
     p.k_split = split;
     p.partial = ws;
     grid.z = split;
+    if (lat) lat->kernels = 1;
     // round 5: a split-K launch of the lean kernels with at most 40 GEMM rows (the 4 x 5 layers of one or two pairs) is finished by the last workgroup of
     // each tile to arrive (lat->tickets, igemm_s3.h s3_splitk_last_arriver) instead of a splitk_reduce* launch: 13.3 -> 11.3 us per layer at batch 1.  From 70
     // rows on, one workgroup summing a 64 x 64 tile is slower than the reduce launch that spreads it (block_2_2 12.9 -> 16.1 us): those keep the launch.
@@ -323,7 +324,8 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     if constexpr (NP == 2) {
         // latency path (round 5): keep bits, then ONE launch that owns four hidden units per workgroup over the whole K (heads_lat.h) instead of
         // feature planes + split-K GEMM + reduce
-        if (lat && batch <= 8 && n_local <= 16 * HL_MAXG) {
+        if (lat && lat->heads_one_launch && batch <= 8 && n_local <= 16 * HL_MAXG) {
+            lat->kernels = lat->mask_ready ? 1 : 2;
             if (!lat->mask_ready) {
                 const size_t nmw = (size_t)batch * n_local * 2 * 160;
                 hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nmw + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
@@ -352,6 +354,9 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
     const bool pipe = NP == 2 && one_per_cu && tile != 22;
     hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nwork + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
                        hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, feat16, f_plane, mask, NP, pipe ? 1 : 0);
+    LatIO lat_count = {};                      // (feature planes + keep bits, the GEMM, its reduce launch if it splits K)
+    if (!lat) lat = &lat_count;
+    lat->tickets = nullptr;
     S3Params p = {};
     p.A = feat16; p.a_plane = f_plane; p.Wp = w1planes; p.w_plane = (size_t)512 * 5120; p.bias = b1;
     p.out32 = hidden;
@@ -361,13 +366,19 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
         if (pipe) {
             p.k_split = 1;
             hipLaunchKernelGGL(igemm_heads_pipe_kernel<NP>, dim3((unsigned)((p.M + 127) / 128), 4, 1), dim3(HeadsPipeCfg::NT), HeadsPipeCfg::LDS_BYTES, s, p);
+            lat->kernels = 2;
             return hipGetLastError();
         }
-        if (one_per_cu) return run_s3<HeadLoaderS3, 128, 128, 2, true, NP, true>(p, s, ws, wsn);
+    }
+    hipError_t e = hipSuccess;
+    bool done = false;
+    if constexpr (NP == 2) {
+        if (one_per_cu) { e = run_s3<HeadLoaderS3, 128, 128, 2, true, NP, true>(p, s, ws, wsn, lat); done = true; }
     }
     // K = 5120 (160 K-tiles): the 128x64 tile amortises better (0.317 vs 0.353 ms at batch 256); small M keeps 64x64 + split-K
-    if (p.M >= 4096) return run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn);
-    return run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, ws, wsn);
+    if (!done) e = p.M >= 4096 ? run_s3<HeadLoaderS3, 128, 64, 2, true, NP>(p, s, ws, wsn, lat) : run_s3<HeadLoaderS3, 64, 64, 2, true, NP>(p, s, ws, wsn, lat);
+    lat->kernels += 1;                         // + heads_prep_kernel
+    return e;
 }
 
 template <int NP>

@@ -154,6 +154,10 @@ class HnetEngine:
         n = self._L.hnet_stage_count(self._h)
         return [(self._L.hnet_stage_name(self._h, i).decode(), self._L.hnet_stage_flops_per_pair(self._h, i)) for i in range(n)]
 
+    def stage_kernels(self):
+        """kernels per stage of the last profiled forward (hnet_stage_kernels: a split-K layer with a separate reduce launch counts 2)"""
+        return [int(self._L.hnet_stage_kernels(self._h, i)) for i in range(self._L.hnet_stage_count(self._h))]
+
     def profile_batch_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov, iters):
         ms = np.zeros(self._L.hnet_stage_count(self._h), np.float32)
         check(self._h, self._L.hnet_profile_batch_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean, d_cov,

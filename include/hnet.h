@@ -238,6 +238,8 @@ int hnet_time_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr
 int hnet_stage_count(const hnet_ctx* ctx);
 const char* hnet_stage_name(const hnet_ctx* ctx, int i);
 double hnet_stage_flops_per_pair(const hnet_ctx* ctx, int i);
+/* kernels the stage's launch consisted of in the last profiled forward (a split-K layer with a separate reduce launch: 2); the fp32-MFMA mode reports 1 */
+int hnet_stage_kernels(const hnet_ctx* ctx, int i);
 int hnet_profile_batch_device(hnet_ctx* ctx, const void* d_prev, const void* d_curr, int pix_fmt,
                               const float* d_prior, int batch, uint64_t pair_seq0, float* d_mean, float* d_cov,
                               int iters, float* stage_ms_avg);
