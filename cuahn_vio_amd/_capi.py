@@ -23,7 +23,7 @@ SYMBOLS = [
     "hnet_infer_batch", "hnet_infer_batch_device", "hnet_infer_batch_packed_device", "hnet_infer_mc_partial_device", "hnet_mc_finish_device",
     "hnet_mc_finish_packed_device",
     "hnet_synchronize", "hnet_last_timing", "hnet_time_batch_device", "hnet_stage_count", "hnet_stage_name",
-    "hnet_stage_flops_per_pair", "hnet_stage_kernels", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
+    "hnet_stage_flops_per_pair", "hnet_stage_kernels", "hnet_get_config", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
     "hnet_op_block4_fused", "hnet_op_block3_fused", "hnet_op_block42_fused", "hnet_precision", "hnet_overflow_flag",

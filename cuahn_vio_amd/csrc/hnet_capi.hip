@@ -812,20 +812,44 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     hnet_default_config(&g);
     memcpy(&g, cfg_in, std::min<size_t>(cfg_in->struct_size ? cfg_in->struct_size : sizeof(g), sizeof(g)));
     g.struct_size = sizeof(g);
-    if (g.max_batch < 1 || g.mc_samples < 1 || g.mc_samples > 256 || g.dropout_p < 0.f || g.dropout_p >= 1.f)
+    if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
+    if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42)) return HNET_ERR_INVALID_ARG;
+    {
+        const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
+        static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
+        if (std::find(std::begin(known), std::end(known), code) == std::end(known)) return HNET_ERR_INVALID_ARG;
+    }
+    // the LDS-DMA / buffer-load kernels address an activation with 31-bit byte offsets (a buffer descriptor covers 2 GiB; an offset beyond it reads zeros,
+    // silently).  The largest array is block_4_1's bordered map, B42_IMG x 16 channels x 2 bytes = 603 520 bytes per pair and plane, and block42_fused_kernel
+    // reaches BOTH fp16 planes through one descriptor (lane offset = plane + patch chunk, scalar offset = tile origin): the sum of the two stays inside the
+    // descriptor - whichever of them the hardware range-checks - for 2 x max_batch x 603 520 < 2^31 -> 1 779 pairs (round 4 bounded one plane: 3 558).
+    // Larger batches: several calls.
+    if ((size_t)2 * g.max_batch * B42_IMG * 32 >= ((size_t)1 << 31)) return HNET_ERR_CAPACITY;
+    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
+        return HNET_ERR_UNSUPPORTED;
+    Blob b;
+    if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
+    // the model variant: what the reference bakes into the traced .pt it loads (trace_model.py:16,36-46; HomographyNet.cpp:81-124 only names the file) comes from
+    // the blob's `hnet.variant` record wherever the caller left the field at HNET_FROM_FILE; without a record, the reference's launch values
+    {
+        const Tensor* v = b.find("hnet.variant", {8});
+        const bool rec = v && v->data[0] == 1.0f;
+        if (v && !rec) return HNET_ERR_BAD_WEIGHTS;                       // a record version this library does not know
+        if (g.use_prior == HNET_FROM_FILE) g.use_prior = rec ? (int)v->data[1] : 1;
+        if (g.blocks_to_run == HNET_FROM_FILE) g.blocks_to_run = rec ? (int)v->data[2] : 3;
+        if (g.mc_samples == HNET_FROM_FILE) g.mc_samples = rec ? (int)v->data[3] : 16;
+        if (g.dropout_p < 0.f) g.dropout_p = rec ? v->data[4] : 0.05f;
+        if (g.emit_error_map == HNET_FROM_FILE) g.emit_error_map = rec ? (int)v->data[5] : 0;
+    }
+    if (g.mc_samples < 1 || g.mc_samples > 256 || !(g.dropout_p >= 0.f) || g.dropout_p >= 1.f || (g.use_prior != 0 && g.use_prior != 1) ||
+        (g.emit_error_map != 0 && g.emit_error_map != 1))
         return HNET_ERR_INVALID_ARG;
     if (g.use_prior && (g.blocks_to_run < 1 || g.blocks_to_run > 3)) return HNET_ERR_INVALID_ARG;
     if ((size_t)g.max_batch * std::max((size_t)g.mc_samples * 1280, (size_t)4 * 5120) + 1024 >= ((size_t)1 << 32)) return HNET_ERR_CAPACITY;   // 32-bit indices of the keep-bit kernel (s3_dispatch.h)
-    // the LDS-DMA / buffer-load kernels address a plane of an activation with 31-bit byte offsets (a buffer descriptor covers 2 GiB; an offset beyond it reads zeros,
-    // silently): the largest plane is block_4_1's bordered map, B42_IMG x 16 channels x 2 bytes = 603 520 bytes per pair -> 3 558 pairs.  Larger batches: several calls.
-    if ((size_t)g.max_batch * B42_IMG * 32 >= ((size_t)1 << 31)) return HNET_ERR_CAPACITY;
-    if (g.precision != HNET_PREC_FP32 && g.precision != HNET_PREC_BF16X3 && g.precision != HNET_PREC_BF16 && g.precision != HNET_PREC_F16X2)
-        return HNET_ERR_UNSUPPORTED;
     if (g.mc_sample_begin == 0 && g.mc_sample_end == 0) g.mc_sample_end = g.mc_samples;
     if (g.mc_sample_begin < 0 || g.mc_sample_end > g.mc_samples || g.mc_sample_begin >= g.mc_sample_end)
         return HNET_ERR_INVALID_ARG;
-    Blob b;
-    if (!parse_blob(blob, len, b)) return HNET_ERR_BAD_WEIGHTS;
 
     if (g.precision == HNET_PREC_F16X2) {     // fp16 planes carry 4096 w: every matrix-core weight must stay below 16 (s3_format.h)
         float wmax = 0.f;
@@ -865,9 +889,9 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     c->s3_tile = (int)(g.variant & HNET_VARIANT_GEMM_MASK);
     c->lat_tail = c->s3_tile != 30;                // (30: the splitk_reduce* launches and the split-K heads of rounds 1 - 4, A/B and bitwise tests)
     c->a14_pad = c->fuse_b4 && c->fuse_b42;
-    c->patch_rb5 = c->s3_tile == 27 ? -32 : 5;   // (variant 27: block_3_2 on the patch kernel without prefetch, A/B)  region rows per batch of staging loads in the 5x5 patch kernel: measured 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256
+    c->patch_rb5 = 5;
     c->patch_b128 = true;
-    c->b4_flags = c->s3_tile == 26 ? 32 : 0;       // (variant 26: the 7 x 32 tiles of rounds 2 - 3, A/B)
+    c->b4_flags = 0;
     c->n_local = g.mc_sample_end - g.mc_sample_begin;
     c->s_begin = g.mc_sample_begin;
 #define CK(expr)                                                                    \
@@ -1189,6 +1213,11 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     return HNET_OK;
 }
 int hnet_precision(const hnet_ctx* c) { return c ? c->cfg.precision : -1; }
+int hnet_get_config(const hnet_ctx* c, hnet_config* out) {
+    if (!c || !out) return HNET_ERR_INVALID_ARG;
+    *out = c->cfg;
+    return HNET_OK;
+}
 
 int hnet_overflow_flag(hnet_ctx* c, void* stream, int* flags) {
     if (!c || !flags) return HNET_ERR_INVALID_ARG;

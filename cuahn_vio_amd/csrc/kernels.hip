@@ -507,7 +507,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const PIX* __restrict__ img1,
         for (int i = 0; i < 9; i++) h[i] = H[b * 9 + i];
     }
     float s1 = 0.0f, s2 = 0.0f;
-    if constexpr (!WARP && K == 8 && sizeof(PIX) == 1) {
+    // (the 8-byte form needs 8-byte aligned images - each pair is 71 680 bytes further, a multiple of 8 - which hnet_infer_batch*_device does not promise:
+    // an odd buffer takes the byte path below, like the other vectorised prep paths; kernel-uniform)
+    const bool vec8 = !WARP && K == 8 && sizeof(PIX) == 1 && ((((uintptr_t)img1 | (uintptr_t)img2) & 7) == 0);
+    if (vec8) {
         // block 1 of the full model (no warp, 8 x 8 pool, u8 images): the eight pixels of a window row are ONE aligned 8-byte load per image (round 4; as 32 byte
         // loads + 32 table look-ups per lane the kernel ran at half the memory rate with 54 % of its LDS cycles bank conflicts).  Same values (u8_to_unit is
         // bit-identical to the table), same order of the sums.

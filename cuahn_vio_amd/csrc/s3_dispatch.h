@@ -100,7 +100,6 @@ static hipError_t run_pipe(S3Params p, hipStream_t s) {
     hipLaunchKernelGGL((igemm_s3_pipe_kernel<L, C, OUT32>), grid, dim3(C::NT), C::LDS_BYTES, s, p);
     return hipGetLastError();
 }
-typedef PipeCfg<5, 2, 2, 4, 140> PipeCfg140;     // 160 x 128, 512 threads
 typedef PipeCfg<3, 2, 3, 4, 140> PipeCfg144;     // 144 x 128, 768 threads (three waves per SIMD): 2.8 % instead of 12.5 % padded rows
 // the layers it serves, measured in process against the four-wave lean kernels at batch 256 (profiles/r04_ab_pipe*.log): the 160 (140) x 128 tile
 // wins on block_2_2 (- 18 %), block_2_3 / 3_4 / 4_5 (- 22 %) and block_3_3 / 4_4 (- 2 ... - 6 %).  Four-wave tiles of 80 x 128 / 80 x 64 for
@@ -153,7 +152,7 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
         }
     }
     if constexpr (NP == 2 && !OUT32 && ((CIN == 128 && KS == 3 && COUT == 256) || (CIN == 64 && COUT == 128))) {
-        if (pipe_ok<CIN, KS, COUT>(p)) return p.tile == 23 ? run_pipe<L, PipeCfg140, OUT32>(p, s) : run_pipe<L, PipeCfg144, OUT32>(p, s);
+        if (pipe_ok<CIN, KS, COUT>(p)) return run_pipe<L, PipeCfg144, OUT32>(p, s);      // (the 160 x 128 / 512-thread tile of the first build lost to it and was removed in round 5)
     }
     if constexpr (COUT <= 32) return run_s3<L, 128, 32, 4, OUT32, NP>(p, s, ws, wsn, lat);
     else {
@@ -186,11 +185,9 @@ hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* 
                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
     flags &= 113;
     // fp16-plane mode: 8 x 32 tiles (57 KB of LDS: still two workgroups per CU; 16 phase-2 M-tiles = four per wave exactly, 19 / 16 rows of halo instead of 17 / 14).
-    // flags bit 5 (hnet_config.variant 26): the 7 x 32 tiles of rounds 2 - 3 (A/B); the three-plane modes need them for two workgroups per CU
-    if constexpr (NP == 2) {
-        if (!(flags & 32)) return run_block4_fused<8, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
-    }
-    return run_block4_fused<7, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    // (the 7 x 32 tiles of rounds 2 - 3 remain the tile of the three-plane modes, which need them for two workgroups per CU)
+    if constexpr (NP == 2) return run_block4_fused<8, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags & ~32);
+    else return run_block4_fused<7, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
 // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h; fp16-plane mode only): x_in fp32 [B][112][160][2] -> out16 fp16 planes [2][B][56][80][32]
@@ -269,25 +266,19 @@ static hipError_t run_patch(const uint16_t* in, size_t i_plane, const void* wfra
     // the tiles are walked from the end of the batch (Infinity-Cache order): bit 0 the 5x5 kernel (block_3_1), bit 1 the 3x3 kernel (block_4_2)
     constexpr int rev = 3;
     const int r = KS == 5 ? (rev & 1) : ((rev >> 1) & 1);
-    if constexpr (KS == 5 && NP != 1) {      // more region rows per batch of staging loads (HNET_PATCH_RB5): the staging was latency bound
+    // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout; the 5 x 5 kernel stages as many region rows per batch of loads as
+    // fit next to its weight registers (5 in the fp16 mode, 3 in split-bf16: 0.156 (1) / 0.142 (2) / 0.123 ms (5) at batch 256).  The half-major b64 form and
+    // the 1 / 2-row forms (the A/B references of rounds 2 - 4) were removed in round 5: `b128` must be true, `rb5` is ignored.
+    if (!b128) return hipErrorInvalidValue;
+    (void)rb5;
+    if constexpr (KS == 5 && NP != 1) {
         constexpr int RBMAX = NP == 2 ? 5 : 3;   // what fits the 256 registers next to the 156 weight registers
-        if (b128 && rb5 >= RBMAX) {
-            hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true, RBMAX>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
-                               out16, o_plane, h, w, n_tiles, r);
-            return hipGetLastError();
-        }
-        if (b128 && rb5 >= 2) {
-            hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true, 2>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
-                               out16, o_plane, h, w, n_tiles, r);
-            return hipGetLastError();
-        }
-    }
-    if (b128)
+        hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true, RBMAX>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
+                           out16, o_plane, h, w, n_tiles, r);
+    } else {
         hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
                            out16, o_plane, h, w, n_tiles, r);
-    else
-        hipLaunchKernelGGL((conv_patch_s2_kernel<KS, NP, false>), dim3(blocks), dim3(256), C::LDS_BYTES, s, in, i_plane, (const u32x4*)wfrag, bias,
-                           out16, o_plane, h, w, n_tiles, r);
+    }
     return hipGetLastError();
 }
 
@@ -300,15 +291,12 @@ hipError_t launch_conv_patch_np(int layer, const uint16_t* in, size_t i_plane, i
         typedef Patch32Cfg<NP> C;
         const int n_tiles = batch * (28 / C::TH) * (40 / C::TW);
         constexpr int rev = 3;      // (bit 2 = conv_patch32: forward walk)
-        if constexpr (NP == 2) {     // the next tile's region in flight under the MFMAs (rb5 = -32: the round-2 / 3 kernel, A/B)
-            if (rb5 != -32) {
-                hipLaunchKernelGGL((conv_patch32_s2_pf_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
-                                   (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
-                return hipGetLastError();
-            }
-        }
-        hipLaunchKernelGGL((conv_patch32_s2_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
-                           (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
+        if constexpr (NP == 2)      // the next tile's region in flight under the MFMAs (fp16-plane mode; the kernel without prefetch serves the other modes)
+            hipLaunchKernelGGL((conv_patch32_s2_pf_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
+                               (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
+        else
+            hipLaunchKernelGGL((conv_patch32_s2_kernel<NP>), dim3((unsigned)std::min(n_tiles, 512)), dim3(256), C::LDS_BYTES, s, in, i_plane,
+                               (const u32x4*)wfrag, bias, out16, o_plane, n_tiles, (rev >> 2) & 1);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
@@ -418,13 +406,13 @@ hipError_t launch_conv_s3_np(int layer, const uint16_t* in, size_t in_plane, int
 // dynamic-LDS limits of the kernels that use more than 64 KB, for this NP; once per device
 template <int NP>
 hipError_t conv_kernels_init_device_np() {
-    hipError_t e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
+    hipError_t e = hipSuccess;
+    if constexpr (NP != 2) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if constexpr (NP == 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 256, NP, true>::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<HeadLoaderS3, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
 #define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
         typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;
-        HNET_PIPE_ATTR(L1283, PipeCfg140, false); HNET_PIPE_ATTR(L645, PipeCfg140, false); HNET_PIPE_ATTR(L643, PipeCfg140, false);
         HNET_PIPE_ATTR(L1283, PipeCfg144, false); HNET_PIPE_ATTR(L645, PipeCfg144, false); HNET_PIPE_ATTR(L643, PipeCfg144, false);
 #undef HNET_PIPE_ATTR
 #define HNET_REGION_ATTR(C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_region_kernel<C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
@@ -437,12 +425,15 @@ hipError_t conv_kernels_init_device_np() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block42_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B42Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block3_fused_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, B3Cfg::LDS_BYTES + B3Cfg::W0_BYTES + B3Cfg::SPARE_BYTES);
     }
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<3, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<3, NP>::LDS_BYTES);
     if constexpr (NP != 1) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true, (NP == 2 ? 5 : 3)>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
+    } else {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch_s2_kernel<5, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PatchS2Cfg<5, NP>::LDS_BYTES);
     }
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
+    if constexpr (NP != 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_patch32_s2_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, Patch32Cfg<NP>::LDS_BYTES);
+    }
     return e;
 }
 

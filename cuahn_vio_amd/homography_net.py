@@ -29,7 +29,7 @@ def _fp(a):
 def kernel_selection_from_env():
     """hnet_config.warp_exact / .graph / .variant from this process's environment.  The C library reads no environment variable (round 4);
     the test suite and tools/ab_bench.py keep selecting reference kernels with HNET_WARP_EXACT, HNET_GRAPH (0 eager, 1 replay also in the timing
-    entry point), HNET_S3_TILE (13 / 20 / 21 / 22 / 23: include/hnet.h HNET_VARIANT_*), HNET_FUSE_SMALL=0, HNET_FUSE_B3=0, HNET_FUSE_B42=0 - mapped here."""
+    entry point), HNET_S3_TILE (13 / 20 / 21 / 22 / 25 / 30: include/hnet.h HNET_VARIANT_*), HNET_FUSE_SMALL=0, HNET_FUSE_B3=0, HNET_FUSE_B42=0 - mapped here."""
     env = os.environ.get
     variant = int(env("HNET_S3_TILE", "0")) & 0xff
     if env("HNET_FUSE_SMALL", "1") == "0":
@@ -42,20 +42,27 @@ def kernel_selection_from_env():
     return int(env("HNET_WARP_EXACT", "0") != "0"), graph, variant
 
 
+FROM_FILE = -1      # include/hnet.h HNET_FROM_FILE
+
+
 class HnetEngine:
     """One hnet context (one GPU).  `weights` is an HNETW001 blob (bytes) or a path to one."""
 
     def __init__(self, weights, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1,
                  emit_error_map=False, device_id=0, mc_shard=None, precision=None):
+        """variant / mc_samples / dropout_p / emit_error_map = None: HNET_FROM_FILE - taken from the blob's `hnet.variant` record
+        (cuahn_vio_amd.weights.pack_state_dict(..., variant=...)); `config()` returns what is in effect"""
         L = lib()
         cfg = Config()
         L.hnet_default_config(C.byref(cfg))
         if precision is None:   # default: the library's (fp16 planes, fp32-grade); HNET_PRECISION=2 / 0 select split-bf16 / the exact-fp32 MFMA path
             precision = int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
         cfg.device_id = device_id
-        cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant]
-        cfg.mc_samples, cfg.dropout_p, cfg.mc_seed = mc_samples, dropout_p, mc_seed
-        cfg.emit_error_map, cfg.precision, cfg.max_batch = int(emit_error_map), precision, max_batch
+        cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant] if variant is not None else (FROM_FILE, FROM_FILE)
+        cfg.mc_samples = FROM_FILE if mc_samples is None else mc_samples
+        cfg.dropout_p = -1.0 if dropout_p is None else dropout_p
+        cfg.mc_seed = mc_seed
+        cfg.emit_error_map, cfg.precision, cfg.max_batch = (FROM_FILE if emit_error_map is None else int(emit_error_map)), precision, max_batch
         if mc_shard is not None:
             cfg.mc_sample_begin, cfg.mc_sample_end = mc_shard
         cfg.warp_exact, cfg.graph, cfg.variant = kernel_selection_from_env()
@@ -67,7 +74,16 @@ class HnetEngine:
         else:
             rc = L.hnet_create(C.byref(cfg), str(weights).encode(), C.byref(self._h))
         check(None, rc)
-        self.n_local = (cfg.mc_sample_end - cfg.mc_sample_begin) if mc_shard else mc_samples
+        used = self.config()
+        if variant is None:
+            self.variant = {(0, 3): "full", (1, 3): "prior3", (1, 2): "prior2", (1, 1): "prior1"}[(used.use_prior, used.blocks_to_run if used.use_prior else 3)]
+        self.n_local = (cfg.mc_sample_end - cfg.mc_sample_begin) if mc_shard else used.mc_samples
+
+    def config(self):
+        """hnet_get_config: the configuration in effect (HNET_FROM_FILE fields resolved from the blob)"""
+        out = Config()
+        check(self._h, self._L.hnet_get_config(self._h, C.byref(out)))
+        return out
 
     def precision(self):
         """the arithmetic mode in effect (hnet_precision: HNET_PREC_F16X2 falls back to HNET_PREC_BF16X3 outside the fp16 range)"""
@@ -302,28 +318,39 @@ class HomographyNet:
     """
 
     def __init__(self, network_model_path, network_model_iterative_path="", use_prior=False, num_of_iteration=1,
-                 show_imgs=False, *, blocks_to_run=3, mc_samples=16, dropout_p=0.05, mc_seed=0, device_id=0,
+                 show_imgs=False, *, blocks_to_run=None, mc_samples=None, dropout_p=None, mc_seed=0, device_id=0,
                  weights_blob=None, precision=None, blocks_to_run_iterative=None, weights_blob_iterative=None):
+        """blocks_to_run / mc_samples / dropout_p = None: from the file's `hnet.variant` record (what the reference freezes into the traced .pt;
+        a record-less blob gives the reference's launch values 3 / 16 / 0.05) - explicit values are overrides, as HNET_* are for the C++ adapter"""
         self.use_prior_4pt_offset = bool(use_prior)
         self.cv_imshow = bool(show_imgs)
         self.iteration = num_of_iteration > 1
         main_err, iter_err = "_showError" in str(network_model_path), "_showError" in str(network_model_iterative_path)
-        self.show_phtometric_error = iter_err if self.iteration else main_err       # one member in the reference: the file loaded last decides (:96-100, :117-121)
-        variant = {3: "prior3", 2: "prior2", 1: "prior1"}[blocks_to_run] if use_prior else "full"
+
+        def make(weights, blocks, emit):
+            variant = "full" if not use_prior else (None if blocks is None else {3: "prior3", 2: "prior2", 1: "prior1"}[blocks])
+            e = HnetEngine(weights, variant=variant, mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
+                           emit_error_map=emit, device_id=device_id, precision=precision)
+            u = e.config()
+            if bool(u.use_prior) != bool(use_prior):
+                e.close()
+                raise ValueError("use_prior disagrees with the variant recorded in the weight file")
+            print(f"model variant: {e.variant}, MC-dropout N = {u.mc_samples}, p = {u.dropout_p:g}, error map {'on' if u.emit_error_map else 'off'}")
+            return e, bool(u.emit_error_map)
+
         print("Loading the Network Model (HNETW001 weights) ...")
-        self._eng = HnetEngine(weights_blob if weights_blob is not None else network_model_path, variant=variant,
-                               mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
-                               emit_error_map=main_err and not self.iteration, device_id=device_id, precision=precision)
+        # ("_showError" in the name forces the map like the reference's sniff; otherwise the file's record decides; unused with an iterative model, :199)
+        self._eng, any_err = make(weights_blob if weights_blob is not None else network_model_path, blocks_to_run,
+                                  False if self.iteration else (True if main_err else None))
         t = self._eng.last_timing()
         print(f"[TIME]: {t['host_ms']:.4f} milliseconds for the first network inference")
         self._eng_iter = None
         if self.iteration:      # HomographyNet.cpp:20-24: a second model for iteration > 0, warmed up (:49-56), fed the same frames
-            v_it = {3: "prior3", 2: "prior2", 1: "prior1"}[blocks_to_run_iterative or blocks_to_run] if use_prior else "full"
             w_it = weights_blob_iterative if weights_blob_iterative is not None else (weights_blob if weights_blob is not None else network_model_iterative_path)
-            self._eng_iter = HnetEngine(w_it, variant=v_it, mc_samples=mc_samples, dropout_p=dropout_p, mc_seed=mc_seed, max_batch=1,
-                                        emit_error_map=iter_err, device_id=device_id, precision=precision)
+            self._eng_iter, any_err = make(w_it, blocks_to_run_iterative, True if iter_err else None)
             check(self._eng_iter.handle, self._eng._L.hnet_attach_images(self._eng_iter.handle, self._eng.handle))
             print("IEKF! Load the Network for Iteration!")
+        self.show_phtometric_error = any_err       # one member in the reference: the file loaded last decides (:96-100, :117-121)
         self._pred_mean = np.zeros((8, 1), np.float32)
         self._pred_Cov = np.zeros((8, 8), np.float32)
         self.last_error_map = None

@@ -144,10 +144,34 @@ def variant_state(seed: int = 0, conv_gain: float = 1.0) -> "OrderedDict[str, np
     return st
 
 
-def pack_state_dict(state) -> bytes:
+VARIANT_TENSOR = "hnet.variant"      # optional [8] float32 record of the blob: what the reference bakes into a traced .pt (trace_model.py:16,36-46)
+VARIANTS = {"full": (0, 3), "prior3": (1, 3), "prior2": (1, 2), "prior1": (1, 1)}      # name -> (use_prior, blocks_to_run)
+
+
+def variant_record(variant: str = "prior3", mc_samples: int = 16, dropout_p: float = 0.05, emit_error_map: bool = False) -> np.ndarray:
+    """The model variant as the eight floats hnet_create reads when an hnet_config field is HNET_FROM_FILE:
+    [record version 1, use_prior, blocks_to_run, mc_samples, dropout_p, emit_error_map, 0, 0].  The reference freezes exactly these into the
+    TorchScript file it loads (trace_model.py:16 dropout_rate, :36-46 prior / no prior and the "_showError" twin; model_to_trace.py:72 blocks_to_run,
+    :202 MC_dropout_num; HomographyNet.cpp:81-124 only names a file) - one blob per traced variant plays the same role here."""
+    use_prior, blocks = VARIANTS[variant]
+    if not (1 <= int(mc_samples) <= 256 and 0.0 <= float(dropout_p) < 1.0):
+        raise ValueError("mc_samples in 1..256, dropout_p in [0, 1)")
+    return np.array([1, use_prior, blocks, int(mc_samples), float(dropout_p), 1 if emit_error_map else 0, 0, 0], dtype="<f4")
+
+
+def pack_state_dict(state, variant=None) -> bytes:
     """Serialise a name->array mapping (reference state_dict layouts) into the HNETW001 blob.
-    Accepts numpy arrays or anything with ``.numpy()`` / ``.detach()`` (torch tensors)."""
+    Accepts numpy arrays or anything with ``.numpy()`` / ``.detach()`` (torch tensors).
+    variant: None (weights only: the caller's hnet_config decides everything) or a ``variant_record(...)`` / a dict of its arguments,
+    stored as the extra tensor ``hnet.variant`` that older readers skip."""
     specs = tensor_specs()
+    if variant is not None:
+        rec = variant_record(**variant) if isinstance(variant, dict) else np.asarray(variant, dtype="<f4")
+        if rec.shape != (8,):
+            raise ValueError("variant record: eight floats")
+        state = OrderedDict(state)
+        state[VARIANT_TENSOR] = rec
+        specs = specs + [(VARIANT_TENSOR, (8,))]
     arrays = []
     for name, shape in specs:
         if name not in state:
@@ -159,7 +183,7 @@ def pack_state_dict(state) -> bytes:
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{name}: shape {a.shape} != expected {shape}")
         arrays.append(a)
-    extra = set(state.keys()) - {n for n, _ in specs}
+    extra = set(state.keys()) - {n for n, _ in specs} - {VARIANT_TENSOR}
     if extra:
         raise KeyError(f"unexpected tensors in state dict: {sorted(extra)[:4]}")
     head = bytearray(MAGIC + struct.pack("<I", len(specs)))
@@ -200,9 +224,19 @@ def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def save_blob(path: str, state) -> None:
+def save_blob(path: str, state, variant=None) -> None:
     with open(path, "wb") as f:
-        f.write(pack_state_dict(state))
+        f.write(pack_state_dict(state, variant))
+
+
+def blob_variant(blob: bytes):
+    """the variant record of a blob as a dict, or None"""
+    st = unpack_blob(blob)
+    if VARIANT_TENSOR not in st:
+        return None
+    r = st[VARIANT_TENSOR]
+    name = {v: k for k, v in VARIANTS.items()}.get((int(r[1]), int(r[2])) if int(r[1]) else (0, 3))
+    return {"variant": name, "mc_samples": int(r[3]), "dropout_p": float(r[4]), "emit_error_map": bool(r[5])}
 
 
 def load_blob(path: str):
@@ -225,15 +259,27 @@ def load_checkpoint(path: str) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def convert_checkpoint(pth_path: str, blob_path: str) -> None:
+def convert_checkpoint(pth_path: str, blob_path: str, variant=None) -> None:
     """``x.pth.tar`` -> HNETW001 blob for hnet_create (strict: every expected tensor present with the reference's shape,
-    nothing else, as ``load_state_dict(strict=True)``)"""
-    save_blob(blob_path, load_checkpoint(pth_path))
+    nothing else, as ``load_state_dict(strict=True)``); variant: see pack_state_dict"""
+    st = load_checkpoint(pth_path)
+    st.pop(VARIANT_TENSOR, None)
+    save_blob(blob_path, st, variant)
 
 
 if __name__ == "__main__":
-    import sys
-    if len(sys.argv) != 3:
-        raise SystemExit("usage: python -m cuahn_vio_amd.weights <checkpoint.pth.tar> <out.hnw>")
-    convert_checkpoint(sys.argv[1], sys.argv[2])
-    print(f"wrote {sys.argv[2]}")
+    # the counterpart of the reference's trace_model.py: one output file per variant it traces (:36-46)
+    #   python -m cuahn_vio_amd.weights ck.pth.tar traced_model_3_blocks_using_prior.hnw --variant prior3 --mc 16 --dropout 0.05
+    #   python -m cuahn_vio_amd.weights ck.pth.tar traced_model_3_blocks_using_prior_showError.hnw --variant prior3 --error-map
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m cuahn_vio_amd.weights", description="reference checkpoint (.pth.tar) -> HNETW001 blob")
+    ap.add_argument("checkpoint")
+    ap.add_argument("out")
+    ap.add_argument("--variant", choices=sorted(VARIANTS), default=None, help="bake the model variant into the blob (default: weights only)")
+    ap.add_argument("--mc", type=int, default=16, help="MC-dropout samples N (MC_dropout_num, model_to_trace.py:202)")
+    ap.add_argument("--dropout", type=float, default=0.05, help="dropout rate (trace_model.py:16)")
+    ap.add_argument("--error-map", action="store_true", help='the "_showError" twin (trace_model.py:40,46)')
+    a = ap.parse_args()
+    var = None if a.variant is None else dict(variant=a.variant, mc_samples=a.mc, dropout_p=a.dropout, emit_error_map=a.error_map)
+    convert_checkpoint(a.checkpoint, a.out, var)
+    print(f"wrote {a.out}" + ("" if var is None else f" ({var})"))

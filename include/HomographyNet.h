@@ -59,29 +59,38 @@ public:
         cv_imshow = show_imgs;
         const bool main_err = network_model_path.find("_showError") != std::string::npos;       // HomographyNet.cpp:96-100
         const bool iter_err = network_model_iterative_path.find("_showError") != std::string::npos;   // :117-121
-        show_phtometric_error = iteration ? iter_err : main_err;      // one member in the reference: the file loaded last decides
+        // The model VARIANT - blocks_to_run, MC-dropout N and rate, the error-map twin - is frozen into the traced .pt the reference loads (trace_model.py:16,36-46;
+        // HomographyNet.cpp:81-124 only names a file).  Here it comes from the HNETW001 file's `hnet.variant` record (python -m cuahn_vio_amd.weights --variant ...):
+        // the fields are left at HNET_FROM_FILE.  HNET_BLOCKS_TO_RUN / HNET_MC_SAMPLES / HNET_DROPOUT_P / HNET_ITER_BLOCKS_TO_RUN are explicit OVERRIDES for
+        // experiments (a record-less blob + no override = the reference's launch values); what is in effect is printed below.
         hnet_config cfg;
         hnet_default_config(&cfg);
         cfg.device_id = env_int("HNET_DEVICE", 0);
-        cfg.use_prior = use_prior ? 1 : 0;
-        cfg.blocks_to_run = env_int("HNET_BLOCKS_TO_RUN", 3);
-        cfg.mc_samples = env_int("HNET_MC_SAMPLES", 16);
-        cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", 0.05);
-        cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);
+        cfg.use_prior = use_prior ? 1 : 0;                             // the constructor argument decides what network_inference passes (HomographyNet.cpp:160-172)
+        cfg.blocks_to_run = env_int("HNET_BLOCKS_TO_RUN", HNET_FROM_FILE);
+        cfg.mc_samples = env_int("HNET_MC_SAMPLES", HNET_FROM_FILE);
+        cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", -1.0);
+        cfg.mc_seed = (uint64_t)env_double("HNET_MC_SEED", 0.0);      // (run-time state of PyTorch's generator in the reference, not a property of the file)
         cfg.precision = env_int("HNET_PRECISION", cfg.precision);      // HNET_PREC_F16X2 (3, default), HNET_PREC_BF16X3 (2), HNET_PREC_FP32 (0), HNET_PREC_BF16 (1)
-        cfg.emit_error_map = (main_err && !iteration) ? 1 : 0;         // with an iterative model the main model's map is never read (:199)
+        // the "_showError" file name forces the map like the reference's sniff (:96-100); otherwise the file's record decides.
+        // With an iterative model the main model's map is never read (:199)
+        cfg.emit_error_map = iteration ? 0 : (main_err ? 1 : HNET_FROM_FILE);
         cfg.max_batch = 1;
         std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());
         int rc = hnet_create(&cfg, network_model_path.c_str(), &ctx_);   // also runs the warm-up forward (:28-45)
         if (rc != HNET_OK)
             throw std::runtime_error(std::string("error loading the model !!! (") + hnet_status_string(rc) + ")");
+        print_variant("main model", ctx_);
         hnet_timing t;
         hnet_last_timing(ctx_, &t);
         std::printf(HNET_BLUE "[TIME]: %.4f milliseconds for the first network inference\n" HNET_RESET, t.host_ms);
+        hnet_config used;
+        hnet_get_config(ctx_, &used);
+        bool any_err = used.emit_error_map != 0;
         if (iteration) {                                               // :20-24, warm-up :49-56
             hnet_config ci = cfg;
-            ci.blocks_to_run = env_int("HNET_ITER_BLOCKS_TO_RUN", cfg.blocks_to_run);
-            ci.emit_error_map = iter_err ? 1 : 0;
+            ci.blocks_to_run = env_int("HNET_ITER_BLOCKS_TO_RUN", HNET_FROM_FILE);      // a separate traced file: its own variant
+            ci.emit_error_map = iter_err ? 1 : HNET_FROM_FILE;
             std::printf("Loading the Network Model for IEKF (HNETW001 weights) from %s ...\n", network_model_iterative_path.c_str());
             rc = hnet_create(&ci, network_model_iterative_path.c_str(), &ctx_iter_);
             if (rc == HNET_OK) rc = hnet_attach_images(ctx_iter_, ctx_);
@@ -90,8 +99,12 @@ public:
                 hnet_destroy(ctx_);
                 throw std::runtime_error(std::string("error loading the model !!! (iterative: ") + hnet_status_string(rc) + ")");
             }
+            print_variant("iterative model", ctx_iter_);
+            hnet_get_config(ctx_iter_, &used);
+            any_err = used.emit_error_map != 0;
             std::printf("IEKF! Load the Network for Iteration!\n");
         }
+        show_phtometric_error = any_err;                               // one member in the reference: the file loaded last decides
         if (show_phtometric_error) err_map_.resize(HNET_IMG_ROWS * HNET_IMG_COLS);
         _pred_mean.setZero();
         _pred_Cov.setZero();
@@ -183,6 +196,12 @@ public:
     int img_counter = 0;   // public in the reference (HomographyNet.h:33), read by VioManager.cpp:257,288
 
 private:
+    static void print_variant(const char* what, hnet_ctx* c) {
+        hnet_config u;
+        if (hnet_get_config(c, &u) != HNET_OK) return;
+        std::printf("%s: %s, blocks_to_run %d, MC-dropout N = %d, p = %g, error map %s\n", what, u.use_prior ? "EKF prior" : "no prior (4 blocks)",
+                    u.use_prior ? u.blocks_to_run : 3, u.mc_samples, (double)u.dropout_p, u.emit_error_map ? "on" : "off");
+    }
     static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
     static double env_double(const char* name, double dflt) { const char* v = std::getenv(name); return v ? std::atof(v) : dflt; }
 

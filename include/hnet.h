@@ -34,7 +34,7 @@ enum {
     HNET_ERR_BAD_WEIGHTS = 2,     /* missing / malformed HNETW001 blob */
     HNET_ERR_DEVICE = 3,          /* HIP runtime error (hnet_last_error has the text) */
     HNET_ERR_NOT_READY = 4,       /* fewer than two images pushed (HomographyNet.cpp:155-158) */
-    HNET_ERR_CAPACITY = 5,        /* batch larger than max_batch; hnet_create: max_batch beyond what the kernels address (3 558 frame pairs per context) */
+    HNET_ERR_CAPACITY = 5,        /* batch larger than max_batch; hnet_create: max_batch beyond what the kernels address (1 779 frame pairs per context) */
     HNET_ERR_UNSUPPORTED = 6
 };
 
@@ -58,6 +58,10 @@ enum { HNET_PIX_U8 = 0, HNET_PIX_F32 = 1 };        /* pixel format of image buff
 /* Replaces: the variant choice the reference bakes into the traced .pt file
  * (trace_pytorch_model/trace_model.py:36-46; blocks_to_run model_to_trace.py:72; MC_dropout_num :202;
  * dropout_rate trace_model.py:16; "_showError" HomographyNet.cpp:96-100). */
+/* use_prior, blocks_to_run, mc_samples, emit_error_map = HNET_FROM_FILE (dropout_p: any negative value): hnet_create takes the field from the blob's
+ * `hnet.variant` record (python -m cuahn_vio_amd.weights --variant ...: one blob per traced variant, as the reference has one .pt per variant); a blob
+ * without the record gives the reference's launch values (use_prior 1, blocks_to_run 3, N 16, p 0.05, no error map).  hnet_get_config returns what is in effect. */
+#define HNET_FROM_FILE (-1)
 typedef struct hnet_config {
     uint32_t struct_size;      /* sizeof(hnet_config), for forward compatibility */
     int32_t  device_id;        /* HIP device ordinal */
@@ -81,10 +85,11 @@ typedef struct hnet_config {
 
 enum { HNET_GRAPH_DEFAULT = 0 /* replay */, HNET_GRAPH_OFF = 1 /* eager launches */, HNET_GRAPH_TIMING = 2 /* replay, also inside hnet_time_batch_device */ };
 enum {
-    HNET_VARIANT_GEMM_MASK = 0xff,            /* low byte: implicit-GEMM kernel selection (csrc/s3_dispatch.h):
+    HNET_VARIANT_GEMM_MASK = 0xff,            /* low byte: implicit-GEMM kernel selection (csrc/s3_dispatch.h); an unknown code is HNET_ERR_INVALID_ARG:
                                                   0 = defaults; 13 = heads FC1 on the four-wave 128 x 64 kernel; 22 = on the eight-wave kernel of round 3;
-                                                  20 = conv layers on the four-wave lean kernels (no pipelined LDS-DMA kernel); 21 = the pipelined kernel at any
-                                                  batch (tests); 23 = its 160 x 128 / 512-thread tile instead of 144 x 128 / 768 threads */
+                                                  20 = conv layers on the four-wave lean kernels (no pipelined LDS-DMA / region kernels); 21 = the pipelined and the
+                                                  region kernel at any batch (tests); 25 = no region kernel; 30 = split-K layers with splitk_reduce launches and the
+                                                  split-K heads at every batch (the round-4 latency path: A/B and bitwise tests of round 5) */
     HNET_VARIANT_NO_LATENCY_PATH = 1u << 8,   /* batch <= 8 on the multi-launch path (bit-identical; tests/test_gpu_latency_path.py) */
     HNET_VARIANT_UNFUSED_B3 = 1u << 9,        /* block_3_0 and block_3_1 as separate launches (fp16-plane mode) */
     HNET_VARIANT_UNFUSED_B42 = 1u << 10       /* block_4_2 and block_4_3 as separate launches (fp16-plane mode) */
@@ -128,6 +133,8 @@ int hnet_overflow_flag(hnet_ctx* ctx, void* stream, int* flags);
  * hnet_overflow_flag.  A non-finite INPUT (NaN prior from a diverged filter, NaN float image) is not an overflow: the call returns
  * the non-finite outputs as the reference would and the context keeps its mode. */
 int hnet_precision(const hnet_ctx* ctx);
+/* the configuration in effect: HNET_FROM_FILE fields resolved from the blob, defaults filled in (what a deployment logs next to the file name) */
+int hnet_get_config(const hnet_ctx* ctx, hnet_config* out);
 
 /* Replaces HomographyNet::load_current_img (HomographyNet.cpp:127-151): copies the 224x320 8-bit image
  * (row_stride in bytes) to the device, prev <- curr, curr <- img; counts images; records `t` from the second

@@ -27,12 +27,16 @@ TOL_PX_VS_ORACLE = 1e-4     # |HIP - oracle (double accumulation)|, px, DEFAULT 
                             # Measured: <= 3.8e-5 on the 28 goldens, worst slot of a 256-pair batch 7.5e-5 (profiles/r03_v10_full_batch_check.log)
 
 
-def tol_px_vs_oracle(precision):
-    """gate of |HIP - oracle| per arithmetic mode.  The oracle accumulates in double; what a mode is compared against is its
-    own fp32 accumulation noise.  The default mode (3, two fp16 planes) is GATED at north_star's 1e-4 px.  The two reference modes - exact fp32 MFMA (0)
-    and split-bf16 (2) - measure 1.0e-4 on the worst slot of a 256-pair batch (the network's fp32 accumulation noise sits ON 1e-4: r03_v10_full_batch_check.log)
-    and are gated at 1.5e-4 = that noise + margin, so that a reordering of the summation or another seed does not flake.  Plain bf16 (1) is reported, never gated."""
-    return {3: TOL_PX_VS_ORACLE, 2: 1.5e-4, 0: 1.5e-4}[int(precision)]
+def tol_px_vs_oracle(precision, worst_slot=False):
+    """gate of |HIP - oracle| per arithmetic mode.  north_star's 1e-4 px in every gated mode on the golden, smoke and replay cases (they measure
+    <= 4e-5: ADVICE r4 - a 50 % regression of a reference mode must not pass).  worst_slot = True is for the checks that look at EVERY slot of a large
+    batch (tests/test_gpu_bench_shapes.py, tools/full_batch_check.py): the oracle accumulates in double, and the worst of 256 slots of the two
+    reference modes - exact fp32 MFMA (0) and split-bf16 (2) - sits ON 1e-4 (1.0e-4 measured: the network's own fp32 accumulation noise,
+    r03_v10_full_batch_check.log), so those two are gated at 1.5e-4 there; the default mode (3) stays at 1e-4 (7.5e-5 measured).  Plain bf16 (1) is
+    reported, never gated."""
+    if worst_slot:
+        return {3: TOL_PX_VS_ORACLE, 2: 1.5e-4, 0: 1.5e-4}[int(precision)]
+    return {3: TOL_PX_VS_ORACLE, 2: TOL_PX_VS_ORACLE, 0: TOL_PX_VS_ORACLE}[int(precision)]
 TOL_COV_REL = 2e-5          # max |cov - ref| / max |ref|
 
 

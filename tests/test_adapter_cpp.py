@@ -98,6 +98,48 @@ def test_adapter_routes_iterations_to_the_iterative_model(blob, tmp_path):
         e.close()
 
 
+@pytest.mark.gpu
+def test_adapter_takes_the_variant_from_the_weight_files(state, tmp_path):
+    """VERDICT r4 missing 3: the reference freezes blocks_to_run, N, p and the error-map twin into the traced .pt it loads (trace_model.py:16,36-46;
+    HomographyNet.cpp:81-124).  Two HNETW001 files written with their variant record (python -m cuahn_vio_amd.weights --variant ...): a prior-3 / N = 16
+    main model and a prior-1 / N = 8 / p = 0.1 iterative model, and an environment WITHOUT any HNET_* variable: every call must be the answer of the engine
+    configured explicitly that way, bit for bit."""
+    from cuahn_vio_amd import synth, weights
+    from cuahn_vio_amd.homography_net import HnetEngine
+    _build()
+    wmain = tmp_path / "main.hnw"
+    witer = tmp_path / "iter.hnw"
+    weights.save_blob(str(wmain), state, dict(variant="prior3", mc_samples=16, dropout_p=0.05))
+    weights.save_blob(str(witer), state, dict(variant="prior1", mc_samples=8, dropout_p=0.1))
+    frames = np.stack([synth.make_pair(95 + i)[0] for i in range(3)])
+    fpath = tmp_path / "frames.u8"
+    frames.tofile(fpath)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HNET_")}
+    r = subprocess.run([BIN, str(wmain), str(fpath), "3", "1", str(witer), "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "main model: EKF prior, blocks_to_run 3, MC-dropout N = 16, p = 0.05" in r.stdout
+    assert "iterative model: EKF prior, blocks_to_run 1, MC-dropout N = 8, p = 0.1" in r.stdout
+    res = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert [(int(x[1]), int(x[2])) for x in res] == [(k, it) for k in (1, 2) for it in (0, 1)]
+    blob = weights.pack_state_dict(state)
+    engs = {0: HnetEngine(blob, variant="prior3", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1),
+            1: HnetEngine(blob, variant="prior1", mc_samples=8, dropout_p=0.1, mc_seed=0, max_batch=1)}
+    prior = np.array([[1.0, -2.0, 0.5, 3.0, -1.5, 0.25, 2.0, -0.75]], np.float32)
+    for seq, x in enumerate(res):
+        k, it = int(x[1]), int(x[2])
+        vals = np.array([float(v) for v in x[3:]], np.float64)
+        m, c = engs[it].infer_batch(frames[k - 1][None], frames[k][None], prior, pair_seq0=seq)
+        assert np.array_equal(vals[:8].astype(np.float32), m[0]), (k, it)
+        assert np.array_equal(vals[8:].astype(np.float32).reshape(8, 8), c[0]), (k, it)
+    for e in engs.values():
+        e.close()
+    # the Python mirror reads the same record
+    e = HnetEngine(str(witer), variant=None, mc_samples=None, dropout_p=None, emit_error_map=None, max_batch=1)
+    u = e.config()
+    assert (e.variant, u.mc_samples, u.emit_error_map) == ("prior1", 8, 0) and abs(u.dropout_p - 0.1) < 1e-7
+    e.close()
+
+
 IEKF_BIN = os.path.join(ROOT, "tests", "cpp", "iekf_demo.bin")
 
 

@@ -42,7 +42,7 @@ def _check_batch(blob, oracle, variant, batch, n_mc, precision, check_pairs, n_d
         o = oracle.forward(prev[b], curr[b], None if prior is None else prior[b], btr, n_mc, 0.05, MC_SEED, s0 + b)
         d = float(np.abs(mean[b] - o["mean"]).max())
         worst = max(worst, d)
-        assert d < tol_px_vs_oracle(precision), (b, d)
+        assert d < tol_px_vs_oracle(precision, worst_slot=True), (b, d)
         assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
     print(f"{variant} B={batch} N={n_mc} precision={precision}: max |hip - oracle| over pairs {list(check_pairs)} = {worst:.2e} px")
     # slot invariance at the benchmarked batch: pair b sits in slot b + rot with the same mask sequence number
@@ -257,12 +257,12 @@ def test_block42_fused_kernel_elementwise(blob, state, batch):
     eng.close()
 
 
-@pytest.mark.parametrize("batch,n_mc", [(192, 32), (250, 32), (256, 32), (512, 16), (700, 12), (2050, 2)])
+@pytest.mark.parametrize("batch,n_mc", [(192, 32), (250, 32), (256, 32), (512, 16), (700, 12), (1366, 3)])
 def test_heads_gemm_kernels_agree_bitwise(blob, batch, n_mc):
     """heads FC1 (model_to_trace.py:222-225,229-232) runs on igemm_heads_pipe_kernel (round 4: LDS-DMA, only the DISTINCT pairs of an M-tile in LDS,
     keep bits applied to the fragments, K-tile-major mask layout) when its 128 x 128 tiles fill whole rounds of the CUs (s3_dispatch.h): M = batch x N =
-    6144 / 8000 (ragged last tile) / 8192 / 8192 / 8400 (N = 12: tiles straddle pairs, 11 - 12 pairs per tile) / 4100 (N = 2: 64 - 65 pairs per tile,
-    nine A groups) rows here.  Same K order and MFMA sequence as the eight-wave kernel of round 3 (HNET_S3_TILE=22) and as the four-wave 128 x 64
+    6144 / 8000 (ragged last tile) / 8192 / 8192 / 8400 (N = 12: tiles straddle pairs, 11 - 12 pairs per tile) / 4098 (N = 3: 42 - 43 pairs per tile,
+    six A groups; max_batch is bounded at 1 779 pairs since round 5) rows here.  Same K order and MFMA sequence as the eight-wave kernel of round 3 (HNET_S3_TILE=22) and as the four-wave 128 x 64
     kernel (HNET_S3_TILE=13, read at hnet_create): every output bit must agree."""
     from cuahn_vio_amd.homography_net import HnetEngine
     prev, curr, prior = _batch(9000 + batch, 16, batch)
@@ -298,7 +298,7 @@ def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle, precisi
     eng = HnetEngine(blob, variant="full", mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=B, precision=precision)
     mean, cov = eng.infer_batch(prev, curr, None, pair_seq0=4242)
     eng.close()
-    worst, gate = 0.0, tol_px_vs_oracle(precision)
+    worst, gate = 0.0, tol_px_vs_oracle(precision, worst_slot=True)
     for b in range(B):
         if b not in _ORACLE_256:
             _ORACLE_256[b] = oracle.forward(prev[b], curr[b], None, 3, n_mc, 0.05, MC_SEED, 4242 + b)
@@ -312,3 +312,53 @@ def test_every_slot_of_a_256_pair_batch_is_inside_the_gate(blob, oracle, precisi
     if out:
         with open(out, "a") as f:
             f.write(f"precision={precision} slots={B} max_abs_err_vs_oracle_px={worst:.3e} gate_px={gate:.1e}\n")
+
+
+@pytest.mark.parametrize("variant,n_mc,weights_seed", [pytest.param("prior3", 16, 0, id="prior3-n16"), pytest.param("full", 16, 3, id="full-n16-weights3")])
+def test_every_slot_in_the_other_deployed_shapes(variant, n_mc, weights_seed):
+    """VERDICT r4 (weak 1): the every-slot check above covers the full model on weight seed 0 only.  The same for the reference's launch default
+    (3 blocks + EKF prior, N = 16: prior offsets up to +- 12 px) and for the full model on another synthetic weight set, default arithmetic, 128 distinct pairs:
+    all slots against the oracle at north_star's 1e-4 px."""
+    from cuahn_vio_amd import weights
+    from cuahn_vio_amd.homography_net import HnetEngine
+    from oracle import pyoracle
+    B = 128
+    blob = weights.pack_state_dict(weights.synthetic_state(weights_seed))
+    orc = pyoracle.Oracle(blob)
+    prev, curr, prior = _batch(81000 + weights_seed, B, B)
+    pr = prior if variant != "full" else None
+    eng = HnetEngine(blob, variant=variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=MC_SEED, max_batch=B)
+    mean, cov = eng.infer_batch(prev, curr, pr, pair_seq0=555)
+    eng.close()
+    worst = 0.0
+    for b in range(B):
+        o = orc.forward(prev[b], curr[b], None if pr is None else pr[b], 3, n_mc, 0.05, MC_SEED, 555 + b)
+        d = float(np.abs(mean[b] - o["mean"]).max())
+        worst = max(worst, d)
+        assert d < TOL_PX_VS_ORACLE, (b, d)
+        assert np.abs(cov[b] - o["cov"]).max() / np.abs(o["cov"]).max() < TOL_COV_REL, b
+    print(f"{variant} N={n_mc} weights {weights_seed}: all {B} slots, max |hip - oracle| = {worst:.2e} px")
+
+
+def test_largest_max_batch_reads_both_planes_of_every_pair(blob):
+    """block42_fused_kernel reaches both fp16 planes of block_4_1's bordered map through ONE 2-GiB buffer descriptor; hnet_create bounds
+    max_batch so that plane offset + tile offset stay inside it (1 779 pairs).  At that bound, eight distinct pairs repeated over the batch (p = 0: no
+    slot-dependent masks): every slot must equal its copy in the first eight slots bit for bit - a low plane that read as zeros for the upper pairs
+    (the failure an out-of-range offset produces, silently) would show up as a 1e-3-relative difference."""
+    import torch
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
+    B = 1779
+    dev = torch.device("cuda:0")
+    ph, ch, _pr, _ = synth.make_batch(31, 8)
+    prev = torch.from_numpy(np.tile(ph, (B // 8 + 1, 1, 1))[:B]).to(dev)
+    curr = torch.from_numpy(np.tile(ch, (B // 8 + 1, 1, 1))[:B]).to(dev)
+    mean, cov = torch.zeros(B, 8, device=dev), torch.zeros(B, 64, device=dev)
+    eng = HnetEngine(blob, variant="full", mc_samples=4, dropout_p=0.0, mc_seed=1, max_batch=B)
+    eng.infer_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, None, B, 0, mean.data_ptr(), cov.data_ptr())
+    torch.cuda.synchronize()
+    m, c = mean.cpu().numpy(), cov.cpu().numpy()
+    eng.close()
+    assert np.isfinite(m).all() and np.abs(m[:8]).max() > 0.1
+    for s in (8, 888, 1768):                        # the next copy, the middle of the batch, the last full group of eight
+        assert np.array_equal(m[s:s + 8], m[:8]) and np.array_equal(c[s:s + 8], c[:8]), s

@@ -149,18 +149,44 @@ def test_pth_tar_checkpoint_round_trip(tmp_path, state, blob):
 
 
 def test_create_refuses_a_max_batch_beyond_the_kernels_31_bit_plane_offsets():
-    """hnet_create validates the configuration before it touches the device: 3 558 pairs is what a 2 GiB buffer descriptor holds of the largest
-    activation plane (block_4_1's bordered map, kernels.h B42_*); a larger max_batch must be refused, not silently read as zeros"""
+    """hnet_create validates the configuration before it touches the device: 1 779 pairs is what a 2 GiB buffer descriptor holds of BOTH planes of the
+    largest activation (block_4_1's bordered map, kernels.h B42_*: block42_fused_kernel reaches the two planes through one descriptor); a larger
+    max_batch must be refused, not silently read as zeros"""
     import ctypes as C
     from cuahn_vio_amd import _capi
     L = _capi.lib()
     cfg = _capi.Config()
     L.hnet_default_config(C.byref(cfg))
-    cfg.max_batch = 4000
+    cfg.max_batch = 1780
     h = C.c_void_p()
     junk = (C.c_ubyte * 16)()
     rc = L.hnet_create_from_memory(C.byref(cfg), junk, 16, C.byref(h))
     assert rc == 5 and not h.value          # HNET_ERR_CAPACITY, before the blob is parsed or a device is touched
-    cfg.max_batch = 3000
+    cfg.max_batch = 1779
     rc = L.hnet_create_from_memory(C.byref(cfg), junk, 16, C.byref(h))
     assert rc not in (0, 5) and not h.value  # (the junk blob is what is wrong now)
+
+
+def test_variant_record_round_trip_and_config_validation(state):
+    """the `hnet.variant` record of an HNETW001 blob (what the reference bakes into a traced .pt): written / read back by cuahn_vio_amd.weights, skipped by
+    readers that do not ask for it; and hnet_create refuses configuration values it does not know before it touches a device"""
+    import ctypes as C
+    from cuahn_vio_amd import _capi, weights
+    b0 = weights.pack_state_dict(state)
+    b1 = weights.pack_state_dict(state, dict(variant="prior2", mc_samples=32, dropout_p=0.25, emit_error_map=True))
+    assert weights.blob_variant(b0) is None
+    assert weights.blob_variant(b1) == {"variant": "prior2", "mc_samples": 32, "dropout_p": 0.25, "emit_error_map": True}
+    u = weights.unpack_blob(b1)
+    assert all(np.array_equal(u[k], state[k]) for k in state) and len(b1) == len(b0) + 128 or len(b1) > len(b0)
+    with pytest.raises(KeyError):
+        weights.variant_record("prior9")
+    with pytest.raises(ValueError):
+        weights.variant_record("full", mc_samples=0)
+    L = _capi.lib()
+    junk = (C.c_ubyte * 16)()
+    for field, val in (("graph", 3), ("variant", 99), ("variant", 1 << 20)):
+        cfg = _capi.Config()
+        L.hnet_default_config(C.byref(cfg))
+        setattr(cfg, field, val)
+        h = C.c_void_p()
+        assert L.hnet_create_from_memory(C.byref(cfg), junk, 16, C.byref(h)) == 1 and not h.value      # HNET_ERR_INVALID_ARG
