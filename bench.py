@@ -260,6 +260,19 @@ KERNEL_OF_STAGE = {"block_4_0+4_1": "block4_fused_kernel", "heads_fc1": "igemm_h
 FP32_STAGES = ("fc_dlt_b1", "fc_dlt_b2", "fc_dlt_b3", "heads_fc2")
 
 
+def committed_config4_cost():
+    """(ms, source) of all-gather + finish on a 1-rank RCCL communicator from the committed C++ measurement (tests/cpp/rccl_gather_example.cpp --time on a gpurun
+    box): the line RCCL_CONFIG4_TIME of the newest profiles/r*_rccl_gather_cost.log; (None, None) when absent"""
+    import glob
+    import re
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rccl_gather_cost.log")), reverse=True):
+        for line in open(fn):
+            m = re.search(r"RCCL_CONFIG4_TIME.*partial\(4 of 32 samples\)\+allgather\+finish=([0-9.]+)\s+partial\(4 of 32 samples\) alone=([0-9.]+)", line)
+            if m:
+                return round(float(m.group(1)) - float(m.group(2)), 4), os.path.relpath(fn, ROOT)
+    return None, None
+
+
 def verify_last_step(blob, prev_h, curr_h, prior_h, variant, n_mc, seq_of_slot, mean, cov, slots):
     """the oracle (test infrastructure, CPU) on `slots` of the last step's batch; returns (n, max px err, max cov rel err)"""
     import numpy as np
@@ -417,7 +430,7 @@ def sub_run(base, ctx, **over):
     for k, v in over.items():
         setattr(a, k, v)
     r, ok = run(a, ctx, primary=False)
-    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms")
+    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms", "mc_sharding")
     out = {k: r[k] for k in keep if k in r}
     if getattr(a, "contexts", 1) > 1:
         out["contexts"] = a.contexts
@@ -495,7 +508,11 @@ def run(args, ctx, primary):
         out_of_step = lambda i: outs[i % NC]
     if mc_mode:
         n_loc = shard[1] - shard[0]
-        ms_loc, lv_loc = torch.zeros(B, n_loc, 8, device=dev), torch.zeros(B, n_loc, 8, device=dev)
+        # one [2, B, n_loc, 8] array per rank (mean_s | logvar_s) and the buffer ONE all-gather fills: the finish reads it in place (round 5: no stack / permute /
+        # .contiguous() launches between the forward and the ensemble)
+        both = torch.zeros(2, B, n_loc, 8, device=dev)
+        ms_loc, lv_loc = both[0], both[1]
+        mc_gathered = torch.zeros(world, 2, B, n_loc, 8, device=dev)
         h1 = torch.zeros(B, 9, device=dev)
 
     stream_mode = args.mode == "stream"
@@ -585,10 +602,10 @@ def run(args, ctx, primary):
             eng.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), ms_loc.data_ptr(),
                                         lv_loc.data_ptr(), h1.data_ptr(), sp)
             if collective:
-                ms_all, lv_all, _ = hdist.gather_mc_samples(ms_loc, lv_loc, h1)
+                hdist.gather_mc_block(both, mc_gathered)
+                eng.mc_finish_gathered_device(mc_gathered.data_ptr(), world, n_loc, h1.data_ptr(), B, out.data_ptr(), sp)
             else:
-                ms_all, lv_all = ms_loc, lv_loc
-            eng.mc_finish_device(ms_all.data_ptr(), lv_all.data_ptr(), n_mc, h1.data_ptr(), B, mean.data_ptr(), cov.data_ptr(), sp)
+                eng.mc_finish_packed_device(ms_loc.data_ptr(), lv_loc.data_ptr(), n_mc, h1.data_ptr(), B, out.data_ptr(), sp)
             return
         if og is not None:
             og.acquire(i, stream)
@@ -607,10 +624,14 @@ def run(args, ctx, primary):
 
     for i in range(args.warmup):
         step(i)
+    if og is not None and args.warmup:
+        og.flush(args.warmup - 1, comp_stream if stream_mode else stream)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if og is not None:      # a step count that is not a multiple of the group: the last, partly filled slab is gathered INSIDE the timed region
+        og.flush(args.warmup + args.steps - 1, comp_stream if stream_mode else stream)
     sync()
     dt = time.perf_counter() - t0
     if collective:
@@ -672,7 +693,7 @@ def run(args, ctx, primary):
         slots = sorted({0, 1, B // 2, B - 1} & set(range(B)))
         s0 = seq0_of_step(last)
         if mc_mode:
-            mean_np, cov_np = mean.cpu().numpy(), cov.cpu().numpy()
+            mean_np, cov_np = out[:, :8].cpu().numpy(), out[:, 8:].cpu().numpy()
         else:
             fin = out_of_step(last)                                       # the packed [B, 72] record of the last executed step
             mean_np, cov_np = fin[:, :8].cpu().numpy(), fin[:, 8:].cpu().numpy()
@@ -695,6 +716,31 @@ def run(args, ctx, primary):
         res["verify"] = {"against": "oracle/ (CPU restatement, double accumulation)", "slots_per_rank": slots, "step": last,
                          "gate_px": gate_px if gated else None, "passed": bool(ok)}
 
+    if rank == 0 and mc_mode and world == 1 and not primary:
+        # BASELINE config 4 stated, not discovered: what sharding the N samples over 8 GPUs saves per rank - the same pair on a context that draws
+        # N / 8 of the samples - against what the collective + the finish add (1-rank RCCL, C++ caller: tests/cpp/rccl_gather_example.cpp --time, committed log)
+        def t_partial(e, nl, n_it=300):
+            bb = torch.zeros(2, B, nl, 8, device=dev)
+            for i in range(n_it + 30):
+                if i == 30:
+                    torch.cuda.synchronize(dev)
+                    t0_ = time.perf_counter()
+                e.infer_mc_partial_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, i * B, bb[0].data_ptr(), bb[1].data_ptr(), h1.data_ptr(), sp)
+            torch.cuda.synchronize(dev)
+            return 1e3 * (time.perf_counter() - t0_) / n_it
+        if n_mc % 8 == 0:
+            e8 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec,
+                            mc_shard=(0, n_mc // 8))
+            t_all, t_8th = t_partial(eng, n_mc), t_partial(e8, n_mc // 8)
+            e8.close()
+            coll = committed_config4_cost()
+            res["mc_sharding"] = {"forward_all_samples_ms": round(t_all, 4), "forward_one_eighth_of_the_samples_ms": round(t_8th, 4),
+                                  "saved_per_rank_ms": round(t_all - t_8th, 4), "allgather_plus_finish_ms": coll[0], "allgather_source": coll[1],
+                                  "statement": ("one pair per step: sharding the N = %d MC samples over 8 GPUs removes %.0f us of heads per rank and adds the collective + finish "
+                                                "(%s us on a 1-rank RCCL communicator, more over xGMI): for ONE pair the 8-GPU form is %s than one GPU - the sharding pays "
+                                                "for batches of pairs, where the heads are 10 %% of a step, or for N >> 32"
+                                                % (n_mc, 1e3 * (t_all - t_8th), "n/a" if coll[0] is None else "%.0f" % (1e3 * coll[0]),
+                                                   "n/a" if coll[0] is None else ("slower" if coll[0] > t_all - t_8th else "faster")))}
     if rank == 0 and not primary and getattr(args, "latency_probe", False) and not mc_mode and not stream_mode:
         # BASELINE config 2 per arithmetic mode ("single frame pair ... bf16"): the batch-1 device latency of THIS configuration (graph replay, 200 after 20)
         e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank, precision=prec)

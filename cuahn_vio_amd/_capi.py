@@ -21,7 +21,7 @@ SYMBOLS = [
     "hnet_default_config", "hnet_create", "hnet_create_from_memory", "hnet_destroy", "hnet_status_string",
     "hnet_last_error", "hnet_version", "hnet_push_image", "hnet_attach_images", "hnet_image_count", "hnet_latest_time", "hnet_infer",
     "hnet_infer_batch", "hnet_infer_batch_device", "hnet_infer_batch_packed_device", "hnet_infer_mc_partial_device", "hnet_mc_finish_device",
-    "hnet_mc_finish_packed_device",
+    "hnet_mc_finish_packed_device", "hnet_mc_finish_gathered_device",
     "hnet_synchronize", "hnet_last_timing", "hnet_time_batch_device", "hnet_stage_count", "hnet_stage_name",
     "hnet_stage_flops_per_pair", "hnet_stage_kernels", "hnet_get_config", "hnet_profile_batch_device", "hnet_op_warp", "hnet_op_dlt", "hnet_op_conv",
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
@@ -96,6 +96,8 @@ def lib():
     L.hnet_mc_finish_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hnet_infer_batch_packed_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_uint64, vp, vp, vp]
     L.hnet_mc_finish_packed_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
+    L.hnet_mc_finish_gathered_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    L.hnet_get_config.argtypes = [vp, C.POINTER(Config)]
     L.hnet_synchronize.argtypes = [vp, vp]
     L.hnet_overflow_flag.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.hnet_last_timing.argtypes = [vp, C.POINTER(Timing)]

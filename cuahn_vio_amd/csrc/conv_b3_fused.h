@@ -62,8 +62,8 @@ struct B3Cfg {
     static_assert(W1 % TW == 0 && H1 % TH == 0, "tiles cover the 56 x 80 output exactly");
 };
 
-// w0frag: [7 kernel rows][2 planes][64 lanes] x 16 B: lane (n = l & 31 = (dx, co), hh = l >> 5) holds kk = 8 hh .. 8 hh + 7 of
-//         W'[kh][kk = 2 kw' + ci][n] = W[co][ci][kh][kw' - dx]   (conv_first.h; planes of the activation split, s3_format.h split2h)
+// w0frag: [7 kernel rows][3 planes][64 lanes] x 16 B (hnet_create's b30_frag, the fragments of conv7_c2_s1_s3_kernel): lane (n = l & 31 = (dx, co), hh = l >> 5)
+//         holds kk = 8 hh .. 8 hh + 7 of W'[kh][kk = 2 kw' + ci][n] = W[co][ci][kh][kw' - dx]   (conv_first.h; weight planes W0, W1, W2 of s3_format.h wsplit2h)
 // w1frag: [2 n-tiles][13 steps][2 planes][64 lanes] x 16 B: lane (i = l & 15, g = l >> 4) holds output channel 16 nt + i, tap 2 st + (g >> 1),
 //         input channels 8 (g & 1) .. + 7
 template <int NP>

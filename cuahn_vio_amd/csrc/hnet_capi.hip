@@ -101,7 +101,7 @@ struct hnet_ctx {
     int s3_tile = 0;                   // HNET_S3_TILE: tile-shape experiments of the implicit-GEMM layers (s3_dispatch.h), 0 = measured defaults
     bool patch_b128 = true;            // block_3_1 / block_4_2 read their fragments with ds_read_b128 from the interleaved layout (HNET_PATCH_B128=0: two ds_read_b64, half-major layout)
     bool fuse_b3 = false;              // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h): fp16-plane mode, HNET_FUSE_B3=0 switches back
-    uint16_t* b3f_w0 = nullptr;        // its weights: block_3_0 as [7][2][64] x 16 B fragments (two planes), block_3_1 as [2][13][2][64] x 16 B
+    // its weights: block_3_0 as the three-plane fragments b30_frag of conv_first.h, block_3_1 as [2][13][2][64] x 16 B
     uint16_t* b3f_w1 = nullptr;
     bool a14_pad = false;              // block_4_1's output (act16[14]) in the bordered layout of kernels.h B42_* (fused block-4 kernel -> LDS-DMA of the fused block_4_2 + 4_3 kernel)
     bool fuse_b42 = false;             // block_4_2 + block_4_3 in one kernel (conv_b42_fused.h): fp16-plane mode, HNET_FUSE_B42=0 switches back
@@ -424,7 +424,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 l = 16;
                 continue;
             }
-            if (c->fuse_b3 && l == 7 && c->n_planes == 2 && c->b3f_w0 && c->b3f_w1 && h == 112 && w == 160) {   // block_3_0 + block_3_1 in one launch
+            if (c->fuse_b3 && l == 7 && c->n_planes == 2 && c->b30_frag && c->b3f_w1 && h == 112 && w == 160) {   // block_3_0 + block_3_1 in one launch
                 const size_t cnt1 = c->act_count[8];
                 uint16_t* o16b = c->act16[8] + P0 * cnt1;
                 STAGE(launch_block3_fused(in, c->b30_frag, c->conv_b[7], c->b3f_w1, c->conv_b[8], o16b, MB * cnt1, B, s, c->n_planes));
@@ -545,7 +545,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
         auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
         for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); fr(c->conv_wfrag[l]); }
         for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
-        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3);
+        fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3);
         fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
     }
     // ---- weights: names are the reference state_dict keys (model_to_trace.py:88-115, :210-235)
@@ -598,23 +598,6 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
                 }
             CK(hipMalloc((void**)&c->b30_frag, fr.size() * 2));
             CK(hipMemcpy(c->b30_frag, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
-            if (c->n_planes == 2) {   // the same fragments in the two-plane form (w = W0 + W1 / 4096) of the fused block_3_0 + block_3_1 kernel
-                std::vector<uint16_t> f2((size_t)7 * 2 * 64 * 8, 0);
-                for (int kh = 0; kh < 7; kh++)
-                    for (int ln = 0; ln < 64; ln++) {
-                        const int n = ln & 31, hh = ln >> 5, dx = n >> 4, co = n & 15;
-                        for (int j = 0; j < 8; j++) {
-                            const int kk = 8 * hh + j, kw = (kk >> 1) - dx, ci = kk & 1;
-                            if (kw < 0 || kw >= 7) continue;
-                            uint16_t a0, a1;
-                            split2h(w->data[(((size_t)co * 2 + ci) * 7 + kh) * 7 + kw], a0, a1);
-                            f2[(((size_t)kh * 2 + 0) * 64 + ln) * 8 + j] = a0;
-                            f2[(((size_t)kh * 2 + 1) * 64 + ln) * 8 + j] = a1;
-                        }
-                    }
-                CK(hipMalloc((void**)&c->b3f_w0, f2.size() * 2));
-                CK(hipMemcpy(c->b3f_w0, f2.data(), f2.size() * 2, hipMemcpyHostToDevice));
-            }
             c->b30_s3 = true;
         }
         if (c->s3 && l == 8 && c->n_planes == 2) {   // block_3_1 for the fused kernel: lane (i, g) of n-tile nt, step st: channel 16 nt + i, tap 2 st + (g >> 1), ci 8 (g & 1) + j
@@ -1055,7 +1038,7 @@ void hnet_destroy(hnet_ctx* c) {
     }
     fr(c->d_seq); fr(c->d_flag);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
-    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w0); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
+    fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
     fr(c->d_mean); fr(c->d_cov); fr(c->d_err); fr(c->d_err_u8); fr(c->d_prior); fr(c->stage_prev); fr(c->stage_curr);
     fr(c->ring[0]); fr(c->ring[1]);
@@ -1412,6 +1395,15 @@ int hnet_mc_finish_packed_device(hnet_ctx* c, const float* d_mean_s, const float
     return HNET_OK;
 }
 
+int hnet_mc_finish_gathered_device(hnet_ctx* c, const float* d_gathered, int world, int n_local, const float* d_h_part1, int batch, float* d_out72, void* stream) {
+    if (!c || !d_gathered || !d_h_part1 || !d_out72 || world < 1 || n_local < 1 || batch < 1) return HNET_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t block = (size_t)batch * n_local * 8;        // floats of one [B][n_local][8] array; a rank's message is [mean block | log-variance block]
+    HIPCHK(c, launch_mc_finish(d_gathered, d_gathered + block, world * n_local, d_h_part1, batch, d_out72, d_out72 + 8, nullptr,
+                               stream ? (hipStream_t)stream : c->stream, c->d_flag, HNET_PACKED_FLOATS, HNET_PACKED_FLOATS, n_local, 2 * block));
+    return HNET_OK;
+}
+
 int hnet_synchronize(hnet_ctx* c, void* stream) {
     if (!c) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1640,7 +1632,7 @@ int hnet_op_block42_fused(hnet_ctx* c, const float* in, int batch, float* out) {
 
 int hnet_op_block3_fused(hnet_ctx* c, const float* in, int batch, float* out) {
     if (!c || !in || !out || batch < 1) return HNET_ERR_INVALID_ARG;
-    if (!c->fuse_b3 || !c->b3f_w0 || !c->b3f_w1) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_3_0 + block_3_1 kernel exists in the fp16-plane mode only");
+    if (!c->fuse_b3 || !c->b30_frag || !c->b3f_w1) return fail(c, HNET_ERR_UNSUPPORTED, "the fused block_3_0 + block_3_1 kernel exists in the fp16-plane mode only");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int h0 = IMG_H / 2, w0 = IMG_W / 2;
     const size_t n_in = (size_t)batch * 2 * h0 * w0, n_out = (size_t)batch * 32 * (h0 / 2) * (w0 / 2);

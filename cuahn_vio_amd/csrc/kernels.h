@@ -164,7 +164,8 @@ hipError_t launch_heads_fc2(const float* hidden, int batch, int n_local, int s_b
 // ensemble/transfer from gathered per-sample outputs [B][n][8]
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
                             float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag = nullptr,
-                            int mean_stride = 8, int cov_stride = 64 /* floats between consecutive pairs: 72 / 72 with cov = mean + 8 for the packed [B][72] record */);
+                            int mean_stride = 8, int cov_stride = 64 /* floats between consecutive pairs: 72 / 72 with cov = mean + 8 for the packed [B][72] record */,
+                            int n_local = 0, size_t rank_stride = 0 /* != 0: the samples as an all-gather leaves them - rank r's [B][n_local][8] block starts r * rank_stride floats in */);
 
 // latency path (n_local <= 64): both launches above in one, one 1024-thread workgroup per pair; bit-identical results
 constexpr int HEADS_FC2_FINISH_MAX_N = 64;

@@ -935,19 +935,23 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     return __hiloint2double(hi, lo);
 }
 // the ensemble + transfer of ONE pair by one wave (t = lane); ms / lv: the pair's per-sample outputs [n][8] (global memory or LDS)
+// n_local / rank_stride (round 5): sample s of the pair lives at (s / n_local) * rank_stride + (s % n_local) * 8 floats - the layout an all-gather of every
+// rank's [B][n_local][8] block produces ([rank][...]); rank_stride = 0: all n samples consecutive (n_local unused)
 __device__ __forceinline__ void mc_finish_wave(const float* ms, const float* lv, int n, const float* __restrict__ H1_b, float* __restrict__ mean_b,
-                                               float* __restrict__ cov_b, float* __restrict__ Htot_b, uint32_t* __restrict__ flag, int t) {
+                                               float* __restrict__ cov_b, float* __restrict__ Htot_b, uint32_t* __restrict__ flag, int t,
+                                               int n_local = 0, size_t rank_stride = 0) {
     const int i = t & 7, c = t >> 3;
+    auto at = [&](int s) -> size_t { return rank_stride ? (size_t)(s / n_local) * rank_stride + (size_t)(s % n_local) * 8 + i : (size_t)s * 8 + i; };
     double sm = 0, sv = 0;
     for (int s = c; s < n; s += 8) {
-        sm += (double)ms[s * 8 + i];
-        sv += exp((double)lv[s * 8 + i]);
+        sm += (double)ms[at(s)];
+        sv += exp((double)lv[at(s)]);
     }
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) { sm += shfl_xor_f64(sm, m); sv += shfl_xor_f64(sv, m); }
     const float mb = (float)(sm / n), vb = (float)(sv / n);
     double se = 0;
-    for (int s = c; s < n; s += 8) { const double d = (double)mb - (double)ms[s * 8 + i]; se += d * d; }
+    for (int s = c; s < n; s += 8) { const double d = (double)mb - (double)ms[at(s)]; se += d * d; }
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) se += shfl_xor_f64(se, m);
     const double en = (double)(float)((double)(float)(se / n) + (double)vb);
@@ -994,10 +998,12 @@ __device__ __forceinline__ void mc_finish_wave(const float* ms, const float* lv,
 // [B][72] record mean | cov that a multi-GPU caller all-gathers: cov = mean + 8)
 __global__ __launch_bounds__(64) void mc_finish_kernel(const float* __restrict__ mean_s, const float* __restrict__ logvar_s, int n,
                                                        const float* __restrict__ H1, int batch, float* __restrict__ mean,
-                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag, int mean_stride, int cov_stride) {
+                                                       float* __restrict__ cov, float* __restrict__ Htot, uint32_t* __restrict__ flag, int mean_stride, int cov_stride,
+                                                       int n_local, size_t rank_stride) {
     const int b = blockIdx.x;
-    mc_finish_wave(mean_s + (size_t)b * n * 8, logvar_s + (size_t)b * n * 8, n, H1 + b * 9, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride,
-                   Htot ? Htot + b * 9 : nullptr, flag, threadIdx.x);
+    const size_t pair = (size_t)b * (rank_stride ? n_local : n) * 8;
+    mc_finish_wave(mean_s + pair, logvar_s + pair, n, H1 + b * 9, mean + (size_t)b * mean_stride, cov + (size_t)b * cov_stride,
+                   Htot ? Htot + b * 9 : nullptr, flag, threadIdx.x, n_local, rank_stride);
 }
 
 // Small batches (latency path): second FC of the heads for ALL samples of a pair and the ensemble in ONE launch, one 1024-thread workgroup
@@ -1061,8 +1067,9 @@ hipError_t launch_heads_fc2_finish(const float* hidden, int batch, int n_local, 
 }
 
 hipError_t launch_mc_finish(const float* mean_s, const float* logvar_s, int n, const float* H1, int batch,
-                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag, int mean_stride, int cov_stride) {
-    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot, flag, mean_stride, cov_stride);
+                            float* mean, float* cov, float* Htot, hipStream_t s, uint32_t* flag, int mean_stride, int cov_stride, int n_local, size_t rank_stride) {
+    if (rank_stride && (n_local < 1 || n % n_local)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(batch), dim3(64), 0, s, mean_s, logvar_s, n, H1, batch, mean, cov, Htot, flag, mean_stride, cov_stride, n_local, rank_stride);
     return hipGetLastError();
 }
 

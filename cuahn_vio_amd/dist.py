@@ -61,6 +61,14 @@ def gather_mc_samples(mean_s, logvar_s, h_part1, group=None):
     return g[0].contiguous(), g[1].contiguous(), h_part1
 
 
+def gather_mc_block(both, gathered, group=None):
+    """Round 5: config 4 without layout launches.  `both` = this rank's [2, B, n_local, 8] array (hnet_infer_mc_partial_device wrote mean_s into both[0]
+    and logvar_s into both[1]); ONE all_gather_into_tensor fills `gathered` [world, 2, B, n_local, 8], which hnet_mc_finish_gathered_device reads in place
+    (rank-major = global sample order): no stack, no permute, no .contiguous() between the forward and the finish."""
+    _all_gather(gathered, both, group)
+    return gathered
+
+
 class OverlappedGather:
     """The gather of the packed [B, 72] outputs OFF the compute stream: two packed output slabs and two gathered slabs; step i
     writes its outputs into its slab (hnet_infer_batch_packed_device: no packing copies), then `submit(i)` hands a full slab to a side stream, which
@@ -77,6 +85,7 @@ class OverlappedGather:
         self.out = [torch.zeros(self.G * batch, 72, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.G * batch, 72, device=device) for _ in range(2)]
         self.pending = [False, False]
+        self.submitted_upto = [-1, -1]      # last step whose slab submission covers it (result() checks)
         if self.cuda:
             # its own priority level: the HIP runtime multiplexes the streams of ONE priority over its hardware queues, and a side stream that lands on the
             # compute stream's queue serialises the gather between two forwards instead of running it under the next one (bench.py, stream mode, saw
@@ -103,6 +112,7 @@ class OverlappedGather:
         if i % self.G != self.G - 1 and not flush:
             return
         k = self._slab(i)
+        self.submitted_upto[k] = i
         if not self.cuda:
             _all_gather(self.gathered[k], self.out[k], self.group)
             self.pending[k] = True
@@ -115,9 +125,18 @@ class OverlappedGather:
             self.ev_gathered[k].record(self.side)
         self.pending[k] = True
 
+    def flush(self, last_step, compute_stream=None):
+        """gather the partly filled slab that holds step `last_step` (a run whose step count is not a multiple of group_steps: call before the closing
+        synchronize of a timed region, so that every step's collective lies inside it)"""
+        if last_step % self.G != self.G - 1:
+            self.submit(last_step, compute_stream, flush=True)
+
     def result(self, i):
-        """[world, B, 72]: step i's records of every rank (after the slab of step i has been submitted)"""
+        """[world, B, 72]: step i's records of every rank.  The slab of step i must have been submitted (submit of its last step, or flush) AFTER
+        step i was enqueued - checked"""
         k, j = self._slab(i), i % self.G
+        if self.submitted_upto[k] < i:
+            raise RuntimeError(f"OverlappedGather.result({i}): the slab of that step has not been submitted since the step was written")
         if self.cuda and self.pending[k]:
             self.ev_gathered[k].synchronize()
         return self.gathered[k].view(self.world, self.G, self.B, 72)[:, j]

@@ -144,6 +144,10 @@ class HnetEngine:
         check(self._h, self._L.hnet_infer_mc_partial_device(self._h, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_mean_s,
                                                             d_logvar_s, d_h1, self._stream(stream)))
 
+    def mc_finish_gathered_device(self, d_gathered, world, n_local, d_h1, batch, d_out72, stream=None):
+        """hnet_mc_finish_gathered_device: the ensemble straight from the all-gathered [world][2][B][n_local][8] buffer"""
+        check(self._h, self._L.hnet_mc_finish_gathered_device(self._h, d_gathered, world, n_local, d_h1, batch, d_out72, self._stream(stream)))
+
     def mc_finish_device(self, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov, stream=None):
         check(self._h, self._L.hnet_mc_finish_device(self._h, d_mean_s, d_logvar_s, n_total, d_h1, batch, d_mean, d_cov,
                                                      self._stream(stream)))

@@ -227,6 +227,12 @@ int hnet_mc_finish_device(hnet_ctx* ctx, const float* d_mean_s, const float* d_l
 /* ... with the packed [batch][72] record of hnet_infer_batch_packed_device as output */
 int hnet_mc_finish_packed_device(hnet_ctx* ctx, const float* d_mean_s, const float* d_logvar_s, int n_total, const float* d_h_part1,
                                  int batch, float* d_out72, void* stream);
+/* Round 5 (BASELINE config 4 without layout launches): the ensemble straight from the buffer an all-gather fills.  Every rank passes ONE [2][B][n_local][8]
+ * array to hnet_infer_mc_partial_device (d_mean_s = its first half, d_logvar_s = its second) and all-gathers it into d_gathered [world][2][B][n_local][8]
+ * (ncclAllGather / all_gather_into_tensor: rank-major = global sample order); this call reads sample s of pair b at rank s / n_local - no stack, permute or
+ * copy between the collective and the finish.  Same two-pass arithmetic and the same bits as hnet_mc_finish_packed_device on the re-ordered samples. */
+int hnet_mc_finish_gathered_device(hnet_ctx* ctx, const float* d_gathered, int world, int n_local, const float* d_h_part1, int batch, float* d_out72,
+                                   void* stream);
 
 int hnet_synchronize(hnet_ctx* ctx, void* stream);
 int hnet_last_timing(const hnet_ctx* ctx, hnet_timing* out);

@@ -134,8 +134,7 @@ def test_tiled_warp_is_bitwise_the_direct_warp(eng_exact, k):
         want = np.stack([_pool_like_kernel(f1, k), _pool_like_kernel(direct, k)])
         got_u8 = eng_exact.op_prep_u8(i1, i2, hm, k)
         got_f32 = eng_exact.op_prep(f1, f2, hm, k)
-        mode = os.environ.get("HNET_PREP_TILED", "1")
-        if mode != "0" and (k <= 2 or mode == "2"):   # otherwise the direct-gather pooling kernel runs (other summation order)
+        if k <= 2:   # (exact sampler: the tiled kernel for K <= 2; the direct-gather pooling kernel - another summation order - above)
             assert np.array_equal(got_u8, want), (name, float(np.abs(got_u8 - want).max()))
             assert np.array_equal(got_f32, want), (name, float(np.abs(got_f32 - want).max()))
         else:

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """In-process A/B of build-time-identical kernels under different context switches (cdna_hip_programming.md §5.4 rule 24:
-perf deltas come from interleaved rounds in ONE process on ONE device).  Each variant is a dict of environment variables that
-hnet_create reads (HNET_B4_CFG, HNET_FUSE_B4, HNET_PATCH, ...); variants are timed round-robin with per-stage HIP events.
+perf deltas come from interleaved rounds in ONE process on ONE device).  Each variant is a dict of the environment variables that the Python
+mirror maps onto hnet_config (cuahn_vio_amd/homography_net.py kernel_selection_from_env: HNET_S3_TILE = the low byte of hnet_config.variant,
+HNET_FUSE_SMALL / HNET_FUSE_B3 / HNET_FUSE_B42 = 0, HNET_GRAPH, HNET_WARP_EXACT; the library itself reads no environment variable); variants are
+timed round-robin with per-stage HIP events.
 
-  python tools/ab_bench.py '{"HNET_B4_CFG":"0"}' '{"HNET_B4_CFG":"1"}' [--rounds 5] [--batch 256] [--stages block_4_0+4_1,block_3_1]
+  python tools/ab_bench.py '{}' '{"HNET_S3_TILE":"30"}' [--rounds 5] [--batch 256] [--stages block_4_0+4_1,block_3_1]
 """
 import argparse, json, os, sys
 import numpy as np
