@@ -164,6 +164,18 @@ __device__ __forceinline__ float cvt_f32_f16_hi(uint32_t packed) {
     return f;
 }
 typedef float f32x2_p __attribute__((ext_vector_type(2)));      // value pairs: v_pk_mul_f32 / v_pk_fma_f32
+// Second fp16 plane of a value pair in TWO instructions (round 5): A1 = f16(c - 4096 A0) with A0 taken straight from the packed fp16 register by
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp32 fma with an fp16 source, result rounded to fp16 into one half of the destination) - instead of two
+// v_cvt_f32_f16, one v_pk_fma_f32 and one v_cvt_pk_f16_f32.  c - 4096 A0 is exact in fp32 (|c - 4096 A0| <= half an fp16 ulp of 4096 A0, on fp32's
+// grid), so both forms round the same number once to fp16: same bits (tools/out_hash.py before / after; the goldens).  c0, c1 = the values at
+// 4096 x scale, a0 = packed f16(c / 4096).
+__device__ __forceinline__ uint32_t f16_residual_pk(uint32_t a0, float c0, float c1) {
+    uint32_t r;
+    const float ms = -S3_F16_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a0), "s"(ms), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(a0), "s"(ms), "v"(c1));
+    return r;
+}
 template <int NP>
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
     if constexpr (NP == 2) {         // fp16 planes: value = A0 + A1 / 4096
@@ -198,9 +210,7 @@ __device__ __forceinline__ void act_split(float a0, float a1, uint32_t (&pl)[3],
         if (!ok) u = f32x2_p{0.f, 0.f};
         const f32x2_p v = u * S3_F16_INV;
         pl[0] = cvt_pk_f16(v[0], v[1]);
-        const f32x2_p h = {cvt_f32_f16_lo(pl[0]), cvt_f32_f16_hi(pl[0])};
-        const f32x2_p r = u - h * S3_F16_SCALE;
-        pl[1] = cvt_pk_f16(r[0], r[1]);
+        pl[1] = f16_residual_pk(pl[0], u[0], u[1]);      // f16(u - 4096 A0): 9 vector instructions per pair (11 until round 4)
     } else {
         split_pair<NP>(ok ? act<NP>(a0) : 0.f, ok ? act<NP>(a1) : 0.f, pl);
     }

@@ -15,6 +15,16 @@
 
 namespace hnet {
 
+// f16(c0 - 4096 A0.lo) | f16(c1 - 4096 A0.hi) << 16 with A0 read straight from the packed fp16 register (v_fma_mixlo / mixhi_f16; igemm_s3.h has the
+// same helper for the GEMM epilogues): the difference is exact in fp32, so this is the one rounding of split2h's second plane
+__device__ __forceinline__ uint32_t prep_f16_residual_pk(uint32_t a0, float c0, float c1) {
+    uint32_t r;
+    const float ms = -S3_F16_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a0), "s"(ms), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(a0), "s"(ms), "v"(c1));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pixel access: u8 -> float exactly as `toType(kFloat) / 255.0` (HomographyNet.cpp:141,146) through a
 // 256-entry table in LDS (one IEEE division per entry per workgroup instead of one per tap)
@@ -252,7 +262,7 @@ __device__ __forceinline__ float warp_sample_box(const float* h, int u, int v, c
 //   * weights come from v_fract_f32, the LDS address from one FMA + one conversion.
 // ~30 vector instructions per pixel instead of ~85.  Used only for tiles with a staged box and Z safely away from 0 (the others take the
 // exact path).  Measured position difference to the exact path: < 6e-5 px; outputs: same golden gates (tests/test_gpu_parity.py).
-struct WarpFast { float bx_lo, bx_hi, by_lo, by_hi, fpitch, fbase; };
+struct WarpFast { float bx_lo, bx_hi, by_lo, by_hi, fpitch; int ibase; };
 __device__ __forceinline__ WarpFast warp_fast_setup(const WarpBox& bx) {
     WarpFast f;
     f.bx_lo = (float)max(bx.gx0, -1);
@@ -260,7 +270,7 @@ __device__ __forceinline__ WarpFast warp_fast_setup(const WarpBox& bx) {
     f.by_lo = (float)max(bx.ry0, -1);
     f.by_hi = (float)min(bx.ry0 + bx.rows - 2, IMG_H);
     f.fpitch = (float)bx.pitch;
-    f.fbase = -((float)bx.ry0 * (float)bx.pitch + (float)bx.gx0);      // |values| < 2^15: exact in fp32
+    f.ibase = -(bx.ry0 * bx.pitch + bx.gx0);                           // element offset of image pixel (0, 0) in the staged box: added to the LDS base once per thread
     return f;
 }
 __device__ __forceinline__ float warp_sample_box_fast(float X, float Y, float Z, const WarpFast& f, int pitch, const float* reg) {
@@ -269,14 +279,14 @@ __device__ __forceinline__ float warp_sample_box_fast(float X, float Y, float Z,
     const float ix = __builtin_amdgcn_fmed3f(X * r1, f.bx_lo, f.bx_hi);   // NaN -> one of the bounds (a zero-weight corner case, never a fault)
     const float iy = __builtin_amdgcn_fmed3f(Y * r1, f.by_lo, f.by_hi);
     const float x0f = floorf(ix), y0f = floorf(iy);
-    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-    const int e = (int)fmaf(y0f, f.fpitch, x0f + f.fbase);             // exact: integers below 2^24
+    const float wx1 = ix - x0f, wy1 = iy - y0f;
+    const int e = (int)fmaf(y0f, f.fpitch, x0f);                       // exact: integers below 2^24 (the box origin is folded into `reg` by the caller)
     const float* t = reg + e;
-    float s = t[0] * (wx0 * wy0);
-    s = fmaf(t[1], wx1 * wy0, s);
-    s = fmaf(t[pitch], wx0 * wy1, s);
-    s = fmaf(t[pitch + 1], wx1 * wy1, s);
-    return s;
+    // round 5: the blend as three interpolations (6 instructions) instead of four weight products and four FMAs (10 with the two 1 - w): the fast sampler's
+    // contract is the 1e-4 px of the network's outputs, not the reference's order of the four products (that is the exact sampler's)
+    const float top = fmaf(wx1, t[1] - t[0], t[0]);
+    const float bot = fmaf(wx1, t[pitch + 1] - t[pitch], t[pitch]);
+    return fmaf(wy1, bot - top, top);
 }
 
 // Linear(5120, 8) of one pair + corner update + DLT + composition (model_to_trace.py:143-150, :163-168, :183-188), by one 256-thread
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float fv = (float)(v0 + r0 + i);
-            w[i] = warp_sample_box_fast(fmaf(h[1], fv, Xc), fmaf(h[4], fv, Yc), fmaf(h[7], fv, Zc), wf, bx.pitch, reg);
+            w[i] = warp_sample_box_fast(fmaf(h[1], fv, Xc), fmaf(h[4], fv, Yc), fmaf(h[7], fv, Zc), wf, bx.pitch, reg + wf.ibase);
         }
     } else if (bx.zsafe) {                                              // workgroup-uniform: the shared-reciprocal division without its range test
 #pragma unroll
@@ -433,11 +443,10 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
             for (int i = 0; i < 8; i++) {                               // = split2h(a), split2h(w) of s3_format.h: A0 = f16(v), A1 = f16((v - A0) 4096)
                 const f2 v = {a[i], w[i]};
                 const h2 hi = {(_Float16)v[0], (_Float16)v[1]};
-                const f2 back = {(float)hi[0], (float)hi[1]};
-                const f2 r = (v - back) * S3_F16_SCALE;
-                const h2 lo = {(_Float16)r[0], (_Float16)r[1]};
-                o0[(size_t)i * B4_WP] = __builtin_bit_cast(uint32_t, hi);
-                o0[s3_plane + (size_t)i * B4_WP] = __builtin_bit_cast(uint32_t, lo);
+                const uint32_t hi_u = __builtin_bit_cast(uint32_t, hi);
+                const f2 c = v * S3_F16_SCALE;                          // (exact) - then A1 = f16(c - 4096 A0) in two mixed-precision FMAs (round 5: 4 instructions, 6 before)
+                o0[(size_t)i * B4_WP] = hi_u;
+                o0[s3_plane + (size_t)i * B4_WP] = prep_f16_residual_pk(hi_u, c[0], c[1]);
             }
         } else
 #pragma unroll
