@@ -18,6 +18,21 @@
 #include <string>
 #include <vector>
 
+// `make ROCTX=1` (-DHNET_ROCTX, links libroctx64): roctx ranges around the forward and around each block, visible in rocprofv3 --marker-trace and in
+// the timeline tools - the counterpart of the stopwatches the reference brackets `forward` with (HomographyNet.cpp:178-188).  Off in the default build:
+// the hot path makes no call into a tracing library.
+#ifdef HNET_ROCTX
+#include <roctracer/roctx.h>
+struct HnetRange {
+    explicit HnetRange(const char* name) { roctxRangePush(name); }
+    ~HnetRange() { roctxRangePop(); }
+    HnetRange(const HnetRange&) = delete;
+};
+#define HNET_RANGE(var, name) HnetRange var(name)
+#else
+#define HNET_RANGE(var, name) do { } while (0)
+#endif
+
 using namespace hnet;
 
 namespace {
@@ -373,7 +388,11 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         else STAGE(launch_prior_dlt(a.prior, Hm, B, s));                               // :129-130
     }
     const int fb = g.use_prior ? 4 - g.blocks_to_run : 0;
+    HNET_RANGE(range_fwd, "hnet forward");
     for (int blk = fb; blk < 4; blk++) {
+        static const char* const kBlockRange[4] = {"hnet block 1", "hnet block 2", "hnet block 3", "hnet block 4 trunk"};
+        HNET_RANGE(range_blk, kBlockRange[blk]);
+        (void)kBlockRange;
         const bool warp = g.use_prior || blk > 0;                                    // block 1 of the full model sees raw img2 (:138)
         int h = IMG_H >> (3 - blk), w = IMG_W >> (3 - blk);
         float* x = c->x_in[blk] + P0 * h * w * 2;
@@ -463,6 +482,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     Hm = Hcur;                                     // H_part1 of this forward
     c->H_last = Hcur - P0 * 9;
     // block 4 heads (:272-282) and output assembly (:310-317)
+    HNET_RANGE(range_heads, "hnet heads + ensemble");
     const float* feat = c->act[19] + P0 * 5120;
     float* hidden = c->hidden + P0 * c->n_local * 512;
     if (c->s3) {
