@@ -139,41 +139,53 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
         }
     };
 
-    // ---- A fragment addressing
+    // ---- A fragment addressing.  Round 5: everything about a (tap, row) address that does not depend on the lane is a scalar of the tap - input pixel
+    // (y, x) = (2 oy - PAD + kh, 2 ox - PAD + kw), so its parity image is (kh - PAD) & 1, (kw - PAD) & 1 and its position inside the image is the row's own
+    // (oy, ox) shifted by dy = (kh - PAD) >> 1, dx = (kw - PAD) >> 1 - and the lane keeps three sums per M-tile row (byte address of output pixel (oy, ox) in
+    // the even-y and in the odd-y images, its T) plus one word of validity bits (which kh / kw fall inside the image).  Eleven vector instructions per
+    // (tap, row) instead of ~ 20 (the kernel was vector-issue bound: 4.6 - 8.0 VALU per MFMA, profiles/r04_v4_pmc_mfma_lds.csv).  Same addresses.
     const int r16 = lane & 15, g16 = lane >> 4;
-    int qpair_e[TM], qpair_o[TM], tbase[TM], oy2[TM], ox2[TM];   // per M-tile row of this lane: its pair's first row in the even-y / odd-y images, pair Ho Wo, 2 oy - PAD, 2 ox - PAD
-    uint32_t row_ok = 0;
+    int qe_b[TM], qo_b[TM], tt0[TM];                             // x 128 bytes: row of (pair, oy, ox) in the (even y, even x) / (odd y, even x) image; T of (pair, oy, ox)
+    uint32_t okb[TM];                                            // bit kh: y inside the image; bit 8 + kw: x inside; 0 for rows beyond the tile
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int ml = i * 16 + r16;                             // row of the tile
         const bool ok = m0 + ml < m_end;
         const int pl_ = ml / R, rem = ml - pl_ * R, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        qpair_e[i] = pl_ * ps_e;
-        qpair_o[i] = pl_ * ps_o;
-        tbase[i] = pl_ * R;
-        oy2[i] = 2 * oy - PAD;
-        row_ok |= ok ? (1u << i) : 0u;                           // (rows beyond the tile read zero rows - of their own bank class: T stays linear in the row)
-        ox2[i] = 2 * ox - PAD;
+        const int t0 = oy * Wo + ox;
+        qe_b[i] = (pl_ * ps_e + t0) * 128;
+        qo_b[i] = (base2 + pl_ * ps_o + t0) * 128;
+        tt0[i] = pl_ * R + t0;                                   // (rows beyond the tile read zero rows - of their own bank class: T stays linear in the row)
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            bits |= ((unsigned)(2 * oy - PAD + k) < (unsigned)p.H) ? (1u << k) : 0u;
+            bits |= ((unsigned)(2 * ox - PAD + k) < (unsigned)p.W) ? (1u << (8 + k)) : 0u;
+        }
+        okb[i] = ok ? bits : 0u;
     }
     bf16x8 fa[2][TM][2];
     int a_byte[TM];                                              // byte offset (inside a plane of a buffer) of this lane's step-0 chunk of the current tap
+    const int xoff_e = C::P * ps_e * 128, xoff_o = C::P * ps_o * 128;      // odd-x image behind the even-x image of the same y parity
     auto tap_addr = [&](int t) {                                 // t wave-uniform; t >= NTAP (the padding tap of KSPLIT): the zero row
 #if defined(HNET_REGION_ABLATE) && HNET_REGION_ABLATE == 2
         if (t != t_lo_w) return;                                 // ablation (wrong results): one address computation per chunk
 #endif
+        // scalars of the tap
         const int kh = t / KS, kw = t - kh * KS;
+        const int ey = kh - PAD, ex = kw - PAD;
+        const int yo = ey & 1, xo = ex & 1, dt = (ey >> 1) * Wo + (ex >> 1);
+        const int s_b = (xo ? (yo ? xoff_o : xoff_e) : 0) + dt * 128;
+        const uint32_t need = t < NTAP ? ((1u << kh) | (1u << (8 + kw))) : 0xFFFFFFFFu;      // (the padding tap: never satisfied)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             // (opaque to the optimiser: the addresses of a tap are the same in every chunk, and hoisting all KS x KS x TM of them out of the chunk loop spills)
-            int oy_ = oy2[i];
-            asm volatile("" : "+v"(oy_));
-            const int y = oy_ + kh, x = ox2[i] + kw;
-            const bool ok = t < NTAP && ((row_ok >> i) & 1u) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const int yo = y & 1, xo = x & 1;
-            const int tt = (y >> 1) * Wo + (x >> 1);
-            const int T = tbase[i] + tt;
-            const int q = ok ? (yo ? base2 + qpair_o[i] : qpair_e[i]) + (xo ? (yo ? C::P * ps_o : C::P * ps_e) : 0) + tt : C::RP + (T & 15);
-            a_byte[i] = q * 128 + ((g16 ^ (2 * ((T >> 1) & 3))) << 4);
+            int t0_ = tt0[i], qs_ = yo ? qo_b[i] : qe_b[i];
+            asm volatile("" : "+v"(t0_), "+v"(qs_));
+            const int T = t0_ + dt;
+            const bool ok = (okb[i] & need) == need;
+            const int qb = ok ? qs_ + s_b : (C::RP + (T & 15)) * 128;
+            a_byte[i] = qb | ((g16 ^ (T & 6)) << 4);
         }
     };
     auto read_a = [&](int set, int buf, int st) {                // st = 32-deep step of the K-tile; a_byte holds the tap's addresses
