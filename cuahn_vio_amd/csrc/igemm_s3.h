@@ -178,11 +178,10 @@ __device__ __forceinline__ uint32_t f16_residual_pk(uint32_t a0, float c0, float
 }
 template <int NP>
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]) {
-    if constexpr (NP == 2) {         // fp16 planes: value = A0 + A1 / 4096
+    if constexpr (NP == 2) {         // fp16 planes: value = A0 + A1 / 4096, A1 = f16((v - A0) 4096) = f16(4096 v - 4096 A0): four instructions (six until round 4)
         pl[0] = cvt_pk_f16(v0, v1);
-        const f32x2_p v = {v0, v1}, h = {cvt_f32_f16_lo(pl[0]), cvt_f32_f16_hi(pl[0])};
-        const f32x2_p r = (v - h) * S3_F16_SCALE;
-        pl[1] = cvt_pk_f16(r[0], r[1]);
+        const f32x2_p c = f32x2_p{v0, v1} * S3_F16_SCALE;               // exact (a power of two; |v| < 2^15)
+        pl[1] = f16_residual_pk(pl[0], c[0], c[1]);
         return;
     }
     pl[0] = cvt_pk(v0, v1);

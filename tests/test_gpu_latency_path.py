@@ -3,8 +3,10 @@ block's prep kernel, heads_fc2 + mc_finish run as one launch (csrc/hnet_capi.hip
 finished without reduce launches (last-arriver tiles, reduce-on-load chains: kernels.h LatIO) - all of this is the same arithmetic in the same
 order, so the homography of blocks 1 - 3 must be BITWISE that of the multi-launch path (HNET_FUSE_SMALL=0) in every arithmetic mode and variant.
 The heads' first FC is a different kernel on the latency path of the default mode (csrc/heads_lat.h: one launch, K summed in another order): there
-the outputs agree to fp32 rounding - gated at 3e-5 px / 1e-5 relative in the covariance, the other modes stay bitwise."""
-TOL_PX_PATHS = 3e-5       # |offset(latency path) - offset(multi-launch path)|, px: different summation order in the heads' first FC only
+the outputs agree to fp32 rounding - gated at 5e-5 px / 1e-5 relative in the covariance, the other modes stay bitwise.
+(Measured over the cases below: 0 ... 3.0e-5 px between the two orders, each of them 2.2e-5 ... 3.8e-5 px from the double-accumulating oracle: the
+mean head's last FC multiplies the hidden units by O(1) weights and cancels to O(5 px), so a 1e-7 relative change of the hidden units is a few 1e-5 px.)"""
+TOL_PX_PATHS = 5e-5       # |offset(latency path) - offset(multi-launch path)|, px: different summation order in the heads' first FC only
 TOL_COV_PATHS = 1e-5
 
 
