@@ -70,10 +70,10 @@ def parse(argv=None):
                     help="skip the additional measurements of the default run (sustained window, other arithmetic modes, configs 3 / 5, "
                          "reference launch default latency)")
     ap.add_argument("--sustain-seconds", type=float, default=1.6, help="length of the sustained window of the default run")
-    ap.add_argument("--contexts", type=int, default=1, metavar="NC",
+    ap.add_argument("--contexts", type=int, default=None, metavar="NC",
                     help="independent steps issued round-robin on NC contexts, each with its own HIP stream and buffers (--mode pairs, one GPU): the launch chain of "
-                         "one step runs under the kernels of the others; what a server with independent mid-size batches does (the default run reports BASELINE "
-                         "configs 3 and 5's per-GPU shape both ways)")
+                         "one step runs under the kernels of the others - what a server with independent batches does.  Default: 2 in --mode pairs (round 5: + 8 %% at "
+                         "256 pairs per step, + 30 %% at 32 - 64; the one-context figure of rounds 1 - 4 is reported beside it as `single_context`), 1 in the other modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
@@ -432,8 +432,7 @@ def sub_run(base, ctx, **over):
     r, ok = run(a, ctx, primary=False)
     keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms", "mc_sharding")
     out = {k: r[k] for k in keep if k in r}
-    if getattr(a, "contexts", 1) > 1:
-        out["contexts"] = a.contexts
+    out["contexts"] = r["config"].get("contexts", 1)
     out["passed"] = bool(ok)
     out["workload"] = r["config"]["workload"]
     out["precision"] = r["config"]["precision"]
@@ -496,15 +495,24 @@ def run(args, ctx, primary):
     torch.cuda.set_stream(stream)
     sp = stream.cuda_stream
     # --contexts NC: step i runs on context i % NC (own stream, own activation buffers, own output record; the inputs are read-only and shared)
-    NC = max(1, int(getattr(args, "contexts", 1) or 1))
-    if NC > 1 and (collective or mc_mode or args.mode == "stream"):
-        raise SystemExit("--contexts: single-GPU --mode pairs only")
+    NC = getattr(args, "contexts", None)
+    if NC is None:
+        NC = 2 if args.mode == "pairs" else 1
+    NC = max(1, int(NC))
+    if NC > 1 and (mc_mode or args.mode == "stream"):
+        raise SystemExit("--contexts: --mode pairs only")
+    if NC > 2 and collective:
+        raise SystemExit("--contexts > 2 with a collective: the overlapped gather has two output slabs")
+    if NC > 1 and og is not None and og.G > 1:      # grouped small steps share a slab across streams: one context there
+        if getattr(args, "contexts", None) is not None:
+            raise SystemExit("--contexts > 1 with grouped collectives (fewer than 128 pairs per GPU and step)")
+        NC = 1
     engs, streams, outs = [eng], [stream], [out]
     for _ in range(NC - 1):
         engs.append(HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec))
         streams.append(torch.cuda.Stream(dev))
         outs.append(torch.zeros(B, 72, device=dev))
-    if NC > 1:
+    if NC > 1 and og is None:
         out_of_step = lambda i: outs[i % NC]
     if mc_mode:
         n_loc = shard[1] - shard[0]
@@ -608,11 +616,11 @@ def run(args, ctx, primary):
                 eng.mc_finish_packed_device(ms_loc.data_ptr(), lv_loc.data_ptr(), n_mc, h1.data_ptr(), B, out.data_ptr(), sp)
             return
         if og is not None:
-            og.acquire(i, stream)
+            og.acquire(i, streams[i % NC])
         engs[i % NC].infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None,
                                                streams[i % NC].cuda_stream)
         if og is not None:
-            og.submit(i, stream)
+            og.submit(i, streams[i % NC])
 
     def sync():
         if stream_mode and use_thread:
@@ -625,13 +633,13 @@ def run(args, ctx, primary):
     for i in range(args.warmup):
         step(i)
     if og is not None and args.warmup:
-        og.flush(args.warmup - 1, comp_stream if stream_mode else stream)
+        og.flush(args.warmup - 1, comp_stream if stream_mode else streams[(args.warmup - 1) % NC])
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     if og is not None:      # a step count that is not a multiple of the group: the last, partly filled slab is gathered INSIDE the timed region
-        og.flush(args.warmup + args.steps - 1, comp_stream if stream_mode else stream)
+        og.flush(args.warmup + args.steps - 1, comp_stream if stream_mode else streams[(args.warmup + args.steps - 1) % NC])
     sync()
     dt = time.perf_counter() - t0
     if collective:
@@ -671,7 +679,8 @@ def run(args, ctx, primary):
                    "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision, "contexts": NC,
                    "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
                                    if mc_mode else
-                                   (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if collective else "single GPU")),
+                                   (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if collective else "single GPU")) +
+                                  (f"; per GPU the independent steps alternate between {NC} contexts / HIP streams" if NC > 1 else ""),
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
         "rccl_ranks": dist.get_world_size() if collective else 1, "backend": backend,
@@ -698,7 +707,7 @@ def run(args, ctx, primary):
             fin = out_of_step(last)                                       # the packed [B, 72] record of the last executed step
             mean_np, cov_np = fin[:, :8].cpu().numpy(), fin[:, 8:].cpu().numpy()
             if og is not None:                                            # ... and what the side-stream gather delivered for it: this rank's rows, bit for bit
-                og.submit(last, stream, flush=True)                      # (a partly filled group of small steps)
+                og.submit(last, streams[last % NC], flush=True)          # (a partly filled group of small steps)
                 g = og.result(last)
                 if not torch.equal(g[rank], fin):
                     raise SystemExit("bench.py: the gathered outputs differ from the local ones")
@@ -844,6 +853,8 @@ def run(args, ctx, primary):
             # the other arithmetic modes and BASELINE's other single-GPU configurations, 20 timed steps each, same process, same oracle gate
             # (a second of idle before each: they follow a 1.5 s sustained window, and the power-limited fp32 MFMA reads 49 k pairs/s on the hot
             # chip where a stand-alone run gives 61 k)
+            if NC > 1:      # the figure comparable with rounds 1 - 4: the same steps on ONE context / stream
+                res["single_context"] = sub_run(args, ctx, contexts=1, no_extras=True)
             res["modes"] = {}
             for pm in ("bf16x3", "fp32", "bf16"):
                 if pm != args.precision:
