@@ -1,6 +1,11 @@
+# the round's evidence set on the GPU box (through gpurun):  bash tools/evidence_round.sh <tag>      e.g. r05_v1
+TAG=${1:-r05_v1}
+R=${TAG%%_*}
 set -x
-bash tools/profile_round.sh r04_v4 > /dev/null 2>&1
-HNET_PARITY_TABLE=$PWD/gpurun_out/r04_parity_table.csv python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16_mode.py -m gpu -q 2>&1 | tail -2
-(python tools/full_batch_check.py 256 32 full 256 3; python tools/full_batch_check.py 256 16 prior3 256 3; python tools/full_batch_check.py 256 32 full 256 2; python tools/full_batch_check.py 256 32 full 256 0) > gpurun_out/r04_full_batch_check.log 2>&1
-python bench.py 2>gpurun_out/r04_v4_bench.err | tail -1 > gpurun_out/r04_v4_bench.json
-ls -la gpurun_out/r04_* gpurun_out/prof_r04_v4
+bash tools/profile_round.sh $TAG > /dev/null 2>&1
+rm -f gpurun_out/${R}_parity_table.csv gpurun_out/${R}_full_batch_check.log
+HNET_PARITY_TABLE=$PWD/gpurun_out/${R}_parity_table.csv python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16_mode.py -m gpu -q 2>&1 | tail -2
+(python tools/full_batch_check.py 256 32 full 256 3; python tools/full_batch_check.py 256 16 prior3 256 3; python tools/full_batch_check.py 256 32 full 256 2; python tools/full_batch_check.py 256 32 full 256 0) > gpurun_out/${R}_full_batch_check.log 2>&1
+python tools/determinism_stress.py 2000 > gpurun_out/${R}_determinism.log 2>&1
+python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
+ls -la gpurun_out/${R}_* gpurun_out/prof_$TAG

@@ -3,7 +3,7 @@
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/kstats_$TAG
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-verify --no-extras "$@" > $OUT.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-verify --no-extras --contexts 1 "$@" > $OUT.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, re
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

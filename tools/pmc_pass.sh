@@ -3,5 +3,5 @@
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
-timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-verify --no-extras > $OUT.log 2>&1
+timeout 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-verify --no-extras --contexts 1 > $OUT.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT

@@ -5,7 +5,8 @@
 #   mfma  : SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT + instruction counts
 TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency --no-verify --no-extras"
+# (--contexts 1: per-kernel durations and counters of ONE stream of launches - with the default two contexts kernels of different steps overlap and stretch each other)
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-latency --no-verify --no-extras --contexts 1"
 mkdir -p $OUT
 python3 $GRAFT_REPO_ROOT/tools/csrc_digest.py > $OUT/csrc_digest.txt
 cd /tmp && export TMPDIR=/tmp
