@@ -32,9 +32,13 @@
 namespace hnet {
 
 // P pairs per tile (P x Ho x Wo <= 80 rows); RP = region rows allocated (>= the four images' 2 P (even(Ho Wo) + even((H / 2) Wo)), multiple of 8); KSPLIT: 64-channel N-tiles, K halves over the wave halves
-template <int CIN_, int KS_, int P_, int RP_, bool KSPLIT_>
+// HI_ x WI_: the layer's input size (round 5: compile-time - the divisions by Wo, Ho Wo and the image sizes of the one-time address set-up were a thousand vector
+// instructions per workgroup, more than the K loop's own; s3_dispatch.h region_ok checks the launch against them)
+template <int CIN_, int KS_, int P_, int RP_, bool KSPLIT_, int HI_, int WI_>
 struct RegionCfg {
     static constexpr int CIN = CIN_, KS = KS_, P = P_, RP = RP_, PAD = (KS_ - 1) / 2;
+    static constexpr int HI = HI_, WI = WI_, HO = (HI_ + 1) / 2, WO = WI_ / 2;
+    static_assert(WI_ % 2 == 0, "the parity images assume an even input width");
     static constexpr bool KSPLIT = KSPLIT_;
     static constexpr int TM = 5, BM = 80, BN = KSPLIT_ ? 64 : 128, NWAVE = 8, NT = 512;
     static constexpr int NCHUNK = CIN / 64, NTAP = KS * KS;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = C::KSPLIT ? wave >> 2 : 0, wn = C::KSPLIT ? wave & 3 : wave;
-    const int R = p.Ho * p.Wo, HW = p.H * p.W;
+    constexpr int R = C::HO * C::WO, HW = C::HI * C::WI;
     const int rows_tile = C::P * R;                              // valid GEMM rows of a tile (<= 80)
     // workgroup -> tile (XCD-aware: an XCD's contiguous range of tiles shares weights AND neighbouring pairs)
     int mt, n0;
@@ -92,9 +96,9 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     const int grow = lane >> 3, gphys = lane & 7;
     constexpr int RGW = (C::RG + NWAVE - 1) / NWAVE;
     // the four images: sizes per pair (even), first rows
-    const int Wo = p.Wo, hh_e = (p.H + 1) >> 1, hh_o = p.H >> 1;
-    const int ps_e = (hh_e * Wo + 1) & ~1, ps_o = (hh_o * Wo + 1) & ~1;
-    const int base2 = 2 * C::P * ps_e;                           // first row of the odd-y images
+    constexpr int Wo = C::WO, hh_e = (C::HI + 1) >> 1, hh_o = C::HI >> 1;
+    constexpr int ps_e = (hh_e * Wo + 1) & ~1, ps_o = (hh_o * Wo + 1) & ~1;
+    constexpr int base2 = 2 * C::P * ps_e;                           // first row of the odd-y images
     uint32_t rvoff[RGW];                                         // byte offset of this lane's 16 bytes of chunk 0 (S3_OOB: no pixel there / beyond the batch)
 #pragma unroll
     for (int j = 0; j < RGW; j++) {
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
         const int xo = qq >= C::P * ps, q3 = xo ? qq - C::P * ps : qq;
         const int pl_ = q3 / ps, t = q3 - pl_ * ps, Y = t / Wo, xh = t - Y * Wo;
         const int T = pl_ * R + t;
-        const int gq = (pair0 + pl_) * HW + (2 * Y + yo) * p.W + 2 * xh + xo;
+        const int gq = (pair0 + pl_) * HW + (2 * Y + yo) * C::WI + 2 * xh + xo;
         const bool ok = q < base2 + 2 * C::P * ps_o && t < hh * Wo && gq < px_total;
         rvoff[j] = ok ? (uint32_t)((gq * CIN + (gphys ^ (2 * ((T >> 1) & 3))) * 8) * 2) : S3_OOB;
     }
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     for (int i = 0; i < TM; i++) {
         const int ml = i * 16 + r16;                             // row of the tile
         const bool ok = m0 + ml < m_end;
-        const int pl_ = ml / R, rem = ml - pl_ * R, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int pl_ = ml / R, rem = ml - pl_ * R, oy = rem / Wo, ox = rem - oy * Wo;
         const int t0 = oy * Wo + ox;
         qe_b[i] = (pl_ * ps_e + t0) * 128;
         qo_b[i] = (base2 + pl_ * ps_o + t0) * 128;
@@ -159,14 +163,14 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
         uint32_t bits = 0;
 #pragma unroll
         for (int k = 0; k < KS; k++) {
-            bits |= ((unsigned)(2 * oy - PAD + k) < (unsigned)p.H) ? (1u << k) : 0u;
-            bits |= ((unsigned)(2 * ox - PAD + k) < (unsigned)p.W) ? (1u << (8 + k)) : 0u;
+            bits |= ((unsigned)(2 * oy - PAD + k) < (unsigned)C::HI) ? (1u << k) : 0u;
+            bits |= ((unsigned)(2 * ox - PAD + k) < (unsigned)C::WI) ? (1u << (8 + k)) : 0u;
         }
         okb[i] = ok ? bits : 0u;
     }
     bf16x8 fa[2][TM][2];
     int a_byte[TM];                                              // byte offset (inside a plane of a buffer) of this lane's step-0 chunk of the current tap
-    const int xoff_e = C::P * ps_e * 128, xoff_o = C::P * ps_o * 128;      // odd-x image behind the even-x image of the same y parity
+    constexpr int xoff_e = C::P * ps_e * 128, xoff_o = C::P * ps_o * 128;      // odd-x image behind the even-x image of the same y parity
     auto tap_addr = [&](int t) {                                 // t wave-uniform; t >= NTAP (the padding tap of KSPLIT): the zero row
 #if defined(HNET_REGION_ABLATE) && HNET_REGION_ABLATE == 2
         if (t != t_lo_w) return;                                 // ablation (wrong results): one address computation per chunk

@@ -127,15 +127,15 @@ static hipError_t run_region(S3Params p, hipStream_t s) {
     hipLaunchKernelGGL((igemm_s3_region_kernel<C, OUT32>), grid, dim3(C::NT), C::LDS_BYTES, s, p);
     return hipGetLastError();
 }
-typedef RegionCfg<128, 5, 1, 280, false> RegionCfg12;     // block_1_2: one pair (14 x 20 x 128 in, 7 x 10 out) x 128 channels per workgroup: 256 workgroups at batch 256
-typedef RegionCfg<128, 3, 4, 288, true> RegionCfg13;      // block_1_3: four pairs (7 x 10 x 128 in, 4 x 5 out) x 64 channels, K halves over the wave halves
-typedef RegionCfg<256, 3, 4, 288, true> RegionCfgT;       // block_2_4 / 3_5 / 4_6: the same with 256 input channels
+typedef RegionCfg<128, 5, 1, 280, false, 14, 20> RegionCfg12;     // block_1_2: one pair (14 x 20 x 128 in, 7 x 10 out) x 128 channels per workgroup: 256 workgroups at batch 256
+typedef RegionCfg<128, 3, 4, 288, true, 7, 10> RegionCfg13;       // block_1_3: four pairs (7 x 10 x 128 in, 4 x 5 out) x 64 channels, K halves over the wave halves
+typedef RegionCfg<256, 3, 4, 288, true, 7, 10> RegionCfgT;        // block_2_4 / 3_5 / 4_6: the same with 256 input channels
 template <class C>
 static bool region_ok(const S3Params& p) {
     // (variant 25: the lean kernels, A/B; 21: at any batch, tests)
     // (a one-workgroup-per-CU kernel as well: from three quarters of a round on - batch 128, 128 workgroups of the 4 x 5 layers: 0.0318 against 0.0235 ms lean)
     const long wgs = (long)((p.M + C::P * p.Ho * p.Wo - 1) / (C::P * p.Ho * p.Wo)) * (p.N / C::BN);
-    return p.wfrag && p.tile != 20 && p.tile != 25 && (wgs >= 192 || p.tile == 21) && 2 * C::P * (((p.Ho * p.Wo + 1) & ~1) + (((p.H >> 1) * p.Wo + 1) & ~1)) <= C::RP && C::P * p.Ho * p.Wo <= 80 &&
+    return p.wfrag && p.H == C::HI && p.W == C::WI && p.Ho == C::HO && p.Wo == C::WO && p.tile != 20 && p.tile != 25 && (wgs >= 192 || p.tile == 21) && 2 * C::P * (((p.Ho * p.Wo + 1) & ~1) + (((p.H >> 1) * p.Wo + 1) & ~1)) <= C::RP && C::P * p.Ho * p.Wo <= 80 &&
            (p.M % (p.Ho * p.Wo)) == 0 && p.W == 2 * p.Wo && ((p.H + 1) >> 1) == p.Ho && p.N % C::BN == 0;
 }
 

@@ -43,19 +43,19 @@ int main() {
     S3Params p = {};
     p.A = A; p.Wp = W; p.bias = bias; p.out32 = out32; p.out16 = out16; p.k_split = 1;
     {   // block_1_2: 128 -> 128, 5x5 s2, 14x20 -> 7x10, batch 256
-        typedef RegionCfg<128, 5, 1, 280, false> C;
+        typedef RegionCfg<128, 5, 1, 280, false, 14, 20> C;
         p.H = 14; p.W = 20; p.Ho = 7; p.Wo = 10; p.M = 256 * 70; p.N = 128;
         p.a_plane = (size_t)256 * 14 * 20 * 128; p.o_plane = (size_t)p.M * 128;
         if (run<C>("block_1_2 70 x 128", igemm_s3_region_kernel<C, false>, p)) return 1;
     }
     {   // block_1_3: 128 -> 256, 3x3 s2, 7x10 -> 4x5
-        typedef RegionCfg<128, 3, 4, 288, true> C;
+        typedef RegionCfg<128, 3, 4, 288, true, 7, 10> C;
         p.H = 7; p.W = 10; p.Ho = 4; p.Wo = 5; p.M = 256 * 20; p.N = 256;
         p.a_plane = (size_t)256 * 7 * 10 * 128; p.o_plane = (size_t)p.M * 256;
         if (run<C>("block_1_3 80 x 64, K halves", igemm_s3_region_kernel<C, false>, p)) return 1;
     }
     {   // block_2_4 / 3_5 / 4_6: 256 -> 256, 3x3 s2, 7x10 -> 4x5, fp32 out
-        typedef RegionCfg<256, 3, 4, 288, true> C;
+        typedef RegionCfg<256, 3, 4, 288, true, 7, 10> C;
         p.H = 7; p.W = 10; p.Ho = 4; p.Wo = 5; p.M = 256 * 20; p.N = 256;
         p.a_plane = (size_t)256 * 7 * 10 * 256;
         if (run<C>("block_3_5 80 x 64, K halves", igemm_s3_region_kernel<C, true>, p)) return 1;
