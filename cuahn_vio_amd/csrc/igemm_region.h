@@ -105,7 +105,8 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
         const int q = (wave + NWAVE * j) * 8 + grow;             // LDS row; this lane fills its piece gphys
         const int yo = q >= base2, qq = yo ? q - base2 : q, ps = yo ? ps_o : ps_e, hh = yo ? hh_o : hh_e;
         const int xo = qq >= C::P * ps, q3 = xo ? qq - C::P * ps : qq;
-        const int pl_ = q3 / ps, t = q3 - pl_ * ps, Y = t / Wo, xh = t - Y * Wo;
+        const int pl_ = yo ? q3 / ps_o : q3 / ps_e;                  // (divisions by constants: two multiplications and a select instead of a run-time division)
+        const int t = q3 - pl_ * ps, Y = t / Wo, xh = t - Y * Wo;
         const int T = pl_ * R + t;
         const int gq = (pair0 + pl_) * HW + (2 * Y + yo) * C::WI + 2 * xh + xo;
         const bool ok = q < base2 + 2 * C::P * ps_o && t < hh * Wo && gq < px_total;
