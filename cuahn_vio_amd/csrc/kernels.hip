@@ -300,13 +300,26 @@ __device__ __forceinline__ void fc_dlt_block(const float* __restrict__ f, const 
     float acc[8];
 #pragma unroll
     for (int o = 0; o < 8; o++) acc[o] = 0.0f;
-#pragma unroll 10    // (90 loads in flight: two dependent round trips instead of five; the order of the FMAs is unchanged)
-    for (int i = 0; i < 20; i++) {
-        const int k = tid + 256 * i;
-        const float x = f[k];
+    // round 5: four consecutive elements per thread and step (k = 4 tid + 1024 i): 45 sixteen-byte loads, ALL in flight before the first FMA - one memory
+    // round trip (rounds 3 - 4: 180 four-byte loads in two batches of 90).  Another order of the 5120 products than before; the block-tail launch and the
+    // prep launches of the latency path share this function, so the two paths still agree bit for bit.
+    float4 xv[5], wv[5][8];
 #pragma unroll
-        for (int o = 0; o < 8; o++) acc[o] = fmaf(x, wfc[o * 5120 + k], acc[o]);
+    for (int i = 0; i < 5; i++) {
+        const int k = 4 * tid + 1024 * i;
+        xv[i] = *reinterpret_cast<const float4*>(f + k);
+#pragma unroll
+        for (int o = 0; o < 8; o++) wv[i][o] = *reinterpret_cast<const float4*>(wfc + o * 5120 + k);
     }
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            acc[o] = fmaf(xv[i].x, wv[i][o].x, acc[o]);
+            acc[o] = fmaf(xv[i].y, wv[i][o].y, acc[o]);
+            acc[o] = fmaf(xv[i].z, wv[i][o].z, acc[o]);
+            acc[o] = fmaf(xv[i].w, wv[i][o].w, acc[o]);
+        }
 #pragma unroll
     for (int o = 0; o < 8; o++) {
         float v = acc[o];
