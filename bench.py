@@ -430,7 +430,7 @@ def sub_run(base, ctx, **over):
     for k, v in over.items():
         setattr(a, k, v)
     r, ok = run(a, ctx, primary=False)
-    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms", "mc_sharding")
+    keep = ("value", "unit", "ms_per_step", "steps", "verified_pairs", "max_px_err", "max_cov_rel_err", "latency_batch1_ms", "mc_sharding", "stage_ms", "stage_kernels")
     out = {k: r[k] for k in keep if k in r}
     out["contexts"] = r["config"].get("contexts", 1)
     out["passed"] = bool(ok)
@@ -750,6 +750,12 @@ def run(args, ctx, primary):
                                                 "for batches of pairs, where the heads are 10 %% of a step, or for N >> 32"
                                                 % (n_mc, 1e3 * (t_all - t_8th), "n/a" if coll[0] is None else "%.0f" % (1e3 * coll[0]),
                                                    "n/a" if coll[0] is None else ("slower" if coll[0] > t_all - t_8th else "faster")))}
+    if rank == 0 and not primary and getattr(args, "stage_probe", False) and not mc_mode and not stream_mode:
+        # per-launch times of THIS configuration (the mid-size batches, where a fixed chain of dependent launches dominates)
+        eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(), cov.data_ptr(), 5)
+        ms_st = eng.profile_batch_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, 0, mean.data_ptr(), cov.data_ptr(), 20)
+        res["stage_ms"] = {n: round(float(m_), 4) for (n, _f), m_ in zip(eng.stages(), ms_st)}
+        res["stage_kernels"] = int(sum(eng.stage_kernels()))
     if rank == 0 and not primary and getattr(args, "latency_probe", False) and not mc_mode and not stream_mode:
         # BASELINE config 2 per arithmetic mode ("single frame pair ... bf16"): the batch-1 device latency of THIS configuration (graph replay, 200 after 20)
         e1 = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=1, device_id=local_rank, precision=prec)
@@ -866,7 +872,7 @@ def run(args, ctx, primary):
                 # steps - config 3's batches, config 5's per-GPU share of a streamed sequence - issues them round-robin on a few contexts / HIP streams so that one
                 # step's chain runs under the others' kernels.  `value` = that with TWO contexts (tools/pipeline_ctx_bench.py measured 1 / 2 / 3 / 4: three or four are
                 # faster still on a quiet box, 178 - 182 k pairs/s at 64 pairs, but not reliably so); the one-context figure of rounds 1 - 4 stays beside it.
-                one = sub_run(args, ctx, contexts=1, **kw)
+                one = sub_run(args, ctx, contexts=1, stage_probe=True, **kw)
                 # (a child process, like the streamed configuration: which hardware queues two streams get depends on every stream the process created before;
                 # after the other sub-runs the in-process figure was 125 k pairs/s where the same command alone gives 174 - 177 k)
                 pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "2", "--steps", "60", "--warmup", "10",
@@ -876,7 +882,7 @@ def run(args, ctx, primary):
                     pip = sub_run(args, ctx, contexts=2, steps=60, warmup=10, **kw)
                     pip["process"] = "in process (child run failed: " + err + ")"
                 pip["contexts"] = 2
-                pip["single_context"] = {k: one[k] for k in ("value", "ms_per_step", "steps", "max_px_err", "passed") if k in one}
+                pip["single_context"] = {k: one[k] for k in ("value", "ms_per_step", "steps", "max_px_err", "passed", "stage_ms", "stage_kernels") if k in one}
                 pip["passed"] = bool(pip["passed"] and one["passed"])
                 return pip
 
