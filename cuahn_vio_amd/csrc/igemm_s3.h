@@ -192,7 +192,15 @@ __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t (&pl)[3]
         pl[2] = cvt_pk(s0, s1);
     }
 }
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, v * 0.1f); }
+// max(a, b) as ONE v_max_f32 (round 5): fmaxf() is llvm.maxnum, which the backend brackets with a canonicalising v_max_f32 x, x per operand that comes out
+// of an accumulator (four extra vector instructions per LeakyReLU of a value pair in kernels that are issue bound).  Same result for every non-NaN input;
+// a NaN accumulator stays NaN-or-the-other-operand as v_max_f32 defines it - such a forward raises the overflow flag either way.
+__device__ __forceinline__ float vmax1(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lrelu(float v) { return vmax1(v, v * 0.1f); }
 // LeakyReLU of an accumulator of mode NP (bias already inside, at the accumulator's scale)
 template <int NP> __device__ __forceinline__ float act(float acc) { return lrelu(s3_descale<NP>(acc)); }
 // two accumulator values of mode NP (bias inside) -> LeakyReLU -> the planes of the pair; `ok` = false writes zeros.
@@ -204,8 +212,8 @@ __device__ __forceinline__ void act_split(float a0, float a1, uint32_t (&pl)[3],
     if constexpr (NP == 2) {
         f32x2_p u = {a0, a1};
         const f32x2_p t = u * 0.1f;
-        u[0] = fmaxf(u[0], t[0]);
-        u[1] = fmaxf(u[1], t[1]);
+        u[0] = vmax1(u[0], t[0]);
+        u[1] = vmax1(u[1], t[1]);
         if (!ok) u = f32x2_p{0.f, 0.f};
         const f32x2_p v = u * S3_F16_INV;
         pl[0] = cvt_pk_f16(v[0], v[1]);
