@@ -295,19 +295,21 @@ __global__ __launch_bounds__(512, 2) void igemm_s3_region_kernel(S3Params p) {
     for (int i = 0; i < TM; i++) {
         const int m = m0 + i * 16 + em;
         f32x4_m16 v = acc[i];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { const float x = v[e] + bv[e]; v[e] = x > 0.0f ? x : x * 0.1f; }
+        {   // (packed: bias add and the 0.1 multiple on value pairs, one v_max_f32 per value; x > 0 ? x : 0.1 x == max(x, 0.1 x) for every non-NaN x)
+            const s3p::f32x2_p x0 = s3p::f32x2_p{v[0], v[1]} + s3p::f32x2_p{bv[0], bv[1]}, x1 = s3p::f32x2_p{v[2], v[3]} + s3p::f32x2_p{bv[2], bv[3]};
+            const s3p::f32x2_p t0 = x0 * 0.1f, t1 = x1 * 0.1f;
+            v[0] = s3p::vmax1(x0[0], t0[0]); v[1] = s3p::vmax1(x0[1], t0[1]); v[2] = s3p::vmax1(x1[0], t1[0]); v[3] = s3p::vmax1(x1[1], t1[1]);
+        }
         if (m < m_end) {
             if constexpr (OUT32) {
                 *reinterpret_cast<f32x4_m16*>(p.out32 + (size_t)m * p.N + n) = v;
             } else {
-                uint16_t sp[2][4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) split2h(v[e], sp[0][e], sp[1][e]);
+                uint32_t pa[3], pb[3];
+                s3p::split_pair<2>(v[0], v[1], pa);
+                s3p::split_pair<2>(v[2], v[3], pb);
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++)
-                    *reinterpret_cast<uint2*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) =
-                        make_uint2((uint32_t)sp[pl][0] | ((uint32_t)sp[pl][1] << 16), (uint32_t)sp[pl][2] | ((uint32_t)sp[pl][3] << 16));
+                    *reinterpret_cast<uint2*>(p.out16 + pl * p.o_plane + (size_t)m * p.N + n) = make_uint2(pa[pl], pb[pl]);
             }
         }
     }
