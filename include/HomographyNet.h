@@ -140,6 +140,8 @@ public:
     double get_latest_inference_time() { return hnet_latest_time(ctx_); }
     // extension: wall time of the last network_inference call (ms), for the timing CSV of VioManager.cpp:304-311
     double last_host_ms() { hnet_timing t; hnet_last_timing(last_net_ ? last_net_ : ctx_, &t); return t.host_ms; }
+    // extension: the same, summed over every network_inference call so far (a frame's share = the difference across its IEKF iterations)
+    double total_host_ms() const { return host_ms_total_; }
 
     // HomographyNet.cpp:153-252
     void network_inference(Eigen::Matrix<double, 8, 1>& prior_4pt_offset_vec, int num_of_inference) {
@@ -153,6 +155,7 @@ public:
         last_net_ = net;
         const int rc = hnet_infer(net, use_prior_4pt_offset ? prior : nullptr, num_of_inference, mean, cov, net_err ? err_map_.data() : nullptr);
         if (rc != HNET_OK) { std::fprintf(stderr, "network_inference: %s (%s)\n", hnet_status_string(rc), hnet_last_error(net)); return; }
+        { hnet_timing t; if (hnet_last_timing(net, &t) == HNET_OK) host_ms_total_ += t.host_ms; }
         for (int i = 0; i < 8; i++) {
             _pred_mean(i, 0) = mean[i];
             for (int j = 0; j < 8; j++) _pred_Cov(i, j) = cov[i * 8 + j];   // symmetric: the reference's column-major Map of row-major data is the same matrix
@@ -208,6 +211,7 @@ private:
     hnet_ctx* ctx_ = nullptr;
     hnet_ctx* ctx_iter_ = nullptr;      // the IEKF's second model (num_of_iteration > 1)
     hnet_ctx* last_net_ = nullptr;      // the context of the last network_inference call
+    double host_ms_total_ = 0.0;        // wall time of all network_inference calls (total_host_ms)
     bool cv_imshow = false;
     bool use_prior_4pt_offset = false;
     bool show_phtometric_error = false;
