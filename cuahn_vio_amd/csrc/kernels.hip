@@ -199,23 +199,26 @@ __device__ inline WarpBox warp_stage_box(const PIX* __restrict__ img, const floa
     bx.rows = ry1 >= ry0 ? ry1 - ry0 + 1 : 0;
     if (bx.pitch * bx.rows > WT_CAP) bx.ok = false;
     if (!bx.ok) return bx;
-    // four rows per thread and pass: the loads of a pass are all issued before the first conversion (with one row per pass every thread
-    // walked its ~5 rows as five dependent global round trips - hidden by other workgroups at large batches, exposed at batch 1)
+    // eight rows per thread and pass (rows rl + 8 k of a 64-row band): the loads of a pass are all issued before the first conversion, and the usual box (32 tile
+    // rows at a scale near 1 -> ~40 rows) is ONE pass = one global round trip.  (Rounds 3 - 4: four rows per pass - every box of more than 32 rows paid a second,
+    // dependent round trip for its last rows; one row per pass before that.)  The kernel is bound by this chain of dependent round trips, not by its instruction
+    // count (profiles/r05_experiments_not_shipped.log item 11).
+    constexpr int RPP = 8;
     const int groups = bx.pitch >> 2;
     const int rl = (int)(threadIdx.x >> 5);
-    for (int rb = 0; rb < bx.rows; rb += 32) {
+    for (int rb = 0; rb < bx.rows; rb += 8 * RPP) {
         for (int c = (int)(threadIdx.x & 31); c < groups; c += 32) {
             const int x = bx.gx0 + 4 * c;                                // multiple of 4: the group is all in or all out
             const bool xin = x >= 0 && x < IMG_W;
-            typename PxRaw<PIX>::type raw[4];
+            typename PxRaw<PIX>::type raw[RPP];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < RPP; k++) {
                 const int r = rb + rl + 8 * k, y = ry0 + r;
                 raw[k] = PxRaw<PIX>::zero();
                 if (r < bx.rows && xin && y >= 0 && y < IMG_H) raw[k] = PxRaw<PIX>::load(img + y * IMG_W + x);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < RPP; k++) {
                 const int r = rb + rl + 8 * k;
                 if (r < bx.rows) *reinterpret_cast<float4*>(&reg[r * bx.pitch + 4 * c]) = PxRaw<PIX>::cvt(raw[k]);   // raw zero -> 0.0f
             }
