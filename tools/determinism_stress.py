@@ -27,4 +27,23 @@ for variant, n_mc, batch in (("full", 32, 1), ("prior3", 16, 1), ("full", 16, 2)
     bad += len(diff)
     print(f"determinism {variant} N={n_mc} batch={batch}: {reps} forwards, {len(diff)} differ from the first" + (f" (first at {diff[0]}, max |d| {np.abs(o[diff[0]] - o[0]).max():.3e})" if diff else ""), flush=True)
     e.close()
+# the bench shape on two contexts / streams at once (the default of bench.py): the steps of one context run under the other's kernels and must not notice
+big = int(os.environ.get("HNET_STRESS_BIG", "200"))
+if big:
+    batch, n_mc = 256, 32
+    ph, ch, prh, _ = synth.make_batch(77, 32)
+    tile = lambda a: torch.from_numpy(np.tile(a, (8,) + (1,) * (a.ndim - 1))).to(dev)
+    prev, curr = tile(ph), tile(ch)
+    engs = [HnetEngine(blob, variant="full", mc_samples=n_mc, dropout_p=0.05, mc_seed=3, max_batch=batch) for _ in range(2)]
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    outs = [torch.zeros(big, batch, 72, device=dev) for _ in range(2)]
+    for i in range(big):
+        for k in range(2):
+            engs[k].infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, None, batch, 5, outs[k][i].data_ptr(), None, streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    o = [x.cpu().numpy() for x in outs]
+    diff = [(k, i) for k in range(2) for i in range(big) if not np.array_equal(o[k][i], o[0][0])]
+    bad += len(diff)
+    print(f"determinism full N={n_mc} batch={batch}, two contexts interleaved: {2 * big} forwards, {len(diff)} differ from the first", flush=True)
+    for e in engs: e.close()
 sys.exit(1 if bad else 0)
