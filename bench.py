@@ -74,6 +74,11 @@ def parse(argv=None):
                     help="independent steps issued round-robin on NC contexts, each with its own HIP stream and buffers (--mode pairs, one GPU): the launch chain of "
                          "one step runs under the kernels of the others - what a server with independent batches does.  Default: 2 in --mode pairs (round 5: + 8 %% at "
                          "256 pairs per step, + 30 %% at 32 - 64; the one-context figure of rounds 1 - 4 is reported beside it as `single_context`), 1 in the other modes")
+    ap.add_argument("--distinct", type=int, default=None, metavar="D",
+                    help="distinct frame pairs in a step's batch (default: all of them; rounds 1 - 5 timed 32 distinct pairs tiled to the batch size)")
+    ap.add_argument("--honour-env", action="store_true",
+                    help="let HNET_S3_TILE / HNET_FUSE_* / HNET_GRAPH / HNET_WARP_EXACT / HNET_PRECISION of the environment select kernels (A/B experiments).  Default: "
+                         "the timed engines are built from this command line only and the variables are IGNORED; whatever HNET_* is set is listed in `env_overrides`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last step (profiling passes)")
@@ -109,6 +114,9 @@ def spawn_ranks(args):
     env["HNET_BENCH_SPAWNED"] = "1"
     proc = subprocess.Popen(cmd, env=env)
     return proc.wait()
+
+
+_INPUT_CACHE = {}      # (replay, rank, distinct pairs) -> host arrays: the default run builds several engines on the same inputs
 
 
 def time_budget_rate(one, budget_s, n_max=5000):
@@ -336,7 +344,10 @@ def dry_run(args, rank, world):
                           "warmup": args.warmup, "max_over_ranks_s": round(dt, 4), "value": None,
                           "resolved": {"config": args.config, "mode": args.mode, "batch_per_gpu": args.batch, "pairs_total": args.pairs_total,
                                        "mc": args.mc, "mc_per_gpu": args.mc // world if args.mode == "mc" else args.mc, "variant": args.variant,
-                                       "replay": args.replay, "gathers": world > 1 or args.force_collective},
+                                       "replay": args.replay, "gathers": world > 1 or args.force_collective,
+                                       # what run() would use: steps per all-gather of the packed outputs (small steps are grouped), contexts / HIP streams per GPU
+                                       "gather_group_steps": (max(1, 128 // args.batch) if args.mode != "mc" else None),
+                                       "contexts": int(args.contexts) if args.contexts else (2 if args.mode == "pairs" else 1)},
                           "gather_checked": gather_ok}), flush=True)
     if world > 1:
         dist.barrier()
@@ -449,9 +460,14 @@ def run(args, ctx, primary):
     import torch.distributed as dist
 
     from cuahn_vio_amd import dist as hdist
+    from cuahn_vio_amd import homography_net as _hn
     from cuahn_vio_amd import synth, weights
     from cuahn_vio_amd.homography_net import PIX_U8, HnetEngine
 
+    # the timed engines come from this command line only: HNET_S3_TILE / HNET_FUSE_* / HNET_GRAPH / HNET_WARP_EXACT / HNET_PRECISION of the environment are ignored
+    # (and listed in `env_overrides`) unless --honour-env
+    honour_env = bool(getattr(args, "honour_env", False))
+    _hn.IGNORE_ENV = not honour_env
     rank, local_rank, world, dev, shared, collective = (ctx[k] for k in ("rank", "local_rank", "world", "dev", "shared", "collective"))
     backend = None
     if collective:
@@ -464,11 +480,16 @@ def run(args, ctx, primary):
     if args.replay:
         from cuahn_vio_amd import replay as hreplay
         replay = hreplay.load_fixture(args.replay)
-    n_distinct = min(B, 32)
-    if replay is not None:      # consecutive frames of the trajectory; rank r starts further along it
-        prev_h, curr_h, prior_h = hreplay.render_pairs(replay, first=rank * n_distinct, count=n_distinct)
-    else:
-        prev_h, curr_h, prior_h, _ = synth.make_batch(1000 + rank * n_distinct, n_distinct)
+    # Round 6: every slot of the timed batch is a DISTINCT pair (36.7 MB of images at 256 pairs; rounds 1 - 5 tiled 32 distinct pairs, 4.6 MB, which stayed
+    # cache-resident for the four warp + pool launches).  --distinct 32 reproduces the old input; the default line carries that figure once (`tiled_32_distinct`).
+    n_distinct = B if not getattr(args, "distinct", None) else max(1, min(B, int(args.distinct)))
+    key = (args.replay, rank, n_distinct)
+    if key not in _INPUT_CACHE:
+        if replay is not None:      # consecutive frames of the trajectory; rank r starts further along it
+            _INPUT_CACHE[key] = hreplay.render_pairs(replay, first=rank * n_distinct, count=n_distinct)
+        else:
+            _INPUT_CACHE[key] = synth.make_batch(1000 + rank * n_distinct, n_distinct)[:3]
+    prev_h, curr_h, prior_h = _INPUT_CACHE[key]
     reps = (B + n_distinct - 1) // n_distinct
     prev = torch.from_numpy(np.tile(prev_h, (reps, 1, 1))[:B]).to(dev)
     curr = torch.from_numpy(np.tile(curr_h, (reps, 1, 1))[:B]).to(dev)
@@ -501,12 +522,9 @@ def run(args, ctx, primary):
     NC = max(1, int(NC))
     if NC > 1 and (mc_mode or args.mode == "stream"):
         raise SystemExit("--contexts: --mode pairs only")
-    if NC > 2 and collective:
-        raise SystemExit("--contexts > 2 with a collective: the overlapped gather has two output slabs")
-    if NC > 1 and og is not None and og.G > 1:      # grouped small steps share a slab across streams: one context there
-        if getattr(args, "contexts", None) is not None:
-            raise SystemExit("--contexts > 1 with grouped collectives (fewer than 128 pairs per GPU and step)")
-        NC = 1
+    # (round 6: with a collective the steps of one gathered slab may run on different contexts / streams - OverlappedGather.submit waits for every producer
+    # stream, acquire makes every stream wait for the slab's previous gather - so grouped small steps (config 5 at 8 GPUs: 32 pairs per GPU, four steps per
+    # all-gather) keep their two contexts)
     engs, streams, outs = [eng], [stream], [out]
     for _ in range(NC - 1):
         engs.append(HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec))
@@ -554,7 +572,7 @@ def run(args, ctx, primary):
         # 2.13 ms when the upload was at least issued before the launches; measured with HNET_STREAM_THREAD=0 / HNET_STREAM_ORDER=before).
         import queue
         import threading
-        use_thread = os.environ.get("HNET_STREAM_THREAD", "1") != "0"
+        use_thread = not (honour_env and os.environ.get("HNET_STREAM_THREAD", "1") == "0")
         up_q = queue.Queue()
         up_done = [threading.Event() for _ in range(2)]
         up_done[0].set()
@@ -581,8 +599,8 @@ def run(args, ctx, primary):
     def step(i):
         if stream_mode:
             k = i % 2
-            skip = os.environ.get("HNET_STREAM_SKIP", "")              # experiments: "copy" / "compute"
-            early = os.environ.get("HNET_STREAM_ORDER", "") == "before"     # experiment: hand the next upload to the DMA engine first
+            skip = os.environ.get("HNET_STREAM_SKIP", "") if honour_env else ""              # experiments: "copy" / "compute"
+            early = honour_env and os.environ.get("HNET_STREAM_ORDER", "") == "before"     # experiment: hand the next upload to the DMA engine first
             if use_thread:
                 up_done[k].wait()                                       # upload(i) has been enqueued (its event recorded) by the uploader
                 up_done[k].clear()
@@ -620,7 +638,7 @@ def run(args, ctx, primary):
         engs[i % NC].infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None,
                                                streams[i % NC].cuda_stream)
         if og is not None:
-            og.submit(i, streams[i % NC])
+            og.submit(i, streams[i % NC], all_streams=streams)
 
     def sync():
         if stream_mode and use_thread:
@@ -633,13 +651,13 @@ def run(args, ctx, primary):
     for i in range(args.warmup):
         step(i)
     if og is not None and args.warmup:
-        og.flush(args.warmup - 1, comp_stream if stream_mode else streams[(args.warmup - 1) % NC])
+        og.flush(args.warmup - 1, comp_stream if stream_mode else streams[(args.warmup - 1) % NC], all_streams=None if stream_mode else streams)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     if og is not None:      # a step count that is not a multiple of the group: the last, partly filled slab is gathered INSIDE the timed region
-        og.flush(args.warmup + args.steps - 1, comp_stream if stream_mode else streams[(args.warmup + args.steps - 1) % NC])
+        og.flush(args.warmup + args.steps - 1, comp_stream if stream_mode else streams[(args.warmup + args.steps - 1) % NC], all_streams=None if stream_mode else streams)
     sync()
     dt = time.perf_counter() - t0
     if collective:
@@ -675,7 +693,7 @@ def run(args, ctx, primary):
         "scaling": "strong" if (mc_mode or args.pairs_total is not None) else "weak", "vs_baseline": None,
         "dtype": dtype_label, "data": "synthetic",
         "config": {"workload": f"{args.variant} HomographyNet forward, 320x224 u8 frame pairs, MC-dropout N={n_mc} p=0.05, "
-                               f"{B} pairs/GPU/step, inputs+outputs resident in HBM",
+                               f"{B} pairs/GPU/step ({n_distinct} distinct), inputs+outputs resident in HBM",
                    "batch_per_gpu": B, "mc_samples": n_mc, "variant": args.variant, "precision": args.precision, "contexts": NC,
                    "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
                                    if mc_mode else
@@ -692,7 +710,8 @@ def run(args, ctx, primary):
         res["config"]["sequence"] = replay["name"]
     if stream_mode:
         res["config"]["workload"] += "; STREAMED: inputs start in pinned host memory, H2D overlapped with compute, outputs back to host"
-        res["config"]["parallelism"] = "host -> device streaming, double-buffered (PCIe-inclusive; not the headline metric)"
+        res["config"]["parallelism"] = ("host -> device streaming, double-buffered (PCIe-inclusive; not the headline metric); ONE compute context per GPU (the copy stream "
+                                        "holds the second hardware queue)" + (f"; RCCL all_gather of the packed outputs every {og.G} step(s) on a side stream" if og is not None else ""))
 
     # ---- self check, outside the timed region: pairs of the LAST step against the CPU oracle (every rank checks its own shard)
     ok = True
@@ -707,7 +726,7 @@ def run(args, ctx, primary):
             fin = out_of_step(last)                                       # the packed [B, 72] record of the last executed step
             mean_np, cov_np = fin[:, :8].cpu().numpy(), fin[:, 8:].cpu().numpy()
             if og is not None:                                            # ... and what the side-stream gather delivered for it: this rank's rows, bit for bit
-                og.submit(last, streams[last % NC], flush=True)          # (a partly filled group of small steps)
+                og.submit(last, streams[last % NC], flush=True, all_streams=streams)          # (a partly filled group of small steps)
                 g = og.result(last)
                 if not torch.equal(g[rank], fin):
                     raise SystemExit("bench.py: the gathered outputs differ from the local ones")
@@ -745,6 +764,7 @@ def run(args, ctx, primary):
             coll = committed_config4_cost()
             res["mc_sharding"] = {"forward_all_samples_ms": round(t_all, 4), "forward_one_eighth_of_the_samples_ms": round(t_8th, 4),
                                   "saved_per_rank_ms": round(t_all - t_8th, 4), "allgather_plus_finish_ms": coll[0], "allgather_source": coll[1],
+                                  "allgather_measured_in_this_run": False,      # a committed C++ measurement (another box, possibly another build): context for the statement, not a live figure
                                   "statement": ("one pair per step: sharding the N = %d MC samples over 8 GPUs removes %.0f us of heads per rank and adds the collective + finish "
                                                 "(%s us on a 1-rank RCCL communicator, more over xGMI): for ONE pair the 8-GPU form is %s than one GPU - the sharding pays "
                                                 "for batches of pairs, where the heads are 10 %% of a step, or for N >> 32"
@@ -789,14 +809,18 @@ def run(args, ctx, primary):
         if ksub == "block4_fused_kernel" and np_arg:
             ksub = "block4_fused_kernel<%d, 256, %d," % (8 if np_arg == 2 else 7, np_arg)
         traffic, traffic_src = committed_traffic(ksub, B) if np_arg else (None, None)
-        res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
+        ach_alg = alg / (ms[k] * 1e-3) / 1e12
+        # achieved = ALGORITHMIC flops per launch / the kernel's duration.  `frac` is that against the dense peak of the instruction issued;
+        # `frac_issued` counts every MFMA the fp32-grade operand split issues per multiply-accumulate (3 in the default mode) - the matrix pipe's occupancy
+        res["roofline"] = {"bound": "mfma", "achieved": round(ach_alg, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach_alg / pk, 4),
+                           "achieved_issued": round(ach, 2), "frac_issued": round(ach / pk, 4),
                            "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": stages[k][0], "kernel_ms": round(ms[k], 4),
                            "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
                            "mfma_per_mac": mfma_per_mac if pk == peak_tf else 1,
                            "fp32_equivalent_tflops": round(alg / (ms[k] * 1e-3) / 1e12, 2),
-                           "note": ("three fp16 MFMAs per multiply-accumulate (two fp16 planes per value): achieved / peak counts the MFMAs issued; counting "
-                                    "useful FLOP only (fp32_equivalent_tflops) the fraction is a third of frac"
+                           "note": ("achieved / frac count ALGORITHMIC flops (2 x MACs); the default mode issues three fp16 MFMAs per multiply-accumulate "
+                                    "(two fp16 planes per value): achieved_issued / frac_issued count those"
                                     if args.precision == "f16x2" else None),
                            "peak_of": ("dense fp16 MFMA (v_mfma_f32_16x16x32_f16; same rate as bf16)" if args.precision == "f16x2" else
                                        "dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)") if pk == PEAK_BF16_MFMA_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
@@ -861,6 +885,8 @@ def run(args, ctx, primary):
             # chip where a stand-alone run gives 61 k)
             if NC > 1:      # the figure comparable with rounds 1 - 4: the same steps on ONE context / stream
                 res["single_context"] = sub_run(args, ctx, contexts=1, no_extras=True)
+            if n_distinct > 32:   # rounds 1 - 5 timed 32 distinct pairs tiled to the batch (images cache-resident for the warp + pool launches): kept beside the headline once
+                res["tiled_32_distinct"] = sub_run(args, ctx, distinct=32, no_extras=True)
             res["modes"] = {}
             for pm in ("bf16x3", "fp32", "bf16"):
                 if pm != args.precision:
@@ -909,6 +935,36 @@ def run(args, ctx, primary):
         if par is not None:
             res["parity"] = par
     if rank == 0 and primary:
+        # The metric is "preds/sec + p50 per-pair latency": the latency figures as TOP-LEVEL scalars, and the line's last kilobyte a compact `summary` that repeats what a
+        # reader of a truncated record needs (the driver keeps the END of stdout, and of nested objects only the names).
+        lat = res.get("latency_batch1_ms") or {}
+        rld = lat.get("reference_launch_default") or {}
+        sc = res.get("single_context") or {}
+        res["latency_p50_ms"] = lat.get("p50")
+        res["latency_p95_ms"] = lat.get("p95")
+        res["latency_floor_us"] = lat.get("floor_us")
+        res["latency_end_to_end_p50_ms"] = lat.get("end_to_end_p50")
+        res["latency_launch_default_p50_ms"] = rld.get("p50")
+        res["latency_launch_default_end_to_end_p50_ms"] = rld.get("end_to_end_p50")
+        res["single_context_value"] = sc.get("value", res["value"] if NC == 1 else None)
+        res["env_overrides"] = {"seen": _hn.env_overrides(), "honoured": honour_env}
+        rf = res.get("roofline") or {}
+        cfgs = res.get("configs") or {}
+        md = res.get("modes") or {}
+        res["summary"] = {
+            "value_pairs_per_s": res["value"], "contexts": NC, "single_context_value": res["single_context_value"], "ms_per_step": res["ms_per_step"],
+            "distinct_pairs_per_step": n_distinct, "tiled_32_distinct_value": (res.get("tiled_32_distinct") or {}).get("value"),
+            "latency_p50_ms": res["latency_p50_ms"], "latency_p95_ms": res["latency_p95_ms"], "latency_floor_us": res["latency_floor_us"],
+            "latency_end_to_end_p50_ms": res["latency_end_to_end_p50_ms"], "latency_launch_default_p50_ms": res["latency_launch_default_p50_ms"],
+            "latency_launches": lat.get("launches"), "latency_kernels": lat.get("kernels"),
+            "latency_by_mode_p50_ms": {k: (v.get("latency_batch1_ms") or {}).get("p50") for k, v in md.items()},
+            "value_by_mode": {k: v.get("value") for k, v in md.items()},
+            "configs_value": {k: (v or {}).get("value") for k, v in cfgs.items()},
+            "configs_single_context": {k: ((v or {}).get("single_context") or {}).get("value") for k, v in cfgs.items() if (v or {}).get("single_context")},
+            "roofline_kernel": rf.get("kernel"), "roofline_kernel_ms": rf.get("kernel_ms"), "roofline_frac_algorithmic": rf.get("frac"),
+            "roofline_frac_issued": rf.get("frac_issued"), "cpu_baseline_pairs_per_s": (res.get("cpu_baseline") or {}).get("value"),
+            "max_px_err_vs_oracle": res.get("max_px_err"), "verify_passed": (res.get("verify") or {}).get("passed"),
+            "env_overrides": res["env_overrides"]["seen"], "env_honoured": honour_env}
         print(json.dumps(res), flush=True)
     if stream_mode and use_thread:
         up_q.put(None)

@@ -100,14 +100,14 @@ struct hnet_ctx {
     float* fc_b[3] = {};
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     // activations (device), sized for cfg.max_batch
-    // split-bf16 mode (HNET_PREC_BF16X3): activations of the layers feeding a conv are three bf16 planes
+    // matrix-core modes (every precision but HNET_PREC_FP32): activations of the layers feeding a conv are 16-bit planes (s3_format.h)
     bool s3 = false;
-    uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] bf16 for the Cin >= 8 layers
+    uint16_t* conv_w16[20] = {};       // [3][Cout][Kp] 16-bit weight planes of the Cin >= 8 layers (fp16 in HNET_PREC_F16X2, bf16 in the bf16 modes; s3_format.h)
     uint16_t* conv_wfrag[20] = {};     // fp16-plane mode, igemm_region.h layers (block_1_2, block_1_3, block_2_4 / 3_5 / 4_6): the weights as MFMA fragments in consumption order
-    uint16_t* act16[20] = {};          // [3][max_batch][Ho][Wo][Cout] bf16
-    bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), split-bf16 mode only
+    uint16_t* act16[20] = {};          // [planes][max_batch][Ho][Wo][Cout] 16-bit activation planes: two fp16 planes in the default mode, three / one bf16 planes in HNET_PREC_BF16X3 / _BF16
+    bool fuse_b4 = false;              // block_4_0 + block_4_1 in one kernel (conv_b4_fused.h), every matrix-core mode
     int b4_flags = 0;                  // bit 0: the fused kernel walks its tiles from the end of the batch (hnet_op_block4_fused `reverse`, tests)
-    uint32_t* x16_b4 = nullptr;        // block-4 input as padded bf16 planes [3][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
+    uint32_t* x16_b4 = nullptr;        // block-4 input as padded 16-bit planes (fp16 / bf16 by mode) [planes][max_batch][B4_HP][B4_WP] dwords (DMA-staged fused kernel, kernels.h)
     size_t x16_plane = 0;              // dwords per plane
     int n_planes = 3;                  // 16-bit planes the matrix-core layers read and write = their arithmetic mode: 3 = split-bf16 (fp32-grade), 1 = plain bf16 (HNET_PREC_BF16), 2 = fp16 planes (HNET_PREC_F16X2, fp32-grade)
     uint16_t* patch_frag[20] = {};     // conv_patch_s2.h weight fragments of block_3_1 / block_4_2: [2][NSTEP][3][64] x 16 B
@@ -133,8 +133,8 @@ struct hnet_ctx {
     bool first_s2 = true;              // HNET_FIRST_S2=0: the round-1 fp32-MFMA implicit GEMM for these two layers
     uint16_t* b40_frag = nullptr;      // block_4_0 weights as 16x16x32 B-fragments of the pixel-pair GEMM [4][3][64] x 16 B, + slot [4]: kernel row 6 as 16x16x16 fragments
     uint16_t* b41_frag = nullptr;      // block_4_1 weights as 16x16x32 B-fragments [7][3][64] x 16 B
-    uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] bf16
-    uint16_t* feat16 = nullptr;        // [3][max_batch][5120] bf16: feat * 1/(1-p), split
+    uint16_t* w1_16 = nullptr;         // heads Linear(5120,256) x2: [3][512][5120] 16-bit weight planes (fp16 / bf16 by mode)
+    uint16_t* feat16 = nullptr;        // [planes][max_batch][5120] 16-bit planes: feat * 1/(1-p), split
     uint8_t* head_mask = nullptr;      // [max_batch][n_local][2][640] keep bits
     size_t act_count[20] = {};         // elements per pair of layer l's output
     float* x_in[4] = {};
@@ -527,7 +527,11 @@ int forward(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     if (a.batch > g.max_batch) return fail(c, HNET_ERR_CAPACITY, "batch exceeds max_batch");
     if (g.use_prior && !a.prior) return fail(c, HNET_ERR_INVALID_ARG, "context uses a prior but none was given");
     c->last_batch = a.batch;
-    return forward_chunk(c, a, s);
+    const int rc = forward_chunk(c, a, s);
+    // a forward that stopped part-way may leave split-K tile counters of the latency path non-zero (a launch that failed after its predecessors ran):
+    // they are zeroed again behind whatever was enqueued, so the next forward starts from the state it assumes (kernels.h SPLITK_TICKETS)
+    if (rc != HNET_OK && c->ws) (void)hipMemsetAsync(c->ws + c->ws_floats, 0, SPLITK_TICKETS * sizeof(uint32_t), s);
+    return rc;
 }
 
 // Captures `body` (work enqueued on c->stream) into an executable graph.  Returns nullptr when capture is not possible;
@@ -839,11 +843,25 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         const Tensor* v = b.find("hnet.variant", {8});
         const bool rec = v && v->data[0] == 1.0f;
         if (v && !rec) return HNET_ERR_BAD_WEIGHTS;                       // a record version this library does not know
-        if (g.use_prior == HNET_FROM_FILE) g.use_prior = rec ? (int)v->data[1] : 1;
-        if (g.blocks_to_run == HNET_FROM_FILE) g.blocks_to_run = rec ? (int)v->data[2] : 3;
-        if (g.mc_samples == HNET_FROM_FILE) g.mc_samples = rec ? (int)v->data[3] : 16;
-        if (g.dropout_p < 0.f) g.dropout_p = rec ? v->data[4] : 0.05f;
-        if (g.emit_error_map == HNET_FROM_FILE) g.emit_error_map = rec ? (int)v->data[5] : 0;
+        // the record's numbers come from a file: finite, integral and in range BEFORE any float -> int conversion (a NaN or 1e30 there is undefined behaviour)
+        int r_prior = 1, r_blocks = 3, r_mc = 16, r_err = 0;
+        float r_p = 0.05f;
+        if (rec) {
+            auto rec_int = [&](int i, int lo, int hi, int& out) {
+                const float f = v->data[i];
+                if (!(f >= (float)lo && f <= (float)hi) || f != std::floor(f)) return false;
+                out = (int)f;
+                return true;
+            };
+            r_p = v->data[4];
+            if (!rec_int(1, 0, 1, r_prior) || !rec_int(2, 1, 3, r_blocks) || !rec_int(3, 1, 256, r_mc) || !rec_int(5, 0, 1, r_err) || !(r_p >= 0.f && r_p < 1.f))
+                return HNET_ERR_BAD_WEIGHTS;
+        }
+        if (g.use_prior == HNET_FROM_FILE) g.use_prior = r_prior;
+        if (g.blocks_to_run == HNET_FROM_FILE) g.blocks_to_run = r_blocks;
+        if (g.mc_samples == HNET_FROM_FILE) g.mc_samples = r_mc;
+        if (g.dropout_p < 0.f) g.dropout_p = r_p;
+        if (g.emit_error_map == HNET_FROM_FILE) g.emit_error_map = r_err;
     }
     if (g.mc_samples < 1 || g.mc_samples > 256 || !(g.dropout_p >= 0.f) || g.dropout_p >= 1.f || (g.use_prior != 0 && g.use_prior != 1) ||
         (g.emit_error_map != 0 && g.emit_error_map != 1))
@@ -1200,6 +1218,7 @@ static bool all_finite(const float* v, size_t n) {
 static int demote_to_bf16x3(hnet_ctx* c) {
     if (c->n_planes != 2 || c->blob_copy.empty()) return HNET_ERR_UNSUPPORTED;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ws) HIPCHK(c, hipMemset(c->ws + c->ws_floats, 0, SPLITK_TICKETS * sizeof(uint32_t)));      // the overflowed forward may have ended anywhere: counters back to zero
     Blob b;
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;

@@ -764,7 +764,10 @@ template <bool OUT32, int NP>
 __device__ __forceinline__ void s3_splitk_last_arriver(const S3Params& p, int m0, int n0, int bm, int bn, uint32_t* lds_word) {
     typedef float f32x4_e __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's partial stores have been acknowledged by memory
+    // vmcnt(0): this wave's partial stores have been acknowledged by memory.  Inline asm with a memory clobber, not __builtin_amdgcn_s_waitcnt: the builtin is
+    // IntrNoMem - nothing at IR level orders it against the buffer-store intrinsics, and a provably empty scoreboard lets later passes drop waits
+    // (MI355X_MICROARCH.md, compiler hazard); the asm statement is opaque to both.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t* ticket = p.tickets + (blockIdx.x + blockIdx.y * gridDim.x);
     if (tid == 0) *lds_word = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -86,12 +86,13 @@ class OverlappedGather:
         self.gathered = [torch.zeros(self.world * self.G * batch, 72, device=device) for _ in range(2)]
         self.pending = [False, False]
         self.submitted_upto = [-1, -1]      # last step whose slab submission covers it (result() checks)
+        self.waited = [set(), set()]        # streams that already wait for the slab's pending gather
         if self.cuda:
             # its own priority level: the HIP runtime multiplexes the streams of ONE priority over its hardware queues, and a side stream that lands on the
             # compute stream's queue serialises the gather between two forwards instead of running it under the next one (bench.py, stream mode, saw
             # the same with its copy stream); queues of different priority are never shared.  (The process group's internal RCCL stream: TORCH_NCCL_HIGH_PRIORITY=1)
             self.side = torch.cuda.Stream(device, priority=-1)
-            self.ev_done = [torch.cuda.Event() for _ in range(2)]        # the forwards of the slab's steps have finished (recorded on the compute stream)
+            self.ev_done = {}                                            # (slab, stream) -> the forwards of the slab's steps on that stream have finished
             self.ev_gathered = [torch.cuda.Event() for _ in range(2)]    # its gather has finished (recorded on the side stream)
 
     def _slab(self, i):
@@ -102,13 +103,18 @@ class OverlappedGather:
         return self.out[self._slab(i)][j * self.B:(j + 1) * self.B]
 
     def acquire(self, i, compute_stream=None):
-        """before the forward of step i writes its part of a slab"""
+        """before the forward of step i writes its part of a slab: the stream that runs it waits for the gather that last read that slab (once per stream and
+        slab generation - with several contexts / streams the steps of one slab run on different streams, round 6)"""
         k = self._slab(i)
-        if self.cuda and self.pending[k] and i % self.G == 0:
-            (compute_stream or torch.cuda.current_stream()).wait_event(self.ev_gathered[k])
+        if self.cuda and self.pending[k]:
+            cs = compute_stream or torch.cuda.current_stream()
+            if cs.cuda_stream not in self.waited[k]:
+                cs.wait_event(self.ev_gathered[k])
+                self.waited[k].add(cs.cuda_stream)
 
-    def submit(self, i, compute_stream=None, flush=False):
-        """after the forward of step i has been enqueued on the compute stream; flush = gather a partly filled slab (end of a run)"""
+    def submit(self, i, compute_stream=None, flush=False, all_streams=None):
+        """after the forward of step i has been enqueued on the compute stream; flush = gather a partly filled slab (end of a run).
+        all_streams: every stream that ran a step of this slab (several contexts round-robin, group_steps > 1): the gather waits for all of them"""
         if i % self.G != self.G - 1 and not flush:
             return
         k = self._slab(i)
@@ -118,18 +124,27 @@ class OverlappedGather:
             self.pending[k] = True
             return
         cs = compute_stream or torch.cuda.current_stream()
-        self.ev_done[k].record(cs)
+        producers = [cs] + [s_ for s_ in (all_streams or []) if s_.cuda_stream != cs.cuda_stream]
+        if self.G == 1:
+            producers = [cs]                       # one step per slab: one producer
+        evs = []
+        for s_ in producers:
+            ev = self.ev_done.setdefault((k, s_.cuda_stream), torch.cuda.Event())
+            ev.record(s_)
+            evs.append(ev)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_done[k])
+            for ev in evs:
+                self.side.wait_event(ev)
             _all_gather(self.gathered[k], self.out[k], self.group)
             self.ev_gathered[k].record(self.side)
         self.pending[k] = True
+        self.waited[k] = set()
 
-    def flush(self, last_step, compute_stream=None):
+    def flush(self, last_step, compute_stream=None, all_streams=None):
         """gather the partly filled slab that holds step `last_step` (a run whose step count is not a multiple of group_steps: call before the closing
         synchronize of a timed region, so that every step's collective lies inside it)"""
         if last_step % self.G != self.G - 1:
-            self.submit(last_step, compute_stream, flush=True)
+            self.submit(last_step, compute_stream, flush=True, all_streams=all_streams)
 
     def result(self, i):
         """[world, B, 72]: step i's records of every rank.  The slab of step i must have been submitted (submit of its last step, or flush) AFTER
@@ -137,6 +152,8 @@ class OverlappedGather:
         k, j = self._slab(i), i % self.G
         if self.submitted_upto[k] < i:
             raise RuntimeError(f"OverlappedGather.result({i}): the slab of that step has not been submitted since the step was written")
+        if self.submitted_upto[k] // self.G != i // self.G:      # the two slabs alternate: a later group of steps has re-used this one
+            raise RuntimeError(f"OverlappedGather.result({i}): the slab of that step has been overwritten by steps {self.submitted_upto[k] // self.G * self.G}..{self.submitted_upto[k]}")
         if self.cuda and self.pending[k]:
             self.ev_gathered[k].synchronize()
         return self.gathered[k].view(self.world, self.G, self.B, 72)[:, j]

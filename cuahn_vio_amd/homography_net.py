@@ -26,10 +26,21 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+IGNORE_ENV = False      # bench.py sets this (unless --honour-env): engines are then built from explicit arguments only, a stray HNET_* variable cannot change the timed kernels
+
+
+def env_overrides():
+    """the HNET_* variables of this process that kernel_selection_from_env / HnetEngine would map onto hnet_config (what bench.py lists in `env_overrides`)"""
+    names = ("HNET_S3_TILE", "HNET_FUSE_SMALL", "HNET_FUSE_B3", "HNET_FUSE_B42", "HNET_GRAPH", "HNET_WARP_EXACT", "HNET_PRECISION")
+    return {n: os.environ[n] for n in names if n in os.environ}
+
+
 def kernel_selection_from_env():
     """hnet_config.warp_exact / .graph / .variant from this process's environment.  The C library reads no environment variable (round 4);
     the test suite and tools/ab_bench.py keep selecting reference kernels with HNET_WARP_EXACT, HNET_GRAPH (0 eager, 1 replay also in the timing
     entry point), HNET_S3_TILE (13 / 20 / 21 / 22 / 25 / 30: include/hnet.h HNET_VARIANT_*), HNET_FUSE_SMALL=0, HNET_FUSE_B3=0, HNET_FUSE_B42=0 - mapped here."""
+    if IGNORE_ENV:
+        return 0, 0, 0
     env = os.environ.get
     variant = int(env("HNET_S3_TILE", "0")) & 0xff
     if env("HNET_FUSE_SMALL", "1") == "0":
@@ -56,7 +67,7 @@ class HnetEngine:
         cfg = Config()
         L.hnet_default_config(C.byref(cfg))
         if precision is None:   # default: the library's (fp16 planes, fp32-grade); HNET_PRECISION=2 / 0 select split-bf16 / the exact-fp32 MFMA path
-            precision = int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
+            precision = cfg.precision if IGNORE_ENV else int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
         cfg.device_id = device_id
         cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant] if variant is not None else (FROM_FILE, FROM_FILE)
         cfg.mc_samples = FROM_FILE if mc_samples is None else mc_samples

@@ -267,6 +267,35 @@ def convert_checkpoint(pth_path: str, blob_path: str, variant=None) -> None:
     save_blob(blob_path, st, variant)
 
 
+F16X2_WEIGHT_BOUND = 15.99      # hnet_create (csrc/hnet_capi.hip): HNET_PREC_F16X2 carries 4096 w in fp16 planes, every matrix-core weight must stay below 16 (csrc/s3_format.h)
+
+
+def weight_range_report(state):
+    """max |w| of every layer whose contraction runs on the matrix cores (the 20 convs and the heads' Linear(5120, 256) x 2 - exactly the tensors hnet_create
+    scans) against the fp16-plane bound: [(tensor name, max |w|, within the bound)], and the arithmetic mode hnet_create selects for this file when asked for
+    the default HNET_PREC_F16X2 (a weight beyond the bound -> HNET_PREC_BF16X3: same results, twice the matrix-core work; never an error).  Activations
+    (|a| < 32768) cannot be checked from the file: an overflow there shows as a non-finite output, which hnet_infer repairs by demoting the context and
+    the device entry points flag (include/hnet.h hnet_overflow_flag)."""
+    rows = []
+    for name, _cin, _cout, _k, _s in CONV_LAYERS:
+        key = ("model_last_block_list.0." if name.startswith("block_4") else "model_part1.") + name + ".0.weight"
+        m = float(np.abs(np.asarray(state[key], dtype=np.float32)).max())
+        rows.append((key, m, m < F16X2_WEIGHT_BOUND))
+    for head in ("fc_block_4_mean", "fc_block_4_uncertainty"):
+        key = "model_last_block_list.0." + head + ".1.weight"
+        m = float(np.abs(np.asarray(state[key], dtype=np.float32)).max())
+        rows.append((key, m, m < F16X2_WEIGHT_BOUND))
+    mode = "HNET_PREC_F16X2 (two fp16 planes, three MFMAs per product)" if all(ok for _n, _m, ok in rows) else \
+        "HNET_PREC_BF16X3 (a weight is beyond the fp16-plane bound: three bf16 planes, six MFMAs per product; same results)"
+    return rows, mode
+
+
+def _load_any(path: str):
+    with open(path, "rb") as f:
+        head = f.read(8)
+    return load_blob(path) if head == MAGIC else load_checkpoint(path)
+
+
 if __name__ == "__main__":
     # the counterpart of the reference's trace_model.py: one output file per variant it traces (:36-46)
     #   python -m cuahn_vio_amd.weights ck.pth.tar traced_model_3_blocks_using_prior.hnw --variant prior3 --mc 16 --dropout 0.05
@@ -274,12 +303,23 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(prog="python -m cuahn_vio_amd.weights", description="reference checkpoint (.pth.tar) -> HNETW001 blob")
     ap.add_argument("checkpoint")
-    ap.add_argument("out")
+    ap.add_argument("out", nargs="?", default=None)
+    ap.add_argument("--check", action="store_true",
+                    help="no conversion: print max |w| of every matrix-core layer of CHECKPOINT (.pth.tar or HNETW001) against the fp16-plane bound and the "
+                         "arithmetic mode hnet_create will select - what the first user of the real checkpoint learns before the first frame")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default=None, help="bake the model variant into the blob (default: weights only)")
     ap.add_argument("--mc", type=int, default=16, help="MC-dropout samples N (MC_dropout_num, model_to_trace.py:202)")
     ap.add_argument("--dropout", type=float, default=0.05, help="dropout rate (trace_model.py:16)")
     ap.add_argument("--error-map", action="store_true", help='the "_showError" twin (trace_model.py:40,46)')
     a = ap.parse_args()
+    if a.check:
+        rows, mode = weight_range_report(_load_any(a.checkpoint))
+        for key, m, ok in rows:
+            print(f"{key:62s} max |w| = {m:10.6f}  {'ok' if ok else 'BEYOND the fp16-plane bound (< %.2f)' % F16X2_WEIGHT_BOUND}")
+        print(f"largest: {max(m for _k, m, _o in rows):.6f}; bound {F16X2_WEIGHT_BOUND}; hnet_create (default precision) will run: {mode}")
+        raise SystemExit(0)
+    if a.out is None:
+        ap.error("OUT is required unless --check")
     var = None if a.variant is None else dict(variant=a.variant, mc_samples=a.mc, dropout_p=a.dropout, emit_error_map=a.error_map)
     convert_checkpoint(a.checkpoint, a.out, var)
     print(f"wrote {a.out}" + ("" if var is None else f" ({var})"))

@@ -16,15 +16,19 @@
 //   * `network_model_path` names an HNETW001 weight blob (cuahn_vio_amd/weights.py) instead of a TorchScript
 //     .pt.  As in the reference, "_showError" in the file name selects the variant that also emits the
 //     photometric error map (HomographyNet.cpp:96-100).
-//   * what the reference freezes into the traced file is read from optional environment variables:
-//     HNET_BLOCKS_TO_RUN (1..3, default 3 = "3_blocks_using_prior"), HNET_MC_SAMPLES (default 16),
-//     HNET_DROPOUT_P (default 0.05), HNET_MC_SEED (default 0), HNET_DEVICE (default 0), HNET_PRECISION (hnet.h).
+//   * what the reference freezes into the traced file (blocks_to_run, MC-dropout N and rate, the error-map twin: trace_model.py:16,36-46) is read from
+//     the HNETW001 file's `hnet.variant` record (python -m cuahn_vio_amd.weights --variant ...); a record-less file gives the reference's launch values
+//     (3 blocks with prior, N 16, p 0.05).  HNET_BLOCKS_TO_RUN / HNET_MC_SAMPLES / HNET_DROPOUT_P / HNET_ITER_BLOCKS_TO_RUN are explicit OVERRIDES for
+//     experiments; HNET_MC_SEED (default 0), HNET_DEVICE (default 0) and HNET_PRECISION (hnet.h) are run-time settings, not properties of the file.
+//     The constructor's `use_prior` must agree with the record (a `full` file opened with use_prior = true throws, like the Python mirror).
 //   * the IEKF "iterative" model (HomographyNet.cpp:20-24,104-124): with num_of_iteration > 1 a SECOND context is created from
 //     `network_model_iterative_path` (its own "_showError" sniff - as in the reference the flag of the file loaded last wins, :117-121 -
 //     and its own HNET_ITER_BLOCKS_TO_RUN, default HNET_BLOCKS_TO_RUN), warmed up like the first (:49-56), attached to the main
 //     context's frames (hnet_attach_images) and used for every call with iteration > 0 (:209-219).
-//   * a failed load throws std::runtime_error instead of printing and crashing at the first forward
-//     (HomographyNet.cpp:91-93).
+//   * a failed load prints the reference's "error loading the model !!!" to stderr and throws std::runtime_error out of the constructor.  The reference
+//     prints and carries on (HomographyNet.cpp:91-93) - into its own warm-up forward on an empty module (:28-45), which throws c10::Error out of the same
+//     constructor: either way `new pytorch::HomographyNet(...)` at VioManager.cpp:107 (no try block there) ends the node before the first frame; here with
+//     the status text of the C ABI in what().  INTEGRATION.md section 5.
 //
 // OpenCV / Eigen types appear only in this header; the shared library has none of them in its ABI.
 #ifndef PYTORCH_HNet_H
@@ -66,7 +70,8 @@ public:
         hnet_config cfg;
         hnet_default_config(&cfg);
         cfg.device_id = env_int("HNET_DEVICE", 0);
-        cfg.use_prior = use_prior ? 1 : 0;                             // the constructor argument decides what network_inference passes (HomographyNet.cpp:160-172)
+        // the constructor argument decides what network_inference passes (HomographyNet.cpp:160-172); with use_prior the file's record is read and must agree
+        cfg.use_prior = use_prior ? HNET_FROM_FILE : 0;
         cfg.blocks_to_run = env_int("HNET_BLOCKS_TO_RUN", HNET_FROM_FILE);
         cfg.mc_samples = env_int("HNET_MC_SAMPLES", HNET_FROM_FILE);
         cfg.dropout_p = (float)env_double("HNET_DROPOUT_P", -1.0);
@@ -78,8 +83,11 @@ public:
         cfg.max_batch = 1;
         std::printf("Loading the Network Model (HNETW001 weights) from %s ...\n", network_model_path.c_str());
         int rc = hnet_create(&cfg, network_model_path.c_str(), &ctx_);   // also runs the warm-up forward (:28-45)
-        if (rc != HNET_OK)
+        if (rc != HNET_OK) {
+            std::fprintf(stderr, "error loading the model !!!\n%s\n", network_model_path.c_str());      // the reference's two lines (:92,95)
             throw std::runtime_error(std::string("error loading the model !!! (") + hnet_status_string(rc) + ")");
+        }
+        require_prior_agrees(ctx_, use_prior, "main model");
         print_variant("main model", ctx_);
         hnet_timing t;
         hnet_last_timing(ctx_, &t);
@@ -95,10 +103,13 @@ public:
             rc = hnet_create(&ci, network_model_iterative_path.c_str(), &ctx_iter_);
             if (rc == HNET_OK) rc = hnet_attach_images(ctx_iter_, ctx_);
             if (rc != HNET_OK) {
+                std::fprintf(stderr, "error loading the model !!!\n%s\n", network_model_iterative_path.c_str());
                 hnet_destroy(ctx_iter_);
                 hnet_destroy(ctx_);
+                ctx_iter_ = ctx_ = nullptr;
                 throw std::runtime_error(std::string("error loading the model !!! (iterative: ") + hnet_status_string(rc) + ")");
             }
+            require_prior_agrees(ctx_iter_, use_prior, "iterative model");
             print_variant("iterative model", ctx_iter_);
             hnet_get_config(ctx_iter_, &used);
             any_err = used.emit_error_map != 0;
@@ -204,6 +215,16 @@ private:
         if (hnet_get_config(c, &u) != HNET_OK) return;
         std::printf("%s: %s, blocks_to_run %d, MC-dropout N = %d, p = %g, error map %s\n", what, u.use_prior ? "EKF prior" : "no prior (4 blocks)",
                     u.use_prior ? u.blocks_to_run : 3, u.mc_samples, (double)u.dropout_p, u.emit_error_map ? "on" : "off");
+    }
+    // the file's record against the constructor argument (the Python mirror raises ValueError for the same mismatch): a `full` file opened with use_prior = true
+    // would otherwise run as prior-3 on a prior the model variant was not meant for.  The contexts are released before the throw (no destructor runs).
+    void require_prior_agrees(hnet_ctx* c, bool use_prior, const char* what) {
+        hnet_config u;
+        if (hnet_get_config(c, &u) == HNET_OK && (u.use_prior != 0) == use_prior) return;
+        hnet_destroy(ctx_iter_);
+        hnet_destroy(ctx_);
+        ctx_iter_ = ctx_ = nullptr;
+        throw std::runtime_error(std::string(what) + ": use_prior disagrees with the variant recorded in the weight file");
     }
     static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
     static double env_double(const char* name, double dflt) { const char* v = std::getenv(name); return v ? std::atof(v) : dflt; }

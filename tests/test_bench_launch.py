@@ -64,3 +64,29 @@ def test_config_4_refuses_an_indivisible_sample_count():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--config", "4", "--dry-run"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert p.returncode != 0
+
+
+def test_config_4_preset_at_world_8():
+    """BASELINE config 4 at its literal shape: EIGHT ranks, 4 of the 32 MC-dropout samples each, one gather in global sample order"""
+    r = _run("--gpus", "8", "--config", "4", "--dry-run")
+    z = r["resolved"]
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["gather_checked"] is True
+    assert z["mode"] == "mc" and z["mc"] == 32 and z["mc_per_gpu"] == 4 and z["batch_per_gpu"] == 1 and z["gathers"] is True
+
+
+def test_config_5_preset_at_world_8():
+    """BASELINE config 5 at its literal shape: eight ranks, 32 streamed pairs each per step, FOUR steps per all-gather of the packed outputs
+    (OverlappedGather(group_steps=4): three slabs = twelve steps through the double-buffered gather, every step's rows of every rank checked); one compute
+    context per GPU in the streamed mode (stated in config.parallelism of the real run)"""
+    r = _run("--gpus", "8", "--config", "5", "--dry-run")
+    z = r["resolved"]
+    assert r["n_gpus"] == 8 and r["gather_checked"] is True
+    assert z["mode"] == "stream" and z["pairs_total"] == 256 and z["batch_per_gpu"] == 32 and z["gather_group_steps"] == 4 and z["contexts"] == 1
+    assert z["variant"] == "prior3" and z["mc"] == 16 and z["gathers"] is True
+
+
+def test_pairs_mode_at_world_8_keeps_two_contexts_with_grouped_gathers():
+    """the resident-input form of config 5's per-GPU shape (--pairs-total 256 over eight ranks = 32 pairs per GPU and step): grouped gathers AND two contexts"""
+    r = _run("--gpus", "8", "--pairs-total", "256", "--variant", "prior3", "--mc", "16", "--dry-run")
+    z = r["resolved"]
+    assert r["n_gpus"] == 8 and r["gather_checked"] is True and z["batch_per_gpu"] == 32 and z["gather_group_steps"] == 4 and z["contexts"] == 2

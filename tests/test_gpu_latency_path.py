@@ -114,9 +114,9 @@ def _engine_env(blob, env, **kw):
 @pytest.mark.parametrize("precision", [pytest.param(3, id="f16x2"), pytest.param(2, id="bf16x3")])
 @pytest.mark.parametrize("variant,n_mc,batch", [("full", 32, 1), ("prior3", 16, 1), ("prior1", 64, 2), ("full", 16, 8), ("prior3", 5, 7), ("full", 16, 20)])
 def test_split_k_without_reduce_launches_is_bitwise_the_reduce_launches(blob, variant, n_mc, batch, precision):
-    """Round 5: the split-K layers of small batches are finished by the last workgroup of a tile to arrive (igemm_s3.h s3_splitk_last_arriver)
-    or reduced by the next layer's loader (igemm_s3_lean_kernel<..., APART>) instead of a splitk_reduce* launch (hnet_config.variant 30 keeps
-    those): same sums in the same order -> the same homography bits, also when the forward is repeated on one context (the tile counters return
+    """Round 5: the split-K layers of small batches with at most 40 GEMM rows are finished by the last workgroup of a tile to arrive (igemm_s3.h
+    s3_splitk_last_arriver) instead of a splitk_reduce* launch (hnet_config.variant 30 keeps those; a reduce-on-load form was measured and removed,
+    DESIGN_HISTORY / profiles/r05_experiments_not_shipped.log): same sums in the same order -> the same homography bits, also when the forward is repeated on one context (the tile counters return
     to zero, the partials of an earlier forward are never read)."""
     from cuahn_vio_amd import synth
     prev, curr, prior, _ = synth.make_batch(700 + batch, batch)
@@ -132,3 +132,37 @@ def test_split_k_without_reduce_launches_is_bitwise_the_reduce_launches(blob, va
         e.close()
     assert np.array_equal(outs[0][1], outs[1][1])
     assert _same_outputs(outs[0][0], outs[1][0], precision if batch <= 8 else 2)      # (beyond 8 pairs the heads run the same kernels on both sides)
+
+
+@pytest.mark.parametrize("variant,n_mc,batch", [("full", 32, 1), ("prior3", 16, 1), ("prior1", 8, 2)])
+def test_last_arriver_split_k_many_repetitions_against_the_reduce_launches(blob, variant, n_mc, batch):
+    """the fence-free last arriver exchanges split-K partials between workgroups outside the HIP memory model (write-through stores, an
+    asm vmcnt(0) wait, a workgroup barrier, a relaxed agent-scope ticket) - a failure would be silent wrong sums.  400 back-to-back forwards on resident
+    buffers (no host synchronisation in between: the launches of consecutive forwards run tail to head, the tile counters are re-used every 10 us) must ALL
+    reproduce the homography of the supported fallback, variant 30 (splitk_reduce* launches), bit for bit, and the packed outputs of the first repetition."""
+    import torch
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import PIX_U8
+    dev = torch.device("cuda:0")
+    reps = 400
+    ph, ch, prh, _ = synth.make_batch(640 + batch, batch)
+    prev, curr, prior = torch.from_numpy(ph).to(dev), torch.from_numpy(ch).to(dev), torch.from_numpy(prh).to(dev)
+    d_prior = prior.data_ptr() if variant != "full" else None
+    kw = dict(variant=variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=3, max_batch=batch)
+    got = {}
+    for name, env in (("last_arriver", {}), ("reduce_launches", {"HNET_S3_TILE": "30"})):
+        e = _engine_env(blob, env, **kw)
+        n = reps if name == "last_arriver" else 3
+        out = torch.zeros(n, batch, 72, device=dev)
+        for i in range(n):
+            e.infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, batch, 5, out[i].data_ptr())
+        e.synchronize()
+        torch.cuda.synchronize()
+        got[name] = (out.cpu().numpy(), np.stack([e.debug_h_part1(b) for b in range(batch)]))
+        e.close()
+    o, h = got["last_arriver"]
+    differ = [i for i in range(1, reps) if not np.array_equal(o[i], o[0])]
+    assert differ == [], f"{len(differ)} of {reps} forwards differ from the first (first at {differ[0]})"
+    o30, h30 = got["reduce_launches"]
+    assert np.array_equal(h, h30)                                  # blocks 1 - 3: the same sums in the same order
+    assert np.abs(o[0][:, :8] - o30[0][:, :8]).max() < TOL_PX_PATHS      # (the heads' first FC of the latency path sums K in another order)
