@@ -7,6 +7,7 @@
 #include "../../include/hnet_rng.h"
 #include "geom.h"
 #include "kernels.h"
+#include "chain_args.h"
 #include "s3_format.h"
 
 #include <algorithm>
@@ -142,6 +143,13 @@ struct hnet_ctx {
     int act_c[20], act_h[20], act_w[20];
     float* ws = nullptr;               // split-K partial sums (igemm.h), 64 MB, followed by the SPLITK_TICKETS tile counters of the latency path (kernels.h LatIO)
     size_t ws_floats = 0;
+    // round 6: the tail of every block (its last 2 - 3 stride-2 layers) of a batch <= 8 as ONE launch on one XCD (chain_lat.h); fp16-plane mode, variant bit NO_CHAIN = off
+    bool use_chain = false;
+    int chain_grid = 256;              // workgroups of a chain launch (one per CU; HNET_VARIANT_CHAIN_GRID_8 / _3: the tests' small grids)
+    uint16_t* chain_w[20] = {};        // the chain layers' weights as MFMA fragments (chain_pack_weights)
+    ChainArgs chain_args[4] = {};      // one argument block per block's chain (passed by value)
+    uint32_t* chain_sync = nullptr;    // CH_AREAS counter areas of CH_SYNC_WORDS words (claims, per-pair item / done counters), one per block's chain: the area of a launch is zero
+                                       // when it starts - every chain launch zeroes the area of the NEXT chain launch of the forward sequence (stream ordered)
     bool lat_tail = true;              // round 5: split-K tiles of the 4 x 5 layers finished by their last-arriving workgroup, heads FC1 of small batches as one launch (heads_lat.h); variant 30 = off
     float *hidden = nullptr, *Hm = nullptr, *Htot = nullptr, *mean_s = nullptr, *logvar_s = nullptr;
     float *d_mean = nullptr, *d_cov = nullptr, *d_err = nullptr, *d_prior = nullptr;
@@ -170,7 +178,7 @@ struct hnet_ctx {
     bool graph_timing = false;         // hnet_time_batch_device too (HNET_GRAPH=1 only: the bare device time is 3 % better eager)
     uint64_t* d_seq = nullptr;
     uint32_t* d_flag = nullptr;        // hnet_overflow_flag: bit 0 = a forward produced a non-finite output since the last poll
-    struct Pinned { uint64_t seq; float prior[8]; float mean[8]; float cov[64]; uint8_t err[HNET_IMG_ROWS * HNET_IMG_COLS]; };
+    struct Pinned { uint64_t seq; float prior[8]; float mean[8]; float cov[64]; uint32_t flag; uint8_t err[HNET_IMG_ROWS * HNET_IMG_COLS]; };
     Pinned* pinned = nullptr;
     uint8_t* pinned_img[2] = {nullptr, nullptr};         // host staging of the pushed frame, one per ring slot
     hipEvent_t ev_img[2] = {nullptr, nullptr};           // its upload has completed
@@ -272,7 +280,7 @@ void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void
         const ConvDesc& d = kConvs[l];
         return 2.0 * d.cout * d.cin * d.ks * d.ks * conv_out_dim(h, d.ks, d.stride) * conv_out_dim(w, d.ks, d.stride);
     };
-    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19}, chain_first[4] = {1, 4, 10, 17};
     const bool small = c->fuse_small && batch <= 8;
     bool pend = false;
     if (g.use_prior) {
@@ -305,6 +313,15 @@ void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void
                 h = conv_out_dim(h, kConvs[8].ks, kConvs[8].stride);
                 w = conv_out_dim(w, kConvs[8].ks, kConvs[8].stride);
                 l = 8;
+            }
+            if (c->use_chain && small && l == chain_first[blk]) {      // one launch for the block's tail (chain_lat.h)
+                for (int l2 = l + 1; l2 <= last[blk]; l2++) {
+                    fl += conv_flops(l2, h, w);
+                    h = conv_out_dim(h, kConvs[l2].ks, kConvs[l2].stride);
+                    w = conv_out_dim(w, kConvs[l2].ks, kConvs[l2].stride);
+                    nm += std::string("+") + (kConvs[l2].name + 6);      // "block_4_4+4_5+4_6"
+                }
+                l = last[blk];
             }
             if (c->fuse_b4 && l == 13) {       // one launch for block_4_0 + block_4_1
                 fl += conv_flops(14, h, w);
@@ -363,7 +380,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     const hnet_config& g = c->cfg;
     const int B = a.batch;
     const size_t P0 = (size_t)a.pair0;
-    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19};
+    static const int first[4] = {0, 3, 7, 13}, last[4] = {2, 6, 12, 19}, chain_first[4] = {1, 4, 10, 17};
     float* Hm = c->Hm + P0 * 9;
     float* Htot = c->Htot + P0 * 9;
     // split-K workspace: only for a launch that covers the whole batch on one stream (small batches)
@@ -424,6 +441,20 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         size_t in_plane = 0;
         const size_t MB = (size_t)g.max_batch;
         for (int l = first[blk]; l <= last[blk]; l++) {
+            if (c->use_chain && small && P0 == 0 && l == chain_first[blk] && in16) {      // the block's tail in one launch on one XCD (chain_lat.h)
+                int nxt = blk < 3 ? blk + 1 : fb;                                         // the chain launch that follows this one on the stream: the next block's, or the next forward's first
+                if (nxt == blk) {                                                         // prior-1: ONE chain per forward - nobody else zeroes its area: a memset node in front of it
+                    if (hipMemsetAsync(c->chain_sync + blk * CH_SYNC_WORDS, 0, CH_SYNC_WORDS * sizeof(uint32_t), s) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "chain area memset");
+                    nxt = 0;
+                }
+                STAGE(launch_tail_chain(blk + 1, c->chain_args[blk], c->chain_sync + blk * CH_SYNC_WORDS, c->chain_sync + nxt * CH_SYNC_WORDS, B, s, c->chain_grid));
+                l = last[blk];
+                in = c->act[l];
+                in16 = nullptr;
+                in_plane = 0;
+                h = c->act_h[l]; w = c->act_w[l];
+                continue;
+            }
             if (c->fuse_b4 && l == 13) {       // block_4_0 + block_4_1 in one launch; the 8-channel map stays in LDS
                 const size_t cnt1 = c->a14_pad ? B42_IMG * 16 : c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
@@ -531,6 +562,7 @@ int forward(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // a forward that stopped part-way may leave split-K tile counters of the latency path non-zero (a launch that failed after its predecessors ran):
     // they are zeroed again behind whatever was enqueued, so the next forward starts from the state it assumes (kernels.h SPLITK_TICKETS)
     if (rc != HNET_OK && c->ws) (void)hipMemsetAsync(c->ws + c->ws_floats, 0, SPLITK_TICKETS * sizeof(uint32_t), s);
+    if (rc != HNET_OK && c->chain_sync) (void)hipMemsetAsync(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t), s);      // (likewise the chains' counter areas)
     return rc;
 }
 
@@ -567,7 +599,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
     } while (0)
     {
         auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-        for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); fr(c->conv_wfrag[l]); }
+        for (int l = 0; l < 20; l++) { fr(c->patch_frag[l]); fr(c->conv_w[l]); fr(c->conv_b[l]); fr(c->conv_w16[l]); fr(c->conv_wfrag[l]); fr(c->chain_w[l]); }
         for (int k = 0; k < 3; k++) { fr(c->fc_w[k]); fr(c->fc_b[k]); }
         fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3);
         fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2);
@@ -579,6 +611,12 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
         const Tensor* w = b.find(pre + "weight", {(uint32_t)d.cout, (uint32_t)d.cin, (uint32_t)d.ks, (uint32_t)d.ks});
         const Tensor* bi = b.find(pre + "bias", {(uint32_t)d.cout});
         if (!w || !bi) return HNET_ERR_BAD_WEIGHTS;
+        if (c->s3 && c->n_planes == 2 && chain_layer(l)) {      // latency path: the layer's weights as the fragments of its one-XCD tail chain (chain_lat.h)
+            std::vector<uint16_t> fr;
+            if (!chain_pack_weights(l, w->data, fr)) return HNET_ERR_BAD_WEIGHTS;
+            CK(hipMalloc((void**)&c->chain_w[l], fr.size() * 2));
+            CK(hipMemcpy(c->chain_w[l], fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        }
         if (c->s3 && l == 13) {     // block_4_0 for the fused kernel: K index 8g+j of step st = (kh = 2st + (g>>1), kk = 8(g&1) + j)
             std::vector<uint16_t> fr((size_t)5 * 3 * 64 * 8, 0);     // slot 4: kernel row 6 alone as 16x16x16 fragments (K = 4 gg + e = tap 2 gg + (e >> 1), ci = e & 1), low 8 bytes
             for (int ln = 0; ln < 64; ln++) {
@@ -821,7 +859,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     g.struct_size = sizeof(g);
     if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
     if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
-    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42)) return HNET_ERR_INVALID_ARG;
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3)) return HNET_ERR_INVALID_ARG;
     {
         const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
         static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
@@ -926,6 +964,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     } while (0)
     CK(hipSetDevice(g.device_id));
     CK(conv_kernels_init_device());      // dynamic-LDS limits of the patch / fused kernels: per device, so set at every create
+    CK(chain_init_device());
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
@@ -972,6 +1011,26 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         c->x16_plane = MB * B4_HP * B4_WP;
         CK(hipMalloc((void**)&c->x16_b4, 3 * c->x16_plane * 4));
         CK(hipMemset(c->x16_b4, 0, 3 * c->x16_plane * 4));
+    }
+    // the one-XCD tail chains of the latency path (chain_lat.h): default mode only; variant 30 (the round-4 latency path) and NO_CHAIN keep the launches
+    c->use_chain = c->n_planes == 2 && c->fuse_small && c->lat_tail && !(g.variant & HNET_VARIANT_NO_CHAIN);
+    c->chain_grid = (g.variant & HNET_VARIANT_CHAIN_GRID_3) ? 3 : (g.variant & HNET_VARIANT_CHAIN_GRID_8) ? 8 : 256;
+    if (c->use_chain) {
+        CK(hipMalloc((void**)&c->chain_sync, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
+        CK(hipMemset(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
+        static const int chain_first[4] = {1, 4, 10, 17};
+        ChainArgs* ca = c->chain_args;
+        for (int blk = 0; blk < 4; blk++) {
+            for (int l = chain_first[blk], j = 0; l <= last[blk]; l++, j++) {
+                ChainLayer& L = ca[blk].L[j];
+                L.in = c->act16[l - 1]; L.in_plane = MB * c->act_count[l - 1];
+                L.wfrag = c->chain_w[l]; L.bias = c->conv_b[l];
+                L.out16 = c->act16[l]; L.out_plane = MB * c->act_count[l];
+                L.out32 = c->act[l];
+                if (!L.in || !L.wfrag || !(L.out16 || L.out32)) c->use_chain = false;      // (a layout this build does not expect: the launches)
+            }
+            ca[blk].flag = c->d_flag;
+        }
     }
     c->ws_floats = (size_t)16 << 20;
     CK(dalloc(&c->ws, c->ws_floats + SPLITK_TICKETS));      // + the tile counters of the split-K launches (kernels.h): zero between launches
@@ -1074,7 +1133,8 @@ void hnet_destroy(hnet_ctx* c) {
         if (c->pinned_img[i]) (void)hipHostFree(c->pinned_img[i]);
         if (c->ev_img[i]) (void)hipEventDestroy(c->ev_img[i]);
     }
-    fr(c->d_seq); fr(c->d_flag);
+    fr(c->d_seq); fr(c->d_flag); fr(c->chain_sync);
+    for (int l = 0; l < 20; l++) fr(c->chain_w[l]);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);
     fr(c->ws); fr(c->w1); fr(c->b1); fr(c->w2); fr(c->b2); fr(c->hidden); fr(c->Hm); fr(c->Hm2); fr(c->Htot); fr(c->mean_s); fr(c->logvar_s);
@@ -1222,6 +1282,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     Blob b;
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;
+    c->use_chain = false;
     c->fuse_b3 = c->fuse_b42 = c->a14_pad = false;    // the fused block-3 / block_4_2+4_3 kernels exist for the fp16 planes only (their layers' buffers stay allocated; act16[14] goes back to the plain layout)
     c->cfg.precision = HNET_PREC_BF16X3;
     const int rc = upload_weights(c, b);
@@ -1232,6 +1293,18 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     c->blob_copy.shrink_to_fit();
     build_stages(c, c->cfg.max_batch);     // the fused fp16-plane kernels are gone from the launch list
     fprintf(stderr, "hnet: activation beyond the fp16 range in HNET_PREC_F16X2: context demoted to HNET_PREC_BF16X3\n");
+    return HNET_OK;
+}
+// A bounded spin of a one-XCD tail chain gave up (chain_lat.h CH_FLAG_TIMEOUT in the flag word: a claimed item never completed - not observed; the bound exists so
+// that a scheduling surprise ends in a flagged forward instead of a hung device).  The context goes back to the launches for good; the host entry points repeat the call.
+static int chain_gave_up(hnet_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->use_chain = false;
+    if (c->chain_sync) HIPCHK(c, hipMemset(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
+    for (int i = 0; i < 2; i++) if (c->g_infer[i]) { (void)hipGraphExecDestroy(c->g_infer[i]); c->g_infer[i] = nullptr; }
+    if (c->g_batch) { (void)hipGraphExecDestroy(c->g_batch); c->g_batch = nullptr; }
+    build_stages(c, c->cfg.max_batch);
+    fprintf(stderr, "hnet: a tail-chain launch timed out on its in-launch hand-off: this context uses the per-layer launches from now on\n");
     return HNET_OK;
 }
 int hnet_precision(const hnet_ctx* c) { return c ? c->cfg.precision : -1; }
@@ -1284,6 +1357,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
                 if (hipMemcpyAsync(pin->mean, c->d_mean, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (hipMemcpyAsync(pin->cov, c->d_cov, 256, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (c->cfg.emit_error_map && hipMemcpyAsync(pin->err, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
+                if (hipMemcpyAsync(&pin->flag, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 // the host entry points inspect (and, for an overflow, repair) their own results: the device flag is for the device-resident entry points only
                 if (hipMemsetAsync(c->d_flag, 0, 4, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 return HNET_OK;
@@ -1299,6 +1373,10 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             HIPCHK(c, hipGraphLaunch(c->g_infer[slot], c->stream));
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (pin->flag & CH_FLAG_TIMEOUT) {
+                const int rd = chain_gave_up(c);
+                return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
+            }
             if (c->n_planes == 2 && !(all_finite(pin->mean, 8) && all_finite(pin->cov, 64)) && prior_finite(c->cfg.use_prior ? prior_px : nullptr, 8)) {
                 const int rd = demote_to_bf16x3(c);
                 return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
@@ -1329,8 +1407,14 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     HIPCHK(c, hipMemcpyAsync(mean_out, c->d_mean, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (err_map_out) HIPCHK(c, hipMemcpyAsync(err_map_out, c->d_err_u8, NPIX, hipMemcpyDeviceToHost, c->stream));
+    uint32_t flag_now = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag_now, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));      // (see the graph path)
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag_now & CH_FLAG_TIMEOUT) {
+        const int rd = chain_gave_up(c);
+        return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
+    }
     if (c->n_planes == 2 && !(all_finite(mean_out, 8) && all_finite(cov_out, 64)) && prior_finite(c->cfg.use_prior ? prior_px : nullptr, 8)) {
         const int rd = demote_to_bf16x3(c);
         return rd != HNET_OK ? rd : hnet_infer(c, prior_px, iteration, mean_out, cov_out, err_map_out);
@@ -1394,8 +1478,14 @@ int hnet_infer_batch(hnet_ctx* c, const void* prev, const void* curr, int pix_fm
     HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, (size_t)batch * 8 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(cov, c->d_cov, (size_t)batch * 64 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (err_map) HIPCHK(c, hipMemcpyAsync(err_map, c->d_err, (size_t)batch * NPIX * sizeof(float), hipMemcpyDeviceToHost, s));
+    uint32_t flag_now = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag_now, c->d_flag, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, s));              // host results are inspected below: hnet_overflow_flag reports device-resident batches only
     HIPCHK(c, hipStreamSynchronize(s));
+    if (flag_now & CH_FLAG_TIMEOUT) {
+        const int rd = chain_gave_up(c);
+        return rd != HNET_OK ? rd : hnet_infer_batch(c, prev, curr, pix_fmt, prior, batch, pair_seq0, mean, cov, err_map);
+    }
     if (c->n_planes == 2 && !(all_finite(mean, (size_t)batch * 8) && all_finite(cov, (size_t)batch * 64)) &&
         (!prior || all_finite(prior, (size_t)batch * 8)) &&
         (pix_fmt == HNET_PIX_U8 || (all_finite((const float*)prev, (size_t)batch * NPIX) && all_finite((const float*)curr, (size_t)batch * NPIX)))) {

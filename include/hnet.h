@@ -92,7 +92,12 @@ enum {
                                                   split-K heads at every batch (the round-4 latency path: A/B and bitwise tests of round 5) */
     HNET_VARIANT_NO_LATENCY_PATH = 1u << 8,   /* batch <= 8 on the multi-launch path (bit-identical; tests/test_gpu_latency_path.py) */
     HNET_VARIANT_UNFUSED_B3 = 1u << 9,        /* block_3_0 and block_3_1 as separate launches (fp16-plane mode) */
-    HNET_VARIANT_UNFUSED_B42 = 1u << 10       /* block_4_2 and block_4_3 as separate launches (fp16-plane mode) */
+    HNET_VARIANT_UNFUSED_B42 = 1u << 10,      /* block_4_2 and block_4_3 as separate launches (fp16-plane mode) */
+    HNET_VARIANT_NO_CHAIN = 1u << 11,         /* batch <= 8: the tail layers of every block as separate launches instead of the one-XCD chain launch of round 6
+                                                  (csrc/chain_lat.h; fp16-plane mode; same arithmetic, another summation order: results agree to fp32 rounding) */
+    HNET_VARIANT_CHAIN_GRID_8 = 1u << 12,     /* tests: the chain launches with 8 workgroups instead of 256 (fewer resident workgroups than items: every workgroup works
+                                                  through several items of a layer) and */
+    HNET_VARIANT_CHAIN_GRID_3 = 1u << 13      /* with 3 (XCDs without a workgroup: pairs are picked up by whoever is done) - the same bits as the 256-workgroup launch */
 };
 
 typedef struct hnet_ctx hnet_ctx;

@@ -392,8 +392,9 @@ def test_device_resident_entry_point_and_timing(blob):
     names = [n for n, _ in eng.stages()]
     # 29: block_4_0 + block_4_1 fused (matrix-core modes); batch 4 takes the latency path: the three block-tail launches and mc_finish are merged away
     # (one more gone in the default arithmetic: block_3_0 + block_3_1 fused)
-    # (two more gone in the default arithmetic: block_3_0 + block_3_1 and block_4_2 + block_4_3 fused): 23 .. 30 launches
-    assert len(ms) == len(names) and 23 <= len(names) <= 30 and len(set(names)) == len(names) and (ms > 0).all()
+    # (two more gone in the default arithmetic: block_3_0 + block_3_1 and block_4_2 + block_4_3 fused): 23 .. 30 launches;
+    # round 6, default arithmetic: the tail of every block is ONE chain launch (csrc/chain_lat.h): 16
+    assert len(ms) == len(names) and 16 <= len(names) <= 30 and len(set(names)) == len(names) and (ms > 0).all()
     assert abs(sum(f for _, f in eng.stages()) - 1.0882e9) < 2e6       # 1.0882 GFLOP per pair, N=16
     eng.close()
 
