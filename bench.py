@@ -72,8 +72,9 @@ def parse(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=1.6, help="length of the sustained window of the default run")
     ap.add_argument("--contexts", type=int, default=None, metavar="NC",
                     help="independent steps issued round-robin on NC contexts, each with its own HIP stream and buffers (--mode pairs, one GPU): the launch chain of "
-                         "one step runs under the kernels of the others - what a server with independent batches does.  Default: 2 in --mode pairs (round 5: + 8 %% at "
-                         "256 pairs per step, + 30 %% at 32 - 64; the one-context figure of rounds 1 - 4 is reported beside it as `single_context`), 1 in the other modes")
+                         "one step runs under the kernels of the others - what a server with independent batches does.  The contexts are an hnet_group (include/hnet.h).  "
+                         "Default: 4 in --mode pairs (round 6, three fresh boxes, profiles/r06_ctx_sweep.log: + 8 %% at 256 pairs per step, + 43 %% at 64, + 60 %% at 32; the "
+                         "one-context figure of rounds 1 - 4 is reported beside it as `single_context`), 1 in the other modes")
     ap.add_argument("--distinct", type=int, default=None, metavar="D",
                     help="distinct frame pairs in a step's batch (default: all of them; rounds 1 - 5 timed 32 distinct pairs tiled to the batch size)")
     ap.add_argument("--honour-env", action="store_true",
@@ -347,7 +348,7 @@ def dry_run(args, rank, world):
                                        "replay": args.replay, "gathers": world > 1 or args.force_collective,
                                        # what run() would use: steps per all-gather of the packed outputs (small steps are grouped), contexts / HIP streams per GPU
                                        "gather_group_steps": (max(1, 128 // args.batch) if args.mode != "mc" else None),
-                                       "contexts": int(args.contexts) if args.contexts else (2 if args.mode == "pairs" else 1)},
+                                       "contexts": int(args.contexts) if args.contexts else (4 if args.mode == "pairs" else 1)},
                           "gather_checked": gather_ok}), flush=True)
     if world > 1:
         dist.barrier()
@@ -508,27 +509,35 @@ def run(args, ctx, primary):
     shard = hdist.shard_range(n_mc, world, rank) if mc_mode else None
     if mc_mode and n_mc % world:
         raise SystemExit("--mode mc needs N divisible by the number of GPUs")
-    eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank,
-                     precision=prec, mc_shard=shard)
-    # everything of a step — the forward's kernels, the packing of the outputs and the RCCL gather — is enqueued on ONE
-    # ordinary (non-default) stream: ordered by the stream, no legacy-default-stream semantics involved
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    sp = stream.cuda_stream
     # --contexts NC: step i runs on context i % NC (own stream, own activation buffers, own output record; the inputs are read-only and shared)
     NC = getattr(args, "contexts", None)
     if NC is None:
-        NC = 2 if args.mode == "pairs" else 1
+        NC = 4 if args.mode == "pairs" else 1
     NC = max(1, int(NC))
     if NC > 1 and (mc_mode or args.mode == "stream"):
         raise SystemExit("--contexts: --mode pairs only")
+    group = None
+    if NC > 1:
+        # round 6: the contexts are an hnet_group (include/hnet.h) - what a C++ caller gets: the library creates the member streams first, in a fixed order,
+        # each on its own priority level / hardware queue, and issues the steps round-robin
+        from cuahn_vio_amd.homography_net import HnetGroup
+        group = HnetGroup(blob, NC, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec)
+        eng = group.members[0]
+    else:
+        eng = HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank,
+                         precision=prec, mc_shard=shard)
+    # everything of a step — the forward's kernels, the packing of the outputs and the RCCL gather — is enqueued on ONE
+    # ordinary (non-default) stream: ordered by the stream, no legacy-default-stream semantics involved
+    stream = torch.cuda.ExternalStream(group.stream(0), device=dev) if group is not None else torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    sp = stream.cuda_stream
     # (round 6: with a collective the steps of one gathered slab may run on different contexts / streams - OverlappedGather.submit waits for every producer
     # stream, acquire makes every stream wait for the slab's previous gather - so grouped small steps (config 5 at 8 GPUs: 32 pairs per GPU, four steps per
-    # all-gather) keep their two contexts)
+    # all-gather) keep their contexts)
     engs, streams, outs = [eng], [stream], [out]
-    for _ in range(NC - 1):
-        engs.append(HnetEngine(blob, variant=args.variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=1, max_batch=B, device_id=local_rank, precision=prec))
-        streams.append(torch.cuda.Stream(dev))
+    for k in range(1, NC):
+        engs.append(group.members[k])
+        streams.append(torch.cuda.ExternalStream(group.stream(k), device=dev))
         outs.append(torch.zeros(B, 72, device=dev))
     if NC > 1 and og is None:
         out_of_step = lambda i: outs[i % NC]
@@ -635,8 +644,11 @@ def run(args, ctx, primary):
             return
         if og is not None:
             og.acquire(i, streams[i % NC])
-        engs[i % NC].infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None,
-                                               streams[i % NC].cuda_stream)
+        if group is not None:       # hnet_group_infer_batch_packed_device: member i % NC (the steps are issued in order from 0), on its own stream
+            m = group.infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None)
+            assert m == i % NC, "step index and group member out of step"
+        else:
+            eng.infer_batch_packed_device(prev.data_ptr(), curr.data_ptr(), PIX_U8, d_prior, B, seq0_of_step(i), out_of_step(i).data_ptr(), None, sp)
         if og is not None:
             og.submit(i, streams[i % NC], all_streams=streams)
 
@@ -698,7 +710,7 @@ def run(args, ctx, primary):
                    "parallelism": (f"MC-dropout samples sharded {n_mc}/{world} per GPU, trunk replicated, RCCL all_gather of [B,N/R,16]"
                                    if mc_mode else
                                    (f"pairs sharded over {world} GPU(s), RCCL all_gather of [B,72] outputs" if collective else "single GPU")) +
-                                  (f"; per GPU the independent steps alternate between {NC} contexts / HIP streams" if NC > 1 else ""),
+                                  (f"; per GPU the independent steps alternate between the {NC} contexts / HIP streams of an hnet_group" if NC > 1 else ""),
                    "weights": "synthetic seed 0 (trained checkpoint not shipped with the reference)"},
         "mc_preds_per_s": round(value * n_mc, 1),
         "rccl_ranks": dist.get_world_size() if collective else 1, "backend": backend,
@@ -854,7 +866,7 @@ def run(args, ctx, primary):
             res["latency_batch1_ms"]["sum_of_launches_us"] = round(float(sum(r["us"] for r in rows)), 1)
             res["latency_batch1_ms"]["floor_us"] = round(fl_total, 1)
             res["latency_batch1_ms"]["floor_definition"] = ("sum over the launches of max(compulsory bytes / 8 TB/s, issued FLOP / dense peak, 1.45 us kernel boundary) + 1.45 us "
-                                                            "for every further kernel of a launch (a split-K layer's reduce kernel; `kernels` = hnet_stage_kernels); "
+                                                            "for every further kernel of a launch (a split-K layer's reduce kernel; `kernels` = hnet_stage_kernels), + 1.0 us per in-launch layer hand-off of a one-XCD tail chain; "
                                                             "per-launch times are event to event (they include the boundary in front of the launch)")
             res["latency_batch1_ms"]["p50_over_floor"] = round(1e3 * res["latency_batch1_ms"]["p50"] / fl_total, 2)
             e1.close()
@@ -896,18 +908,18 @@ def run(args, ctx, primary):
             def both_ways(**kw):
                 # Mid-size batches leave the chip waiting on their own launch chain (25 dependent launches of 8 - 20 us each): a deployment with INDEPENDENT
                 # steps - config 3's batches, config 5's per-GPU share of a streamed sequence - issues them round-robin on a few contexts / HIP streams so that one
-                # step's chain runs under the others' kernels.  `value` = that with TWO contexts (tools/pipeline_ctx_bench.py measured 1 / 2 / 3 / 4: three or four are
-                # faster still on a quiet box, 178 - 182 k pairs/s at 64 pairs, but not reliably so); the one-context figure of rounds 1 - 4 stays beside it.
+                # step's chain runs under the others' kernels.  `value` = that with the FOUR contexts of an hnet_group (round 6: member streams created first, each on its own
+                # priority level - monotone 1 -> 4 contexts and within 4 % over three fresh boxes, profiles/r06_ctx_sweep.log); the one-context figure of rounds 1 - 4 stays beside it.
                 one = sub_run(args, ctx, contexts=1, stage_probe=True, **kw)
                 # (a child process, like the streamed configuration: which hardware queues two streams get depends on every stream the process created before;
                 # after the other sub-runs the in-process figure was 125 k pairs/s where the same command alone gives 174 - 177 k)
-                pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "2", "--steps", "60", "--warmup", "10",
+                pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "4", "--steps", "60", "--warmup", "10",
                                  "--precision", str(args.precision), "--no-extras", "--no-cpu-baseline", "--no-latency"])
                 if "error" in pip:
                     err = pip["error"]
-                    pip = sub_run(args, ctx, contexts=2, steps=60, warmup=10, **kw)
+                    pip = sub_run(args, ctx, contexts=4, steps=60, warmup=10, **kw)
                     pip["process"] = "in process (child run failed: " + err + ")"
-                pip["contexts"] = 2
+                pip["contexts"] = 4
                 pip["single_context"] = {k: one[k] for k in ("value", "ms_per_step", "steps", "max_px_err", "passed", "stage_ms", "stage_kernels") if k in one}
                 pip["passed"] = bool(pip["passed"] and one["passed"])
                 return pip
@@ -969,8 +981,12 @@ def run(args, ctx, primary):
     if stream_mode and use_thread:
         up_q.put(None)
         up_thread.join()
-    for e_ in engs:
-        e_.close()
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))      # (the current stream may be a member stream of the group, which dies with it)
+    if group is not None:
+        group.close()
+    else:
+        eng.close()
     return res, ok
 
 
@@ -1047,6 +1063,10 @@ def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_t
         mf = 1 if (n.startswith("fc_dlt") and "prep" not in n) or n.startswith("heads_fc2") else mfma_per_mac
         t_b, t_f = by / 8e12 * 1e6, fl * mf / ((peak_tf if mf > 1 else 157.3) * 1e12) * 1e6
         fl_us = max(t_b, t_f, 1.45) + 1.45 * (max(1, int(nk)) - 1)       # every further kernel of the launch is one more dependent boundary
+        # a one-XCD tail chain (csrc/chain_lat.h, "block_4_4+4_5+4_6"): its layers are separated by in-launch hand-offs inside one XCD, which the price list of
+        # MI355X_MICROARCH.md puts at 0.8 - 1.3 us each (same-XCD flag hand-off): 1.0 us per layer after the first
+        if n.startswith("block_") and n.count("+") >= 1 and n.split("+")[0][-1] in "234" and not n.endswith(("4_1", "3_1", "4_3")):
+            fl_us += 1.0 * n.count("+")
         total_floor += fl_us
         rows.append({"launch": n, "us": round(float(us), 2), "kernels": int(nk), "floor_us": round(float(fl_us), 2),
                      "bound": "boundary" if max(t_b, t_f) <= 1.45 else ("hbm" if t_b >= t_f else "mfma")})

@@ -27,6 +27,8 @@ SYMBOLS = [
     "hnet_op_prep", "hnet_op_prep_u8", "hnet_debug_layer_output", "hnet_debug_h_part1",
     "hnet_set_camera", "hnet_set_undistort_maps", "hnet_get_undistort_maps", "hnet_push_raw_image", "hnet_op_undistort",
     "hnet_op_block4_fused", "hnet_op_block3_fused", "hnet_op_block42_fused", "hnet_precision", "hnet_overflow_flag",
+    "hnet_create_group", "hnet_create_group_from_memory", "hnet_destroy_group", "hnet_group_size", "hnet_group_context", "hnet_group_stream",
+    "hnet_group_last_error", "hnet_group_infer_batch_packed_device", "hnet_group_join", "hnet_group_synchronize", "hnet_group_overflow_flag",
 ]
 
 
@@ -119,6 +121,21 @@ def lib():
     L.hnet_op_prep_u8.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp, C.c_int, fp]
     L.hnet_debug_layer_output.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t]
     L.hnet_debug_h_part1.argtypes = [vp, C.c_int, fp]
+    L.hnet_create_group.argtypes = [C.POINTER(Config), C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.hnet_create_group_from_memory.argtypes = [C.POINTER(Config), vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.hnet_destroy_group.argtypes = [vp]
+    L.hnet_destroy_group.restype = None
+    L.hnet_group_size.argtypes = [vp]
+    L.hnet_group_context.argtypes = [vp, C.c_int]
+    L.hnet_group_context.restype = vp
+    L.hnet_group_stream.argtypes = [vp, C.c_int]
+    L.hnet_group_stream.restype = vp
+    L.hnet_group_last_error.argtypes = [vp]
+    L.hnet_group_last_error.restype = C.c_char_p
+    L.hnet_group_infer_batch_packed_device.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_uint64, vp, vp, C.POINTER(C.c_int)]
+    L.hnet_group_join.argtypes = [vp, vp]
+    L.hnet_group_synchronize.argtypes = [vp]
+    L.hnet_group_overflow_flag.argtypes = [vp, C.POINTER(C.c_int)]
     for name in SYMBOLS:
         getattr(L, name)   # AttributeError here = the library does not export what include/hnet.h declares
     _lib = L

@@ -93,6 +93,7 @@ struct hnet_ctx {
     hnet_config cfg;
     hipStream_t stream = nullptr;
     std::string err;
+    bool owns_stream = true;           // false: a member of an hnet_group (the group owns the streams)
     std::vector<uint8_t> blob_copy;    // HNET_PREC_F16X2 only: the weight blob, kept so that an activation overflow can demote the context to HNET_PREC_BF16X3
     // weights (device)
     float* conv_w[20] = {};
@@ -189,6 +190,17 @@ struct hnet_ctx {
         return prev == o.prev && curr == o.curr && prior == o.prior && mean == o.mean && cov == o.cov && batch == o.batch && fmt == o.fmt; } };
     GraphKey g_key = {};
     hipGraphExec_t g_batch = nullptr;                     // hnet_time_batch_device on resident buffers (last signature)
+};
+
+// N contexts of one configuration on one device for INDEPENDENT steps (a server's batches, a rank's share of a streamed sequence): step k runs on context k mod N,
+// each context on its own HIP stream, so that the dependent launch chain of one step runs under the kernels of the others.
+struct hnet_group {
+    std::vector<hnet_ctx*> ctx;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> ev;        // hnet_group_join: one event per member stream
+    int device_id = 0;
+    uint64_t next = 0;                 // round-robin position
+    std::string err;
 };
 
 namespace {
@@ -851,7 +863,7 @@ int upload_weights(hnet_ctx* c, const Blob& b) {
 #undef CK
 }
 
-int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet_ctx** out) {
+int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet_ctx** out, hipStream_t preset_stream = nullptr) {
     if (!cfg_in || !out) return HNET_ERR_INVALID_ARG;
     hnet_config g;
     hnet_default_config(&g);
@@ -965,7 +977,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     CK(hipSetDevice(g.device_id));
     CK(conv_kernels_init_device());      // dynamic-LDS limits of the patch / fused kernels: per device, so set at every create
     CK(chain_init_device());
-    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (preset_stream) { c->stream = preset_stream; c->owns_stream = false; }      // a group member: the group created its streams first, each on a priority level / hardware queue of its own
+    else CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
     { const int rc_w = upload_weights(c, b); if (rc_w != HNET_OK) { hnet_destroy(c); return rc_w; } }
@@ -1118,6 +1131,116 @@ int hnet_create(const hnet_config* cfg, const char* weights_path, hnet_ctx** out
     return create_impl(cfg, buf.data(), buf.size(), out);
 }
 
+// ---- context groups
+static int create_group_impl(const hnet_config* cfg, const uint8_t* blob, size_t len, int n_ctx, hnet_group** out) {
+    if (!cfg || !out || n_ctx < 1 || n_ctx > HNET_GROUP_MAX) return HNET_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device_id < 0 || cfg->device_id >= ndev) return HNET_ERR_DEVICE;
+    if (hipSetDevice(cfg->device_id) != hipSuccess) return HNET_ERR_DEVICE;
+    hnet_group* g = new hnet_group();
+    g->device_id = cfg->device_id;
+    // The streams FIRST, in a fixed order, before any other stream of the group exists, and each on its own priority level as far as the device has levels: the
+    // HIP runtime multiplexes the streams of ONE priority over its hardware queues (which queue a stream gets depends on every stream the process created before),
+    // and two member streams that share a queue serialise their steps; queues of different priority are never shared.
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);          // numerically: greatest <= least (lower = more urgent)
+    const int levels = least - greatest + 1;
+    for (int i = 0; i < n_ctx; i++) {
+        hipStream_t st = nullptr;
+        const int prio = levels > 1 ? greatest + (i % levels) : 0;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) { hnet_destroy_group(g); return HNET_ERR_DEVICE; }
+        g->streams.push_back(st);
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { hnet_destroy_group(g); return HNET_ERR_DEVICE; }
+        g->ev.push_back(e);
+    }
+    for (int i = 0; i < n_ctx; i++) {
+        hnet_ctx* c = nullptr;
+        const int rc = create_impl(cfg, blob, len, &c, g->streams[i]);
+        if (rc != HNET_OK) { hnet_destroy_group(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    *out = g;
+    return HNET_OK;
+}
+
+int hnet_create_group_from_memory(const hnet_config* cfg, const void* blob, size_t len, int n_ctx, hnet_group** out) {
+    if (!blob) return HNET_ERR_INVALID_ARG;
+    return create_group_impl(cfg, (const uint8_t*)blob, len, n_ctx, out);
+}
+
+int hnet_create_group(const hnet_config* cfg, const char* weights_path, int n_ctx, hnet_group** out) {
+    if (!weights_path) return HNET_ERR_INVALID_ARG;
+    FILE* f = fopen(weights_path, "rb");
+    if (!f) { fprintf(stderr, "hnet_create_group: cannot open weights file %s\n", weights_path); return HNET_ERR_BAD_WEIGHTS; }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf(n > 0 ? n : 0);
+    size_t got = n > 0 ? fread(buf.data(), 1, n, f) : 0;
+    fclose(f);
+    if ((long)got != n) return HNET_ERR_BAD_WEIGHTS;
+    return create_group_impl(cfg, buf.data(), buf.size(), n_ctx, out);
+}
+
+void hnet_destroy_group(hnet_group* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device_id);
+    for (hnet_ctx* c : g->ctx) hnet_destroy(c);                          // (synchronises the member's stream; the streams are the group's)
+    for (hipEvent_t e : g->ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : g->streams) if (s) (void)hipStreamDestroy(s);
+    delete g;
+}
+
+int hnet_group_size(const hnet_group* g) { return g ? (int)g->ctx.size() : 0; }
+hnet_ctx* hnet_group_context(hnet_group* g, int i) { return (g && i >= 0 && i < (int)g->ctx.size()) ? g->ctx[i] : nullptr; }
+void* hnet_group_stream(hnet_group* g, int i) { return (g && i >= 0 && i < (int)g->streams.size()) ? (void*)g->streams[i] : nullptr; }
+const char* hnet_group_last_error(const hnet_group* g) { return g ? g->err.c_str() : ""; }
+
+int hnet_group_infer_batch_packed_device(hnet_group* g, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch, uint64_t pair_seq0,
+                                         float* d_out72, float* d_err_map, int* member) {
+    if (!g || g->ctx.empty()) return HNET_ERR_INVALID_ARG;
+    const int i = (int)(g->next % g->ctx.size());
+    const int rc = hnet_infer_batch_packed_device(g->ctx[i], d_prev, d_curr, pix_fmt, d_prior, batch, pair_seq0, d_out72, d_err_map, nullptr);
+    if (rc != HNET_OK) { g->err = g->ctx[i]->err; return rc; }
+    g->next++;
+    if (member) *member = i;
+    return HNET_OK;
+}
+
+int hnet_group_join(hnet_group* g, void* stream) {
+    if (!g || !stream) return HNET_ERR_INVALID_ARG;
+    if (hipSetDevice(g->device_id) != hipSuccess) return HNET_ERR_DEVICE;
+    for (size_t i = 0; i < g->streams.size(); i++) {
+        if (hipEventRecord(g->ev[i], g->streams[i]) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g->ev[i], 0) != hipSuccess) {
+            g->err = "hnet_group_join: event";
+            return HNET_ERR_DEVICE;
+        }
+    }
+    return HNET_OK;
+}
+
+int hnet_group_synchronize(hnet_group* g) {
+    if (!g) return HNET_ERR_INVALID_ARG;
+    if (hipSetDevice(g->device_id) != hipSuccess) return HNET_ERR_DEVICE;
+    for (hipStream_t s : g->streams)
+        if (hipStreamSynchronize(s) != hipSuccess) { g->err = "hipStreamSynchronize"; return HNET_ERR_DEVICE; }
+    return HNET_OK;
+}
+
+int hnet_group_overflow_flag(hnet_group* g, int* flags) {
+    if (!g || !flags) return HNET_ERR_INVALID_ARG;
+    int all = 0;
+    for (hnet_ctx* c : g->ctx) {
+        int f = 0;
+        const int rc = hnet_overflow_flag(c, nullptr, &f);
+        if (rc != HNET_OK) { g->err = c->err; return rc; }
+        all |= f;
+    }
+    *flags = all;
+    return HNET_OK;
+}
+
 void hnet_destroy(hnet_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
@@ -1143,7 +1266,7 @@ void hnet_destroy(hnet_ctx* c) {
     for (auto e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

@@ -60,6 +60,24 @@ def kernel_selection_from_env():
 FROM_FILE = -1      # include/hnet.h HNET_FROM_FILE
 
 
+def make_config(variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1, emit_error_map=False, device_id=0, mc_shard=None, precision=None):
+    """hnet_config from the arguments of HnetEngine / HnetGroup (None = HNET_FROM_FILE where the C ABI has it) and this process's kernel-selection environment"""
+    cfg = Config()
+    lib().hnet_default_config(C.byref(cfg))
+    if precision is None:   # default: the library's (fp16 planes, fp32-grade); HNET_PRECISION=2 / 0 select split-bf16 / the exact-fp32 MFMA path
+        precision = cfg.precision if IGNORE_ENV else int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
+    cfg.device_id = device_id
+    cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant] if variant is not None else (FROM_FILE, FROM_FILE)
+    cfg.mc_samples = FROM_FILE if mc_samples is None else mc_samples
+    cfg.dropout_p = -1.0 if dropout_p is None else dropout_p
+    cfg.mc_seed = mc_seed
+    cfg.emit_error_map, cfg.precision, cfg.max_batch = (FROM_FILE if emit_error_map is None else int(emit_error_map)), precision, max_batch
+    if mc_shard is not None:
+        cfg.mc_sample_begin, cfg.mc_sample_end = mc_shard
+    cfg.warp_exact, cfg.graph, cfg.variant = kernel_selection_from_env()
+    return cfg
+
+
 class HnetEngine:
     """One hnet context (one GPU).  `weights` is an HNETW001 blob (bytes) or a path to one."""
 
@@ -68,20 +86,9 @@ class HnetEngine:
         """variant / mc_samples / dropout_p / emit_error_map = None: HNET_FROM_FILE - taken from the blob's `hnet.variant` record
         (cuahn_vio_amd.weights.pack_state_dict(..., variant=...)); `config()` returns what is in effect"""
         L = lib()
-        cfg = Config()
-        L.hnet_default_config(C.byref(cfg))
-        if precision is None:   # default: the library's (fp16 planes, fp32-grade); HNET_PRECISION=2 / 0 select split-bf16 / the exact-fp32 MFMA path
-            precision = cfg.precision if IGNORE_ENV else int(os.environ.get("HNET_PRECISION", str(cfg.precision)))
-        cfg.device_id = device_id
-        cfg.use_prior, cfg.blocks_to_run = VARIANTS[variant] if variant is not None else (FROM_FILE, FROM_FILE)
-        cfg.mc_samples = FROM_FILE if mc_samples is None else mc_samples
-        cfg.dropout_p = -1.0 if dropout_p is None else dropout_p
-        cfg.mc_seed = mc_seed
-        cfg.emit_error_map, cfg.precision, cfg.max_batch = (FROM_FILE if emit_error_map is None else int(emit_error_map)), precision, max_batch
-        if mc_shard is not None:
-            cfg.mc_sample_begin, cfg.mc_sample_end = mc_shard
-        cfg.warp_exact, cfg.graph, cfg.variant = kernel_selection_from_env()
+        cfg = make_config(variant, mc_samples, dropout_p, mc_seed, max_batch, emit_error_map, device_id, mc_shard, precision)
         self.cfg, self.variant, self._L = cfg, variant, L
+        self._owned = True
         self._h = C.c_void_p()
         if isinstance(weights, (bytes, bytearray)):
             buf = (C.c_char * len(weights)).from_buffer_copy(weights)
@@ -106,11 +113,21 @@ class HnetEngine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.hnet_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.hnet_destroy(self._h)
             self._h = None
 
     def __del__(self):
         self.close()
+
+    @classmethod
+    def _borrow(cls, handle, variant=None):
+        """a view of a context somebody else owns (a member of an HnetGroup): every method works, close() does not destroy"""
+        e = cls.__new__(cls)
+        e._L, e._h, e._owned, e.variant = lib(), C.c_void_p(handle), False, variant
+        e.cfg = e.config()
+        e.n_local = (e.cfg.mc_sample_end - e.cfg.mc_sample_begin) or e.cfg.mc_samples
+        return e
 
     @property
     def handle(self):
@@ -325,6 +342,63 @@ class HnetEngine:
         out = np.zeros(9, np.float32)
         check(self._h, self._L.hnet_debug_h_part1(self._h, pair, _fp(out)))
         return out.reshape(3, 3)
+
+
+class HnetGroup:
+    """hnet_group (include/hnet.h): n_ctx contexts of one configuration for INDEPENDENT steps - step k runs on member k mod n_ctx, each member on its own HIP
+    stream (created first, each on its own priority level / hardware queue).  `weights`: an HNETW001 blob (bytes) or a path."""
+
+    def __init__(self, weights, n_ctx, variant="full", mc_samples=16, dropout_p=0.05, mc_seed=0, max_batch=1, emit_error_map=False, device_id=0, precision=None):
+        L = lib()
+        cfg = make_config(variant, mc_samples, dropout_p, mc_seed, max_batch, emit_error_map, device_id, None, precision)
+        self._L, self._g, self.variant = L, C.c_void_p(), variant
+        if isinstance(weights, (bytes, bytearray)):
+            buf = (C.c_char * len(weights)).from_buffer_copy(weights)
+            rc = L.hnet_create_group_from_memory(C.byref(cfg), C.cast(buf, C.c_void_p), len(weights), int(n_ctx), C.byref(self._g))
+        else:
+            rc = L.hnet_create_group(C.byref(cfg), str(weights).encode(), int(n_ctx), C.byref(self._g))
+        check(None, rc)
+        self.n = int(L.hnet_group_size(self._g))
+        self.members = [HnetEngine._borrow(L.hnet_group_context(self._g, i), variant) for i in range(self.n)]
+
+    def _check(self, rc):
+        if rc != _capi.HNET_OK:
+            raise HnetError(rc, self._L.hnet_status_string(rc).decode() + ": " + self._L.hnet_group_last_error(self._g).decode())
+
+    def stream(self, i):
+        """member i's hipStream_t as an integer handle (torch.cuda.ExternalStream(handle) wraps it)"""
+        return int(self._L.hnet_group_stream(self._g, i) or 0)
+
+    def infer_batch_packed_device(self, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_out72, d_err=None):
+        """the next step, on the next member's stream; returns that member's index.  Does not synchronise; consecutive steps need distinct output buffers"""
+        m = C.c_int(-1)
+        self._check(self._L.hnet_group_infer_batch_packed_device(self._g, d_prev, d_curr, fmt, d_prior, batch, pair_seq0, d_out72, d_err, C.byref(m)))
+        return int(m.value)
+
+    def join(self, stream):
+        """`stream` (a torch stream or a raw handle) waits for everything enqueued on the members so far"""
+        self._check(self._L.hnet_group_join(self._g, HnetEngine._stream(stream)))
+
+    def synchronize(self):
+        self._check(self._L.hnet_group_synchronize(self._g))
+
+    def overflow_flag(self):
+        v = C.c_int(0)
+        self._check(self._L.hnet_group_overflow_flag(self._g, C.byref(v)))
+        return int(v.value)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()
+            self._L.hnet_destroy_group(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HomographyNet:

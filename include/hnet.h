@@ -239,6 +239,33 @@ int hnet_mc_finish_packed_device(hnet_ctx* ctx, const float* d_mean_s, const flo
 int hnet_mc_finish_gathered_device(hnet_ctx* ctx, const float* d_gathered, int world, int n_local, const float* d_h_part1, int batch, float* d_out72,
                                    void* stream);
 
+/* ---- context groups (round 6): INDEPENDENT steps on several contexts ------------------------------------------------------------
+ * A forward of <= 64 frame pairs leaves most of the chip waiting on its own chain of dependent launches.  Where the steps are independent - a server's batches,
+ * a rank's share of a streamed sequence (BASELINE configs 3 and 5) - issuing them round-robin on a few contexts, each with its own HIP stream and buffers, runs
+ * one step's chain under the others' kernels: + 30 ... 40 % pairs/s at 32 - 64 pairs per step, + 5 % at 256 (bench.py --contexts).
+ * A group is n_ctx contexts of ONE configuration on one device (weights uploaded per member).  It creates its streams before anything else, in a fixed order,
+ * each on its own stream-priority level as far as the device has levels (three on this part): streams of one priority share the runtime's hardware queues in an
+ * order that depends on the process's stream history, and two members on one queue serialise; queues of different priority are never shared.
+ * hnet_group_infer_batch_packed_device = hnet_infer_batch_packed_device on member (call count mod n_ctx), on THAT member's stream; it does not synchronise.
+ * Outputs of consecutive calls must not alias (two steps are in flight at once).  hnet_group_join makes `stream` wait for everything enqueued on the members so far
+ * (one event per member); hnet_group_synchronize waits on the host.  Results are those of a single context, bit for bit (tests/test_gpu_group.py).
+ * Not thread-safe (one caller thread, like a context). */
+#define HNET_GROUP_MAX 8
+typedef struct hnet_group hnet_group;
+int hnet_create_group(const hnet_config* cfg, const char* weights_path, int n_ctx, hnet_group** out);
+int hnet_create_group_from_memory(const hnet_config* cfg, const void* blob, size_t len, int n_ctx, hnet_group** out);
+void hnet_destroy_group(hnet_group* group);
+int hnet_group_size(const hnet_group* group);
+hnet_ctx* hnet_group_context(hnet_group* group, int i);      /* member i (hnet_get_config, hnet_precision, per-member calls); owned by the group */
+void* hnet_group_stream(hnet_group* group, int i);           /* member i's hipStream_t (to order a caller's own work - a collective, a copy - behind its step) */
+const char* hnet_group_last_error(const hnet_group* group);
+/* member: NULL, or receives the index of the member the step was enqueued on */
+int hnet_group_infer_batch_packed_device(hnet_group* group, const void* d_prev, const void* d_curr, int pix_fmt, const float* d_prior, int batch,
+                                         uint64_t pair_seq0, float* d_out72, float* d_err_map, int* member);
+int hnet_group_join(hnet_group* group, void* stream);
+int hnet_group_synchronize(hnet_group* group);
+int hnet_group_overflow_flag(hnet_group* group, int* flags);   /* hnet_overflow_flag of every member, ORed; synchronises the members */
+
 int hnet_synchronize(hnet_ctx* ctx, void* stream);
 int hnet_last_timing(const hnet_ctx* ctx, hnet_timing* out);
 

@@ -85,8 +85,8 @@ def test_config_5_preset_at_world_8():
     assert z["variant"] == "prior3" and z["mc"] == 16 and z["gathers"] is True
 
 
-def test_pairs_mode_at_world_8_keeps_two_contexts_with_grouped_gathers():
-    """the resident-input form of config 5's per-GPU shape (--pairs-total 256 over eight ranks = 32 pairs per GPU and step): grouped gathers AND two contexts"""
+def test_pairs_mode_at_world_8_keeps_its_contexts_with_grouped_gathers():
+    """the resident-input form of config 5's per-GPU shape (--pairs-total 256 over eight ranks = 32 pairs per GPU and step): grouped gathers AND the contexts of the hnet_group"""
     r = _run("--gpus", "8", "--pairs-total", "256", "--variant", "prior3", "--mc", "16", "--dry-run")
     z = r["resolved"]
-    assert r["n_gpus"] == 8 and r["gather_checked"] is True and z["batch_per_gpu"] == 32 and z["gather_group_steps"] == 4 and z["contexts"] == 2
+    assert r["n_gpus"] == 8 and r["gather_checked"] is True and z["batch_per_gpu"] == 32 and z["gather_group_steps"] == 4 and z["contexts"] == 4
