@@ -11,13 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "adapter_smoke.bin")
 
 
-def _build(src="adapter_smoke.cpp", out=None):
+def _build(src="adapter_smoke.cpp", out=None, hip_headers=False):
     from cuahn_vio_amd import _capi
     if not os.path.exists(_capi.LIB_PATH):
         import __graft_entry__ as g
         g.build()
     rocm_lib = "/opt/rocm/lib"
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include")] + \
+          (["-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-Wno-unused-result"] if hip_headers else []) + [      # (a host program that calls the HIP runtime API itself)
            os.path.join(ROOT, "tests", "cpp", src), "-o", out or BIN,
            "-L", os.path.join(ROOT, "cuahn_vio_amd"), "-lhnet_hip", f"-Wl,-rpath,{os.path.join(ROOT, 'cuahn_vio_amd')}",
            "-L", rocm_lib, "-lamdhip64", f"-Wl,-rpath,{rocm_lib}"]
@@ -223,3 +224,17 @@ def test_adapter_latency_from_cpp(blob, tmp_path):
         line = [l for l in r.stderr.splitlines() if l.startswith("LATENCY")][0]
         print(("full" if use_prior == "0" else "prior-3"), line)
         assert float(line.split()[2]) < 2.0
+
+
+@pytest.mark.gpu
+def test_cpp_group_example_runs(blob, tmp_path):
+    """tests/cpp/group_example.cpp: a C++ caller of hnet_group (round 6) - twelve independent steps round-robin on three contexts, a consumer stream joined behind
+    them, every step bit-identical to a single context's; with --time the pairs/s of the same loop (what bench.py --contexts measures through the Python mirror)"""
+    exe = os.path.join(ROOT, "tests", "cpp", "group_example.bin")
+    _build("group_example.cpp", exe, hip_headers=True)
+    w = tmp_path / "w.hnw"
+    w.write_bytes(blob)
+    r = subprocess.run([exe, str(w), "3", "32", "--time"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GROUP_OK members=3 batch=32" in r.stdout and "GROUP_TIME" in r.stdout
+    print(r.stdout[-300:])

@@ -7,5 +7,8 @@ rm -f gpurun_out/${R}_parity_table.csv gpurun_out/${R}_full_batch_check.log
 HNET_PARITY_TABLE=$PWD/gpurun_out/${R}_parity_table.csv python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16_mode.py -m gpu -q 2>&1 | tail -2
 (python tools/full_batch_check.py 256 32 full 256 3; python tools/full_batch_check.py 256 16 prior3 256 3; python tools/full_batch_check.py 256 32 full 256 2; python tools/full_batch_check.py 256 32 full 256 0) > gpurun_out/${R}_full_batch_check.log 2>&1
 python tools/determinism_stress.py 2000 > gpurun_out/${R}_determinism.log 2>&1
+# round 6: the one-XCD tail chains against the per-layer launches (outputs, per-layer maps, batch-1 / batch-8 device time), the chain kernel's in-kernel phase stamps
+python tools/chain_check.py 200 > gpurun_out/${R}_chain_check.log 2>&1
+(tools/trace_chain_plain.bin 1; tools/trace_chain_plain.bin 8; tools/trace_chain.bin 1) > gpurun_out/${R}_chain_trace.log 2>&1
 python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
 ls -la gpurun_out/${R}_* gpurun_out/prof_$TAG
