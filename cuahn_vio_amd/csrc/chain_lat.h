@@ -5,28 +5,37 @@
 //   block 2: block_2_2 (64 -> 128, 5 x 5), block_2_3 (128 -> 256, 3 x 3), block_2_4 (256 -> 256) 28 x 40 -> 14 x 20 -> 7 x 10 -> 4 x 5
 //   blocks 3, 4: block_x_3 / _4 (64 -> 128, 3 x 3), _4 / _5 (128 -> 256), _5 / _6 (256 -> 256)   the same sizes
 //
-// Why.  At batch 1 these layers are 0.01 - 0.06 GFLOP each behind 0.3 - 2.4 MB of weights: as launches they cost 11 us apiece (split-K GEMM + reduce kernel or
-// last-arriver tickets: 18 kernels per forward, ~ 120 of the 190 us), almost all of it kernel boundaries and first round trips.  A dependent kernel costs
-// ~ 4 us + 1.5 us of boundary whatever it does; a hand-off INSIDE a launch is cheap only between workgroups that share an L2 (MI355X_MICROARCH.md, price list:
-// chip-wide barriers 4 - 7 us, same-XCD hand-offs ~ 1 us).  So one XCD (32 CUs, one L2) runs the whole tail of a frame pair:
+// Why.  At batch 1 these layers are 0.01 - 0.06 GFLOP each behind 0.3 - 2.4 MB of weights.  As launches they are 18 kernels of 4 - 9 us (split-K GEMM + reduce /
+// last-arriver tickets; rocprofv3: profiles/r06_experiments_not_shipped.log item 10), none of which does more than a microsecond of work: a dependent kernel costs
+// its boundary and three or four dependent round trips whatever it does.  A hand-off INSIDE a launch is cheap only between workgroups that share an L2
+// (MI355X_MICROARCH.md, price list: chip-wide barriers 4 - 7 us, same-XCD hand-offs ~ 1 us).  So one XCD (32 CUs, one L2) runs the whole tail of a frame pair:
 //   * plain stores of a layer's output stay in that XCD's L2; the next layer reads them with sc1 loads (L1 bypassed, L2 served): no write-through, no fence;
-//   * a layer is cut into <= 32 ITEMS (a tile of 8 / 16 output channels x a slice of output rows, the whole K): one per CU, no split-K partials in memory - the
-//     eight waves of a workgroup split K and add their partial tiles through LDS in wave order (deterministic);
-//   * the weights come as pre-packed MFMA fragments straight into registers (hnet_create packs them in consumption order: a wave-instruction is contiguous),
-//     ALL of an item's loads in flight at once and issued BEFORE the wait for the previous layer (they do not depend on it);
-//   * the item's input region is staged once into LDS as four parity images (a stride-2 tap reads ONE of them: consecutive output pixels are consecutive slots;
-//     slot pitch = CIN x 2 + 16 bytes: the 16 pixels of a B fragment fall into 16 different bank groups), zero padding included.
+//   * a layer is cut into 32 ITEMS (a tile of 8 / 16 output channels x a slice of output rows, the whole K): one per CU, no split-K partials in memory - the
+//     eight waves of a workgroup take equal shares of K and add their partial tiles through LDS in wave order (deterministic);
+//   * the weights come as pre-packed MFMA fragments straight into registers (hnet_create packs them in consumption order: a wave instruction is contiguous), every
+//     load of an item in flight at once - and ONE LAYER AHEAD: a workgroup draws its first item of every layer when the launch starts, and issues the fragments
+//     of its next layer's item behind the stores of the current one (its registers are free there), so that they travel during the signalling, the wait for the
+//     layer and the region copy (counted vmcnt waits: loads and stores complete in issue order);
+//   * the item's input region is staged once into LDS by LDS-DMA as four parity images (a stride-2 tap reads ONE of them: consecutive output pixels are
+//     consecutive slots; slot pitch = CIN x 2 + 16 bytes: the 16 pixels of a B fragment fall into 16 different bank groups), zero padding included; the slot ->
+//     pixel table is built before the wait;
+//   * workgroup barriers wait for LDS traffic only (ch_bar): __syncthreads() would wait for the fragments in flight and for every counter atomic.
+// What a layer costs here (tools/trace_chain.hip, in-kernel stamps): wait for the previous layer 0.7 us, region copy 1.9 (~ 100 KB per CU at ~ 50 GB/s), MFMAs 1.3
+// (two waves per SIMD share the matrix pipe), reduction + stores + next fragments 1.5, signal 0.4, ~ 0.8 of transitions: 6.5 us per layer, 22.5 us for a
+// three-layer chain against 28 us + gaps for the five kernels it replaces.
 //
 // Placement independence.  HIP promises nothing about workgroup -> XCD placement, so nothing here assumes it: every workgroup reads its XCD from HW_REG_XCC_ID;
-// the XCD whose workgroup wins an agent-scope compare-and-swap on the pair's claim word OWNS that pair for this launch, workgroups of other XCDs leave.  Items
-// are CLAIMED from XCD-local counters (any number >= 1 of resident owner workgroups finishes the chain: no co-residency assumption, no deadlock: a workgroup
-// only ever waits for items that running workgroups have claimed), every spin is bounded (a timeout raises bit 1 of the context's flag word).  With the observed
-// round-robin placement a 256-workgroup launch gives every XCD 32 workgroups and up to eight pairs run on eight XCDs side by side.
+// the XCD whose workgroup wins an agent-scope compare-and-swap on the pair's claim word OWNS that pair for this launch (pair p is first tried by the XCDs
+// x = p mod batch; a pair nobody claimed - an XCD without workgroups - is picked up by any workgroup that is done), workgroups of other XCDs leave.  Items are
+// CLAIMED from an XCD-local counter (any number >= 1 of resident owner workgroups finishes the chain: no co-residency assumption, no deadlock: a workgroup only
+// ever waits for items that running workgroups have claimed), every spin is bounded (a timeout raises bit 1 of the context's flag word).  The tests launch the
+// chain with 8 and with 3 workgroups: same bits.  With the observed round-robin placement a 256-workgroup launch gives every XCD 32 workgroups and up to eight
+// pairs run on eight XCDs side by side.
 //
-// Words shared between XCDs (claim, exit count, generation) are touched by agent-scope atomics only; the item / done counters of a pair are touched only by
-// its owner XCD (L2-local atomics, sc1 polls) and live in two alternating sets selected by the launch generation: the set of the NEXT launch is zeroed by the
-// owner during this one, so no word is ever reset while somebody may still use it and consecutive launches may be owned by different XCDs (kernel boundaries
-// write the L2 back).
+// The claim words are the only words XCDs share (agent-scope compare-and-swap); the item counter and the done counters of a pair are touched by its owner XCD
+// only (L2-local atomics, sc1 polls).  Every chain launch of a forward has its own counter AREA, all zero when the launch starts: workgroup 0 of the PREVIOUS
+// chain launch of the stream zeroes it (write-through stores; stream order: nobody uses it then) - no word is ever reset while somebody may still use it, and
+// consecutive launches may be owned by different XCDs (kernel boundaries write the L2 back).
 //
 // Arithmetic: the two-plane fp16 form of igemm_s3.h (hi += W0 A0, lo += W0 A1 + W1 A0, result = hi + lo / 4096) with K summed in another order than the
 // split-K kernels: results agree to fp32 rounding (tests/test_gpu_latency_path.py gates 5e-5 px; hnet_config.variant HNET_VARIANT_NO_CHAIN keeps the launches).
@@ -74,8 +83,7 @@ struct ChainCfg {
 };
 
 // dynamic LDS: the region (the largest, block_1_2's: 156 672 B; its first bytes double as the reduction buffer), the slot table (<= 528 words), the broadcast words
-// and the 1-KB dump of warm_w (its own bytes: another wave may still be reading the table when the first prefetched fragments land)
-constexpr int CH_TABLE_OFF = 153 * 1024, CH_DUMP_OFF = 156 * 1024, CH_LDS_BYTES = 160 * 1024;
+constexpr int CH_TABLE_OFF = 153 * 1024, CH_LDS_BYTES = 160 * 1024;
 
 __device__ __forceinline__ uint32_t ch_load_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // global_load_dword sc1: L1 bypassed
 __device__ __forceinline__ uint32_t ch_local_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // executed in this XCD's L2
@@ -105,7 +113,6 @@ __device__ __forceinline__ bool ch_wait_eq(const uint32_t* p, uint32_t target, u
 template <class C>
 struct ChainOps {
     static constexpr int TM = C::TM, SPW = C::SPW, NCH = C::NCH;
-    static constexpr int WARM_N = (2 * SPW * C::FRAG_BYTES + 8191) / 8192;      // warm_w: wave instructions of 64 lines
     // every wave takes SPW consecutive steps; steps beyond NSTEP (K padded to eight equal shares) load zeros (out-of-range offsets: no traffic) against any valid
     // fragment of the region - no control flow in the unrolled loops, one constant in the counted waits
     typedef bf16x8 W[SPW][2];
@@ -132,25 +139,7 @@ struct ChainOps {
                 fw[k][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, vo, base + (k * 2 + pl) * C::FRAG_BYTES, 0));
         }
     }
-    // the same fragments pulled into this XCD's L2 only (LDS-DMA into a 1-KB dump: no registers): issued one layer ahead, behind that layer's region, they stream
-    // from memory during its arithmetic, its stores and the wait for it; load_w then finds them in the L2
-    __device__ static __forceinline__ void warm_w(const ChainLayer& L, const Item& it, uint8_t* dump, int wave, int lane) {
-#ifdef HNET_CHAIN_NO_WARM
-        return;
-#endif
-        // one dword per 128-byte line: the L2 fetches the line, 4 bytes of it cross to the CU (the CU's 64 B / clk from the L2 is what bounds these layers)
-        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)L.wfrag, 0, 0x7FFFFFF0, 0x00020000);
-        constexpr int BYTES = 2 * SPW * C::FRAG_BYTES;                       // this wave's fragments are contiguous
-        const int base = (it.tile * C::NSTEP + wave * SPW) * 2 * C::FRAG_BYTES;
-        const int real = min(SPW, C::NSTEP - wave * SPW) * 2 * C::FRAG_BYTES;      // (steps beyond NSTEP do not exist in memory)
-#pragma unroll
-        for (int k = 0; k < WARM_N; k++) {
-            const int off = (k * 64 + lane) * 128;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)dump, 4, off < real ? (uint32_t)off : S3_OOB, base, 0, 0);
-        }
-        (void)BYTES;
-    }
-    // waits until at most this wave's warm_w of layer C is in flight (loads return in issue order: everything issued BEFORE it has landed)
+    // waits until at most this wave's load_w of layer C is in flight (loads and stores return in issue order: everything issued BEFORE it has completed)
     __device__ static __forceinline__ void wait_all_but_w(int) { ch_wait_vm<2 * SPW>(); }
     // (2a) slot -> byte offset of its pixel in a plane of the input (S3_OOB: padding): a table in LDS, once per item (it depends on the item only: built before the
     // wait for the previous layer) - the region copy below then costs three instructions per piece instead of thirty
@@ -262,7 +251,6 @@ template <> struct ChainOps<ChainNone> {
     struct Item { int tile, oy0, mi; };
     __device__ static __forceinline__ Item item(int) { return Item{0, 0, 0}; }
     __device__ static __forceinline__ void load_w(const ChainLayer&, const Item&, W&, int, int) {}
-    __device__ static __forceinline__ void warm_w(const ChainLayer&, const Item&, uint8_t*, int, int) {}
     __device__ static __forceinline__ void wait_all_but_w(int) { ch_wait_vm<0>(); }
 };
 
