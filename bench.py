@@ -1047,7 +1047,7 @@ def latency_floor(stage_names, stage_flops, stage_us, n_mc, mfma_per_mac, peak_t
             part = part.strip()
             if part.startswith("block_") and part in geo:
                 by += geo[part]
-            elif part.startswith("4_") or part.startswith("3_"):              # "block_4_0+4_1": the second layer of a fused pair
+            elif len(part) == 3 and part[0] in "1234" and part[1] == "_":      # "block_4_0+4_1", "block_2_2+2_3+2_4": the further layers of a fused launch / a tail chain
                 by += geo.get("block_" + part, 0.0)
             elif part.startswith("prep_b"):
                 k = 8 >> (int(part[-1]) - 1)
