@@ -911,13 +911,14 @@ def run(args, ctx, primary):
                 # step's chain runs under the others' kernels.  `value` = that with the FOUR contexts of an hnet_group (round 6: member streams created first, each on its own
                 # priority level - monotone 1 -> 4 contexts and within 4 % over three fresh boxes, profiles/r06_ctx_sweep.log); the one-context figure of rounds 1 - 4 stays beside it.
                 one = sub_run(args, ctx, contexts=1, stage_probe=True, **kw)
+                # (200 steps after 40: a 32 - 64-pair step is 0.2 - 0.35 ms, and the chip needs ~ 30 ms under load to settle its clock - 60 steps read 3 - 5 % low)
                 # (a child process, like the streamed configuration: which hardware queues two streams get depends on every stream the process created before;
                 # after the other sub-runs the in-process figure was 125 k pairs/s where the same command alone gives 174 - 177 k)
-                pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "4", "--steps", "60", "--warmup", "10",
+                pip = child_run(["--variant", kw["variant"], "--batch", str(kw["batch"]), "--mc", str(kw["mc"]), "--contexts", "4", "--steps", "200", "--warmup", "40",
                                  "--precision", str(args.precision), "--no-extras", "--no-cpu-baseline", "--no-latency"])
                 if "error" in pip:
                     err = pip["error"]
-                    pip = sub_run(args, ctx, contexts=4, steps=60, warmup=10, **kw)
+                    pip = sub_run(args, ctx, contexts=4, steps=200, warmup=40, **kw)
                     pip["process"] = "in process (child run failed: " + err + ")"
                 pip["contexts"] = 4
                 pip["single_context"] = {k: one[k] for k in ("value", "ms_per_step", "steps", "max_px_err", "passed", "stage_ms", "stage_kernels") if k in one}
