@@ -33,6 +33,7 @@
 #include <utility>
 #include "igemm_s3.h"
 #include "kernels.h"
+#include "warp_dev.h"
 
 #ifndef HNET_B4_ABLATE
 #define HNET_B4_ABLATE 0          // tools/trace_b4.hip: 1 no phase 2, 2 no phase 1, 3 no global stores, 4 no phase-1 epilogue arithmetic, 5 no leftover M-tiles (wrong results);
@@ -77,6 +78,14 @@ struct B4Cfg {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// WARPIN (round 6): the kernel builds its input patches itself - cat(img1, warp(img2, H)) of model_to_trace.py:261-263 sampled straight into the LDS patch planes -
+// instead of copying them from planes a prep launch wrote: the u8 source box of the NEXT tile's patch under the pair's homography and the patch of img1 are fetched
+// by LDS-DMA (4 bytes per lane, out-of-image positions as out-of-range offsets = zeros) while this tile's phase 1 runs, and sampled between phase 1 and phase 2
+// with the fast sampler of kernels.hip (same arithmetic, same clamps).  Box: B4W_ROWS rows of B4W_PITCH bytes; a patch whose box does not fit, or whose Z is not
+// safely away from 0, takes the exact sampler with direct gathers (as the prep kernel's tiles do).
+constexpr int B4W_PITCH = 128, B4W_ROWS = 64, B4W_I1ROWS = 26;
+constexpr int B4W_LDS_BYTES = (B4W_ROWS + B4W_I1ROWS) * B4W_PITCH;
 
 // the split-bf16 product group: six partial products, smallest first (igemm_s3.h); NP = 1: the plain bf16 product
 template <int NP>
@@ -178,11 +187,12 @@ using s3p::lrelu;
 // REUSE (4-wave geometry): a wave's consecutive phase-1 M-tiles are two region rows apart, so step st of tile j + 1 reads exactly what
 // step st + 1 of tile j read (same lanes, same addresses): the fragments stay in registers and a tile fetches ONE new 32-deep fragment plus
 // its 16-deep tail instead of three plus tail (LDS reads of phase 1: 7 -> 3 ds_read_b64 per plane and tile), prefetched one tile ahead.
-template <int TH1, int THREADS, int NP, bool DMA = false, bool REUSE = false>
+template <int TH1, int THREADS, int NP, bool DMA = false, bool REUSE = false, bool WARPIN = false>
 __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __restrict__ x_in_v, size_t x_plane, const u32x4* __restrict__ w0frag,
                                                                   const float* __restrict__ bias0, const u32x4* __restrict__ w1frag,
                                                                   const float* __restrict__ bias1, uint16_t* __restrict__ out16,
-                                                                  size_t o_plane, int n_tiles, int flags) {
+                                                                  size_t o_plane, int n_tiles, int flags, B4Warp wp = B4Warp{}) {
+    static_assert(!WARPIN || (DMA && NP == 2), "the sampling form replaces the LDS-DMA patch copy of the fp16-plane mode");
     using namespace b4v3;
     typedef B4Cfg<TH1, THREADS, NP, DMA> C;
     const float* const x_in = reinterpret_cast<const float*>(x_in_v);
@@ -338,8 +348,115 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                                                  (void __attribute__((address_space(3)))*)(lds_raw + k * 1024), 16, 0, 0);
         }
     };
+    // ---- WARPIN: box geometry + LDS-DMA issue for the patch of tile t (everything wave-uniform), and the sampling of that patch
+    unsigned char* const wbox = lds_raw + C::LDS_BYTES;                       // [B4W_ROWS][B4W_PITCH] u8: img2's box
+    unsigned char* const wi1 = wbox + B4W_ROWS * B4W_PITCH;                    // [B4W_I1ROWS][B4W_PITCH] u8: img1, patch row r, byte pc + 3
+    [[maybe_unused]] float wh[9];
+    [[maybe_unused]] int w_gx0 = 0, w_ry0 = 0, w_pitch = 0, w_rows = 0, w_b = 0, w_iy0 = 0, w_ix0 = 0;
+    [[maybe_unused]] bool w_fast = false;
+    [[maybe_unused]] auto warp_issue = [&](int t) {
+        int nb, nby, nbx;
+        tile_origin(t, nb, nby, nbx);
+        w_b = nb; w_iy0 = 2 * nby * TH1 - 5; w_ix0 = 64 * nbx - 5;           // image pixel of patch pixel (0, 0)
+#pragma unroll
+        for (int i = 0; i < 9; i++) wh[i] = wp.H[nb * 9 + i];
+        // bounding box of the taps: the four warped corners of the patch clipped to the image (a projective map with Z of one sign takes the rectangle to a convex
+        // quadrilateral), exactly as warp_stage_box of kernels.hip: lane c of the first quad evaluates corner c
+        const int y0c = max(w_iy0, 0), y1c = min(w_iy0 + PH0 - 1, H0 - 1), x0c = max(w_ix0, 0), x1c = min(w_ix0 + PW0 - 1, W0 - 1);
+        const int c = lane & 3;
+        float cx, cy, Z;
+        warp_coords(wh, (c & 1) ? x1c : x0c, (c >> 1) ? y1c : y0c, cx, cy, Z);
+        const unsigned quad0 = 0xFu;
+        const bool pos = ((unsigned)__ballot(Z > 0.0f) & quad0) == quad0;
+        const bool neg = ((unsigned)__ballot(Z < 0.0f) & quad0) == quad0;
+        const bool zs = ((unsigned)__ballot(warp_z_safe(Z)) & quad0) == quad0;
+        const bool finite = ((unsigned)__ballot(fabsf(cx) < 1.0e6f && fabsf(cy) < 1.0e6f) & quad0) == quad0;
+        const float lo_x = uniform_f(quad_min(cx)), hi_x = uniform_f(quad_max(cx));
+        const float lo_y = uniform_f(quad_min(cy)), hi_y = uniform_f(quad_max(cy));
+        const bool ok = (pos || neg) && finite;
+        const int rx0 = max((int)floorf(ok ? lo_x : 0.0f) - 1, -1), rx1 = min((int)floorf(ok ? hi_x : 0.0f) + 2, W0 + 1);
+        const int ry0 = max((int)floorf(ok ? lo_y : 0.0f) - 1, -1), ry1 = min((int)floorf(ok ? hi_y : 0.0f) + 2, H0 + 1);
+        w_gx0 = (rx0 + 4) / 4 * 4 - 4;
+        w_ry0 = ry0;
+        w_pitch = rx1 >= rx0 ? (rx1 - w_gx0 + 4) / 4 * 4 : 0;
+        w_rows = ry1 >= ry0 ? ry1 - ry0 + 1 : 0;
+        w_fast = ok && zs && w_pitch <= B4W_PITCH && w_rows <= B4W_ROWS && w_rows >= 2 && w_pitch >= 2;
+        typedef void __attribute__((address_space(3)))* lds_p;
+        const int hrow = lane >> 5, cc = lane & 31;
+        if (w_fast) {
+            const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(wp.img2 + (size_t)nb * (H0 * W0)), 0, H0 * W0, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < B4W_ROWS / 2 / WAVES; k++) {
+                const int rp = wave + WAVES * k;                             // pair of box rows (wave-uniform)
+                if (2 * rp < w_rows) {
+                    const int r = 2 * rp + hrow, y = w_ry0 + r, x = w_gx0 + 4 * cc;     // x is a multiple of 4: the four pixels are all in or all out
+                    const bool in = r < w_rows && 4 * cc < w_pitch && (unsigned)y < (unsigned)H0 && (unsigned)x < (unsigned)W0;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_p)(wbox + rp * 256), 4, in ? (uint32_t)(y * W0 + x) : S3_OOB, 0, 0, 0);
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(wp.img1 + (size_t)nb * (H0 * W0)), 0, H0 * W0, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (B4W_I1ROWS / 2 + WAVES - 1) / WAVES; k++) {
+            const int rp = wave + WAVES * k;
+            if (rp < B4W_I1ROWS / 2) {
+                const int r = 2 * rp + hrow, y = w_iy0 + r, x = w_ix0 - 3 + 4 * cc;     // 64 nbx - 8: a multiple of 4
+                const bool in = r < PH0 && cc < (PW0 + 3 + 3) / 4 && (unsigned)y < (unsigned)H0 && (unsigned)x < (unsigned)W0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_p)(wi1 + rp * 256), 4, in ? (uint32_t)(y * W0 + x) : S3_OOB, 0, 0, 0);
+            }
+        }
+    };
+    [[maybe_unused]] auto warp_sample = [&]() {
+        // = the fast branch of prep_warp_tiled_kernel (kernels.hip) pixel for pixel: X, Y, Z by the same FMAs, one shared reciprocal + Newton step, the position clamped
+        // to the box (which acts only where the box was clipped to the frame: the zero padding), three interpolations; the pair (img1, warped img2) split into the two
+        // fp16 planes as the prep kernel's stores did.  Patch pixels outside the image are zeros (block_4_0's padding).
+        const float bx_lo = (float)max(w_gx0, -1), bx_hi = (float)min(w_gx0 + w_pitch - 2, W0);
+        const float by_lo = (float)max(w_ry0, -1), by_hi = (float)min(w_ry0 + w_rows - 2, H0);
+        const int ibase = -(w_ry0 * B4W_PITCH + w_gx0);
+        const uint8_t* i2b = wp.img2 + (size_t)w_b * (H0 * W0);
+#pragma unroll 2
+        for (int q = 0; q < (PH0 * PW0 + THREADS - 1) / THREADS; q++) {
+            const int i = tid + q * THREADS;
+            if (i < PH0 * PW0) {
+                const int pr = i / PW0, pc = i - pr * PW0;
+                const int iy = w_iy0 + pr, ix = w_ix0 + pc;
+                const bool inside = (unsigned)iy < (unsigned)H0 && (unsigned)ix < (unsigned)W0;
+                const float a = u8_to_unit((float)wi1[pr * B4W_PITCH + pc + 3]);
+                float w;
+                if (w_fast) {                                                // workgroup-uniform
+                    const float fu = (float)ix, fv = (float)iy;
+                    const float X = fmaf(wh[1], fv, fmaf(wh[0], fu, wh[2])), Y = fmaf(wh[4], fv, fmaf(wh[3], fu, wh[5])), Z = fmaf(wh[7], fv, fmaf(wh[6], fu, wh[8]));
+                    const float r0 = __builtin_amdgcn_rcpf(Z);
+                    const float r1 = fmaf(fmaf(-Z, r0, 1.0f), r0, r0);
+                    const float sx = __builtin_amdgcn_fmed3f(X * r1, bx_lo, bx_hi), sy = __builtin_amdgcn_fmed3f(Y * r1, by_lo, by_hi);
+                    const float x0f = floorf(sx), y0f = floorf(sy);
+                    const float wx1 = sx - x0f, wy1 = sy - y0f;
+                    const int e = (int)fmaf(y0f, (float)B4W_PITCH, x0f) + ibase;
+                    const float t0 = u8_to_unit((float)wbox[e]), t1 = u8_to_unit((float)wbox[e + 1]);
+                    const float t2 = u8_to_unit((float)wbox[e + B4W_PITCH]), t3 = u8_to_unit((float)wbox[e + B4W_PITCH + 1]);
+                    const float top = fmaf(wx1, t1 - t0, t0), bot = fmaf(wx1, t3 - t2, t2);
+                    w = fmaf(wy1, bot - top, top);
+                } else {                                                     // rare: the exact sampler, taps gathered from memory
+                    float sx, sy, Z;
+                    warp_coords<false>(wh, inside ? ix : 0, inside ? iy : 0, sx, sy, Z);
+                    w = warp_taps_global<uint8_t, false>(i2b, sx, sy, nullptr);
+                }
+                uint32_t pk[3];
+                split_pair<NP>(inside ? a : 0.0f, inside ? w : 0.0f, pk);
+                const int pe = pr * PROW0 + pc * 2;
+#pragma unroll
+                for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + pe]) = pk[pl];
+            }
+        }
+    };
     if ((int)blockIdx.x < n_tiles) {
-        if constexpr (DMA) dma_issue(blockIdx.x);
+        if constexpr (WARPIN) {
+            warp_issue(blockIdx.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            warp_sample();                                   // (made visible by the barrier at the top of the tile loop)
+        } else if constexpr (DMA) dma_issue(blockIdx.x);
         else patch_load(blockIdx.x);
     }
     const uint32_t gv = (uint32_t)(m * 32 + g * 8);          // DMA: byte offset of this lane's 8-byte piece in a 16-pixel output run
@@ -356,9 +473,13 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
 
         if constexpr (DMA) {
             // ---- phase 0: this wave's share of the patch copy has landed (it ran under phase 2 of the previous tile) ...
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if constexpr (WARPIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the patch was written by LDS stores (the stores of phase 2 stay in flight)
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // ... and everybody else's; the previous tile's phase 2 is done with the image
             asm volatile("" ::: "memory");
+            if constexpr (WARPIN) {
+                if (tile + (int)gridDim.x < n_tiles) warp_issue(tile + gridDim.x);   // box + img1 of the NEXT tile's patch: in flight during phase 1
+            }
             B4_T(1);
         } else {
             // ---- phase 0: prefetched patch -> bf16 planes in LDS
@@ -613,6 +734,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's asm ds_writes (the barrier's own wait does not count them)
         B4_T(3);
         if constexpr (DMA) {
+            if constexpr (WARPIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next patch's box has landed (issued a phase 1 ago)
             __builtin_amdgcn_s_barrier();                    // raw barrier: a __syncthreads() would also drain the stores of phase 2
             asm volatile("" ::: "memory");
             B4_T(4);
@@ -665,7 +787,9 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
                 }
             }
 #else
-            if (tile + (int)gridDim.x < n_tiles) dma_issue(tile + gridDim.x);    // the patch is dead: the next tile's copy runs under phase 2
+            if constexpr (WARPIN) {
+                if (tile + (int)gridDim.x < n_tiles) warp_sample();              // the patch is dead: the next tile's is sampled into it
+            } else if (tile + (int)gridDim.x < n_tiles) dma_issue(tile + gridDim.x);    // the patch is dead: the next tile's copy runs under phase 2
 #endif
         } else {
             __syncthreads();

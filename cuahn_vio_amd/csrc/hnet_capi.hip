@@ -146,6 +146,8 @@ struct hnet_ctx {
     size_t ws_floats = 0;
     // round 6: the tail of every block (its last 2 - 3 stride-2 layers) of a batch <= 8 as ONE launch on one XCD (chain_lat.h); fp16-plane mode, variant bit NO_CHAIN = off
     bool use_chain = false;
+    bool b4_in_stale = false;          // the last forward's block 4 sampled its input in-kernel: x16_b4 does not hold it (hnet_debug_layer_output(13) refuses)
+    bool warp_in = false;              // batch > 8: block 4's warp + concat sampled inside the block_4_0 + block_4_1 kernel (conv_b4_fused.h WARPIN) - no prep_b4 launch
     int chain_grid = 256;              // workgroups of a chain launch (one per CU; HNET_VARIANT_CHAIN_GRID_8 / _3: the tests' small grids)
     uint16_t* chain_w[20] = {};        // the chain layers' weights as MFMA fragments (chain_pack_weights)
     ChainArgs chain_args[4] = {};      // one argument block per block's chain (passed by value)
@@ -283,9 +285,15 @@ std::vector<float> permute_fc(const float* w, int n_out) {
     return out;
 }
 
+// block 4 of a forward of `batch` pairs samples its own input (no prep_b4 launch); prev == nullptr: images unknown yet - the usual case (4-byte aligned u8) is assumed
+static bool b4_warp_in(const hnet_ctx* c, int batch, const void* prev, const void* curr, int pix_fmt) {
+    if (!c->warp_in || !c->fuse_b4 || !c->x16_b4 || c->n_planes != 2 || (c->fuse_small && batch <= 8)) return false;
+    return prev ? block4_warp_in_supported(prev, curr, pix_fmt == HNET_PIX_U8, c->n_planes) : true;
+}
+
 // the launches of one forward of `batch` pairs, in order (what the STAGE macro of forward_chunk records events for): the latency path
 // (batch <= 8) has fewer of them
-void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void* curr = nullptr) {      // (image pointers: forward_chunk fuses the block tail into a prep launch only for 16-byte-aligned images)
+void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void* curr = nullptr, int pix_fmt = HNET_PIX_U8) {      // (image pointers: forward_chunk fuses the block tail into a prep launch only for 16-byte-aligned images)
     c->stages.clear();
     const hnet_config& g = c->cfg;
     auto conv_flops = [&](int l, int h, int w) {
@@ -303,6 +311,7 @@ void build_stages(hnet_ctx* c, int batch, const void* prev = nullptr, const void
     for (int blk = fb; blk < 4; blk++) {
         const bool fused_prep = pend && (prev ? prep_fc_supported(prev, curr, 8 >> blk, blk == 3 && c->x16_b4 != nullptr) : (blk < 3 || c->x16_b4 != nullptr));
         if (pend && !fused_prep) c->stages.push_back({blk == fb && g.use_prior ? "prior_dlt" : "fc_dlt_b" + std::to_string(blk), blk == fb && g.use_prior ? 0.0 : 2.0 * 8 * 5120});
+        if (!(blk == 3 && !pend && b4_warp_in(c, batch, prev, curr, pix_fmt)))       // (block 4 of a large batch samples its input itself: conv_b4_fused.h WARPIN)
         c->stages.push_back({std::string(fused_prep ? (blk == fb && g.use_prior ? "prior_dlt+" : "fc_dlt+") : "") + "prep_b" + std::to_string(blk + 1),
                              fused_prep && !(blk == fb && g.use_prior) ? 2.0 * 8 * 5120 : 0.0});
         pend = false;
@@ -427,6 +436,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         float* x = c->x_in[blk] + P0 * h * w * 2;
         const bool b4_dma = blk == 3 && c->x16_b4 != nullptr;      // block 4 always warps (:261): the prep kernel writes the padded planes
         uint32_t* x16 = b4_dma ? c->x16_b4 + P0 * B4_HP * B4_WP : nullptr;
+        B4Warp b4w = {};
+        bool b4w_on = false;
+        if (blk == 3) c->b4_in_stale = false;
         if (have_pend) {
             if (prep_fc_supported(a.prev, a.curr, 8 >> blk, x16 != nullptr)) {
                 pend.H_out = pend.feat ? Hnext : Hcur;                                // the prior's DLT has no input homography: it may land in Hcur
@@ -445,6 +457,10 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, Hcur, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
             }
             have_pend = false;
+        } else if (blk == 3 && b4_warp_in(c, B, a.prev, a.curr, a.pix_fmt)) {
+            b4w = B4Warp{(const uint8_t*)a.prev, (const uint8_t*)a.curr, Hcur};          // no launch: block_4_0 + block_4_1 samples cat(img1, warp(img2, H)) itself
+            b4w_on = true;
+            c->b4_in_stale = true;
         } else {
             STAGE(launch_prep(a.prev, a.curr, a.pix_fmt, warp ? Hcur : nullptr, 8 >> blk, x, B, s, x16, c->x16_plane, c->n_planes, c->warp_exact));
         }
@@ -471,7 +487,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 const size_t cnt1 = c->a14_pad ? B42_IMG * 16 : c->act_count[14];
                 uint16_t* o16 = c->act16[14] + P0 * cnt1;
                 STAGE(launch_block4_fused(b4_dma ? (const void*)x16 : (const void*)in, c->x16_plane, c->b40_frag, c->conv_b[13], c->b41_frag, c->conv_b[14], o16,
-                                          MB * cnt1, B, s, c->b4_flags | (c->a14_pad ? 64 : 0), c->n_planes));
+                                          MB * cnt1, B, s, c->b4_flags | (c->a14_pad ? 64 : 0), c->n_planes, b4w_on ? &b4w : nullptr));
                 in = nullptr; in16 = o16; in_plane = MB * cnt1;
                 h = c->act_h[14]; w = c->act_w[14];
                 l = 14;
@@ -871,7 +887,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     g.struct_size = sizeof(g);
     if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
     if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
-    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3)) return HNET_ERR_INVALID_ARG;
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_NO_WARP_FUSE)) return HNET_ERR_INVALID_ARG;
     {
         const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
         static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
@@ -1028,6 +1044,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     // the one-XCD tail chains of the latency path (chain_lat.h): default mode only; variant 30 (the round-4 latency path) and NO_CHAIN keep the launches
     c->use_chain = c->n_planes == 2 && c->fuse_small && c->lat_tail && !(g.variant & HNET_VARIANT_NO_CHAIN);
     c->chain_grid = (g.variant & HNET_VARIANT_CHAIN_GRID_3) ? 3 : (g.variant & HNET_VARIANT_CHAIN_GRID_8) ? 8 : 256;
+    // block 4's warp + concat inside the block_4_0 + block_4_1 kernel (batch > 8): fp16-plane mode with the fast sampler (HNET_WARP_EXACT keeps the prep launch)
+    c->warp_in = c->n_planes == 2 && c->fuse_b4 && c->x16_b4 && !c->warp_exact && !(g.variant & HNET_VARIANT_NO_WARP_FUSE);
     if (c->use_chain) {
         CK(hipMalloc((void**)&c->chain_sync, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
         CK(hipMemset(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
@@ -1406,6 +1424,7 @@ static int demote_to_bf16x3(hnet_ctx* c) {
     if (!parse_blob(c->blob_copy.data(), c->blob_copy.size(), b)) return fail(c, HNET_ERR_BAD_WEIGHTS, "weight blob");
     c->n_planes = 3;
     c->use_chain = false;
+    c->warp_in = false;
     c->fuse_b3 = c->fuse_b42 = c->a14_pad = false;    // the fused block-3 / block_4_2+4_3 kernels exist for the fp16 planes only (their layers' buffers stay allocated; act16[14] goes back to the plain layout)
     c->cfg.precision = HNET_PREC_BF16X3;
     const int rc = upload_weights(c, b);
@@ -1727,7 +1746,7 @@ int hnet_profile_batch_device(hnet_ctx* c, const void* d_prev, const void* d_cur
                               uint64_t pair_seq0, float* d_mean, float* d_cov, int iters, float* stage_ms_avg) {
     if (!c || iters < 1 || !stage_ms_avg) return HNET_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    build_stages(c, batch, d_prev, d_curr);   // the launches of a forward of THIS batch and THESE images (the latency path has fewer): hnet_stage_name follows
+    build_stages(c, batch, d_prev, d_curr, pix_fmt);   // the launches of a forward of THIS batch and THESE images (the latency path has fewer): hnet_stage_name follows
     const size_t ns = c->stages.size();
     std::vector<double> acc(ns, 0.0);
     // the per-stage events live in the context only for the duration of this call: whatever happens, they are destroyed
@@ -1939,6 +1958,7 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     float* d_t = nullptr;
     HIPCHK(c, t.alloc(&d_t, n));
     if (c->fuse_b4 && layer == 13) {   // the fused kernel keeps block_4_0's output in LDS: recompute it unfused for inspection
+        if (c->b4_in_stale) return fail(c, HNET_ERR_UNSUPPORTED, "layer 13 of a batch > 8: block 4 sampled its input in-kernel (inspect it on a context with HNET_VARIANT_NO_WARP_FUSE)");
         uint16_t* tmp = nullptr;
         HIPCHK(c, t.alloc(&tmp, 3 * n));
         const float* xin = c->x_in[3] + (size_t)pair * NPIX * 2;

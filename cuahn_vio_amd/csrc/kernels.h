@@ -59,8 +59,14 @@ hipError_t launch_conv_first_s2(int layer, const float* x_in, const void* wfrag,
                                 hipStream_t s, int n_planes = 3);
 // block_4_0 + block_4_1 in one launch (conv_b4_fused.h): x_in = the padded 16-bit planes B4_* below (x_plane dwords per plane)
 // flags: bit 0 walk the tiles from the end, bit 4 plain tile order, bit 5 the 7 x 32 tiles of rounds 2 - 3, bit 6 write the bordered B42_* layout (fp16-plane mode)
+// warp != nullptr (fp16-plane mode, u8 images, 4-byte aligned): the kernel samples cat(img1, warp(img2, H)) itself and x_in is not read (conv_b4_fused.h WARPIN, round 6)
+struct B4Warp { const uint8_t* img1; const uint8_t* img2; const float* H; };
+inline bool block4_warp_in_supported(const void* img1, const void* img2, int pix_fmt_is_u8, int n_planes) {
+    return pix_fmt_is_u8 && n_planes == 2 && ((((uintptr_t)img1 | (uintptr_t)img2) & 3) == 0);
+}
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */, int n_planes = 3);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags = 0 /* bit 0: reverse tile walk */, int n_planes = 3,
+                               const B4Warp* warp = nullptr);
 // block_3_0 + block_3_1 in one launch (conv_b3_fused.h), fp16-plane mode (n_planes == 2) only: x_in fp32 NHWC [B][112][160][2] (the block's prep output),
 // w0frag [7][2][64] x 16 B, w1frag [2][13][2][64] x 16 B (packed by hnet_create), out16 [2][B][56][80][32]
 hipError_t launch_block3_fused(const float* x_in, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1, uint16_t* out16,

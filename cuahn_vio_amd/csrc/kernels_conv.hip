@@ -138,8 +138,8 @@ hipError_t conv_kernels_init_device() {
 #define HNET_NP(fn, ...) (n_planes == 1 ? fn<1>(__VA_ARGS__) : n_planes == 2 ? fn<2>(__VA_ARGS__) : fn<3>(__VA_ARGS__))
 
 hipError_t launch_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int n_planes) {
-    return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+                               uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, int n_planes, const B4Warp* warp) {
+    return HNET_NP(launch_block4_fused_np, x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags, warp);
 }
 
 hipError_t launch_block42_fused(const uint16_t* in16, size_t i_plane, const void* w2frag, const float* bias2, const void* w3frag, const float* bias3,

@@ -171,23 +171,31 @@ static hipError_t run_conv_s3(const S3Params& p, hipStream_t s, float* ws, size_
 // (8 x 32 / 512 threads, fp32 input without DMA, no fragment reuse and the v2 kernel were removed in round 4; DESIGN.md section 3.4 keeps the table)
 template <int TH1, int NP>
 static hipError_t run_block4_fused(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
+                                   uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, const B4Warp* warp = nullptr) {
     typedef B4Cfg<TH1, 256, NP, true> C;
     const int n_tiles = batch * (112 / C::TH1) * (160 / C::TW1);
     const int per_cu = std::max(1, std::min(2, std::min(2048 / 256, (160 * 1024) / C::LDS_BYTES)));   // two waves per SIMD (launch bounds)
     const unsigned blocks = (unsigned)std::min(n_tiles, 256 * per_cu);        // persistent
+    if constexpr (NP == 2 && TH1 == 8) {
+        static_assert(2 * (C::LDS_BYTES + B4W_LDS_BYTES) <= 160 * 1024, "two workgroups per CU with the warp box");
+        if (warp) {                                                           // the kernel samples its own patches (conv_b4_fused.h WARPIN): x_in is not read
+            hipLaunchKernelGGL((block4_fused_kernel<TH1, 256, NP, true, true, true>), dim3(blocks), dim3(256), C::LDS_BYTES + B4W_LDS_BYTES, s, x_in, x_plane,
+                               (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags, *warp);
+            return hipGetLastError();
+        }
+    } else if (warp) return hipErrorInvalidValue;
     hipLaunchKernelGGL((block4_fused_kernel<TH1, 256, NP, true, true>), dim3(blocks), dim3(256), C::LDS_BYTES, s, x_in, x_plane,
-                       (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags);
+                       (const u32x4*)w0frag, bias0, (const u32x4*)w1frag, bias1, out16, o_plane, n_tiles, flags, B4Warp{});
     return hipGetLastError();
 }
 template <int NP>
 hipError_t launch_block4_fused_np(const void* x_in, size_t x_plane, const void* w0frag, const float* bias0, const void* w1frag, const float* bias1,
-                                  uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags) {
+                                  uint16_t* out16, size_t o_plane, int batch, hipStream_t s, int flags, const B4Warp* warp) {
     flags &= 113;
     // fp16-plane mode: 8 x 32 tiles (57 KB of LDS: still two workgroups per CU; 16 phase-2 M-tiles = four per wave exactly, 19 / 16 rows of halo instead of 17 / 14).
     // (the 7 x 32 tiles of rounds 2 - 3 remain the tile of the three-plane modes, which need them for two workgroups per CU)
-    if constexpr (NP == 2) return run_block4_fused<8, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags & ~32);
-    else return run_block4_fused<7, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
+    if constexpr (NP == 2) return run_block4_fused<8, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags & ~32, warp);
+    else return warp ? hipErrorInvalidValue : run_block4_fused<7, NP>(x_in, x_plane, w0frag, bias0, w1frag, bias1, out16, o_plane, batch, s, flags);
 }
 
 // block_3_0 + block_3_1 in one kernel (conv_b3_fused.h; fp16-plane mode only): x_in fp32 [B][112][160][2] -> out16 fp16 planes [2][B][56][80][32]
@@ -440,7 +448,7 @@ hipError_t conv_kernels_init_device_np() {
 // the explicit instantiations live in kernels_conv.hip (NP = 3), kernels_conv_bf16.hip (NP = 1) and kernels_conv_f16x2.hip (NP = 2)
 #define HNET_S3_DISPATCH_INSTANCES(KW, NP)                                                                                               \
     KW template hipError_t launch_block4_fused_np<NP>(const void*, size_t, const void*, const float*, const void*, const float*,         \
-                                                      uint16_t*, size_t, int, hipStream_t, int);                                         \
+                                                      uint16_t*, size_t, int, hipStream_t, int, const B4Warp*);                          \
     KW template hipError_t launch_block42_fused_np<NP>(const uint16_t*, size_t, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_block3_fused_np<NP>(const float*, const void*, const float*, const void*, const float*, uint16_t*, size_t, int, hipStream_t); \
     KW template hipError_t launch_conv_first_s3_np<NP>(const float*, const void*, const float*, uint16_t*, size_t, int, int, int, hipStream_t); \

@@ -31,7 +31,7 @@ IGNORE_ENV = False      # bench.py sets this (unless --honour-env): engines are 
 
 def env_overrides():
     """the HNET_* variables of this process that kernel_selection_from_env / HnetEngine would map onto hnet_config (what bench.py lists in `env_overrides`)"""
-    names = ("HNET_S3_TILE", "HNET_FUSE_SMALL", "HNET_FUSE_B3", "HNET_FUSE_B42", "HNET_CHAIN", "HNET_CHAIN_GRID", "HNET_GRAPH", "HNET_WARP_EXACT", "HNET_PRECISION")
+    names = ("HNET_S3_TILE", "HNET_FUSE_SMALL", "HNET_FUSE_B3", "HNET_FUSE_B42", "HNET_CHAIN", "HNET_CHAIN_GRID", "HNET_WARP_FUSE", "HNET_GRAPH", "HNET_WARP_EXACT", "HNET_PRECISION")
     return {n: os.environ[n] for n in names if n in os.environ}
 
 
@@ -53,6 +53,8 @@ def kernel_selection_from_env():
         variant |= 1 << 11
     if env("HNET_CHAIN_GRID", "") in ("8", "3"):      # tests: the chain launches with 8 / 3 workgroups (HNET_VARIANT_CHAIN_GRID_*)
         variant |= (1 << 12) if env("HNET_CHAIN_GRID") == "8" else (1 << 13)
+    if env("HNET_WARP_FUSE", "1") == "0":   # block 4's warp + concat as a launch of its own (include/hnet.h HNET_VARIANT_NO_WARP_FUSE)
+        variant |= 1 << 14
     graph = {"0": 1, "1": 2}.get(env("HNET_GRAPH", ""), 0)
     return int(env("HNET_WARP_EXACT", "0") != "0"), graph, variant
 

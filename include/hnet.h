@@ -97,7 +97,9 @@ enum {
                                                   (csrc/chain_lat.h; fp16-plane mode; same arithmetic, another summation order: results agree to fp32 rounding) */
     HNET_VARIANT_CHAIN_GRID_8 = 1u << 12,     /* tests: the chain launches with 8 workgroups instead of 256 (fewer resident workgroups than items: every workgroup works
                                                   through several items of a layer) and */
-    HNET_VARIANT_CHAIN_GRID_3 = 1u << 13      /* with 3 (XCDs without a workgroup: pairs are picked up by whoever is done) - the same bits as the 256-workgroup launch */
+    HNET_VARIANT_CHAIN_GRID_3 = 1u << 13,     /* with 3 (XCDs without a workgroup: pairs are picked up by whoever is done) - the same bits as the 256-workgroup launch */
+    HNET_VARIANT_NO_WARP_FUSE = 1u << 14      /* batch > 8: block 4's warp + concat as a launch of its own that writes the padded fp16 planes, instead of being sampled inside
+                                                  the block_4_0 + block_4_1 kernel (csrc/conv_b4_fused.h WARPIN, round 6; fp16-plane mode, u8 images; same sampler, same bits) */
 };
 
 typedef struct hnet_ctx hnet_ctx;
