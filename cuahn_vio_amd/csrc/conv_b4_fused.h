@@ -36,9 +36,8 @@
 #include "warp_dev.h"
 
 #ifndef HNET_B4_ABLATE
-#define HNET_B4_ABLATE 0          // tools/trace_b4.hip: 1 no phase 2, 2 no phase 1, 3 no global stores, 4 no phase-1 epilogue arithmetic, 5 no leftover M-tiles (wrong results);
-                                  // 6 / 7 (round 6, timing only): the next tile's patch is SAMPLED in the kernel instead of copied (7: the arithmetic, LDS reads and patch stores alone) - the vector / LDS work of folding
-                                  // prep_b4 (warp + concat + plane split) into the patch staging, VERDICT r5 item 4 (profiles/r06_experiments_not_shipped.log item 12)
+#define HNET_B4_ABLATE 0          // tools/trace_b4.hip: 1 no phase 2, 2 no phase 1, 3 no global stores, 4 no phase-1 epilogue arithmetic, 5 no leftover M-tiles (wrong results)
+                                  // (6 / 7 of round 6 - timing-only stand-ins for in-kernel sampling - were replaced by the real thing: the WARPIN instantiation below)
 #endif
 
 namespace hnet {
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
     const uint32_t gv = (uint32_t)(m * 32 + g * 8);          // DMA: byte offset of this lane's 8-byte piece in a 16-pixel output run
 
     [[maybe_unused]] int tile_no = -1;
-    [[maybe_unused]] unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_prev = 0;
+    [[maybe_unused]] unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_prev = 0;      // (6: WARPIN sampling, 7: WARPIN box geometry + DMA issue)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_no++;
         B4_T(0);
@@ -478,8 +477,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
             __builtin_amdgcn_s_barrier();                    // ... and everybody else's; the previous tile's phase 2 is done with the image
             asm volatile("" ::: "memory");
             if constexpr (WARPIN) {
+                B4_T(1);
                 if (tile + (int)gridDim.x < n_tiles) warp_issue(tile + gridDim.x);   // box + img1 of the NEXT tile's patch: in flight during phase 1
-            }
+                B4_T(7);
+            } else
             B4_T(1);
         } else {
             // ---- phase 0: prefetched patch -> bf16 planes in LDS
@@ -738,59 +739,10 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
             __builtin_amdgcn_s_barrier();                    // raw barrier: a __syncthreads() would also drain the stores of phase 2
             asm volatile("" ::: "memory");
             B4_T(4);
-#if HNET_B4_ABLATE == 6 || HNET_B4_ABLATE == 7
-            // what a fused warp would do for the NEXT tile's patch ((2 TH1 + 9) x 80 pixels), per thread ~ 8 pixels: the source box of img2 (u8) into LDS, img1's
-            // pixel from memory, a projective map with a shared reciprocal + Newton step, four taps from the box, the blend, the two-channel fp16 plane split, two
-            // LDS stores into the patch planes.  Timing only: the image pointers alias the input planes, the box lives in the output-staging bytes, results are garbage.
-            if (tile + (int)gridDim.x < n_tiles) {
-                int nb, nby, nbx;
-                tile_origin(tile + gridDim.x, nb, nby, nbx);
-                const unsigned char* im = reinterpret_cast<const unsigned char*>(x_in_v) + (size_t)nb * (H0 * W0) + (size_t)(2 * nby * TH1) * W0 + 64 * nbx;
-                float* boxf = reinterpret_cast<float*>(lds_raw) + NP * PPLANE / 2;          // (28 x 96 floats behind the patch planes' first half: timing only)
-                // box: 28 rows x 96 columns of u8 -> f32: 2 688 pixels, 10.5 per thread
-                // (ablation 7: no box copy, no barrier, img1 not read - the sampling arithmetic, its LDS reads and the patch stores alone: a LOWER bound of the fused form)
-#if HNET_B4_ABLATE == 6
-#pragma unroll
-                for (int q = 0; q < 11; q++) {
-                    const int i = tid + q * THREADS;
-                    if (i < 28 * 96) boxf[i] = (float)im[(i / 96) * W0 + (i % 96)] * (1.0f / 255.0f);
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-#endif
-                const float h0 = 1.001f, h1 = 0.002f, h2 = 1.5f, h3 = -0.001f, h4 = 0.999f, h5 = 2.25f, h6 = 1e-6f, h7 = -2e-6f, h8 = 1.0f;
-                constexpr int NPX = PH0 * PW0;
-#pragma unroll
-                for (int q = 0; q < (NPX + THREADS - 1) / THREADS; q++) {
-                    const int i = min(tid + q * THREADS, NPX - 1);
-                    const int pr = i / PW0, pc = i - pr * PW0;
-#if HNET_B4_ABLATE == 6
-                    const float a = (float)im[(size_t)pr * W0 + pc] * (1.0f / 255.0f);            // img1's pixel
-#else
-                    const float a = (float)(pr + pc) * (1.0f / 255.0f);
-#endif
-                    const float fu = (float)pc, fv = (float)pr;
-                    const float X = fmaf(h0, fu, fmaf(h1, fv, h2)), Y = fmaf(h3, fu, fmaf(h4, fv, h5)), Z = fmaf(h6, fu, fmaf(h7, fv, h8));
-                    float rz = __builtin_amdgcn_rcpf(Z);
-                    rz = fmaf(fmaf(-Z, rz, 1.0f), rz, rz);
-                    const float sx = X * rz, sy = Y * rz;
-                    const float x0 = floorf(sx), y0 = floorf(sy), wx = sx - x0, wy = sy - y0;
-                    const int e = min(max((int)y0, 0), 26) * 96 + min(max((int)x0, 0), 94);
-                    const float t00 = boxf[e], t01 = boxf[e + 1], t10 = boxf[e + 96], t11 = boxf[e + 97];
-                    const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
-                    const float w = fmaf(wy, bot - top, top);
-                    uint32_t pk[3];
-                    split_pair<NP>(a, w, pk);
-                    const int pe = pr * PROW0 + pc * 2;
-#pragma unroll
-                    for (int pl = 0; pl < NP; pl++) *reinterpret_cast<uint32_t*>(&patch[pl * PPLANE + pe]) = pk[pl];
-                }
-            }
-#else
             if constexpr (WARPIN) {
                 if (tile + (int)gridDim.x < n_tiles) warp_sample();              // the patch is dead: the next tile's is sampled into it
+                B4_T(6);
             } else if (tile + (int)gridDim.x < n_tiles) dma_issue(tile + gridDim.x);    // the patch is dead: the next tile's copy runs under phase 2
-#endif
         } else {
             __syncthreads();
         }
@@ -883,8 +835,8 @@ __global__ __launch_bounds__(THREADS, 2) void block4_fused_kernel(const void* __
         B4_T(5);
     }   // persistent tile loop
 #ifdef HNET_B4_TRACE
-    if (blockIdx.x < 8 && lane == 0) for (int k = 0; k < 6; k++) g_b4_trace[(blockIdx.x * 4 + wave) * 7 + k] = tr_acc[k];
-    if (blockIdx.x < 8 && lane == 0) g_b4_trace[(blockIdx.x * 4 + wave) * 7 + 6] = (unsigned long long)(tile_no - 1);
+    if (blockIdx.x < 8 && lane == 0) for (int k = 0; k < 8; k++) g_b4_trace[(blockIdx.x * 4 + wave) * 9 + k] = tr_acc[k];
+    if (blockIdx.x < 8 && lane == 0) g_b4_trace[(blockIdx.x * 4 + wave) * 9 + 8] = (unsigned long long)(tile_no - 1);
 #endif
 }
 

@@ -887,7 +887,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     g.struct_size = sizeof(g);
     if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
     if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
-    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_NO_WARP_FUSE)) return HNET_ERR_INVALID_ARG;
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_WARP_FUSE)) return HNET_ERR_INVALID_ARG;
     {
         const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
         static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
@@ -1044,8 +1044,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     // the one-XCD tail chains of the latency path (chain_lat.h): default mode only; variant 30 (the round-4 latency path) and NO_CHAIN keep the launches
     c->use_chain = c->n_planes == 2 && c->fuse_small && c->lat_tail && !(g.variant & HNET_VARIANT_NO_CHAIN);
     c->chain_grid = (g.variant & HNET_VARIANT_CHAIN_GRID_3) ? 3 : (g.variant & HNET_VARIANT_CHAIN_GRID_8) ? 8 : 256;
-    // block 4's warp + concat inside the block_4_0 + block_4_1 kernel (batch > 8): fp16-plane mode with the fast sampler (HNET_WARP_EXACT keeps the prep launch)
-    c->warp_in = c->n_planes == 2 && c->fuse_b4 && c->x16_b4 && !c->warp_exact && !(g.variant & HNET_VARIANT_NO_WARP_FUSE);
+    // opt-in (it measured slower): block 4's warp + concat inside the block_4_0 + block_4_1 kernel (batch > 8): fp16-plane mode with the fast sampler
+    c->warp_in = c->n_planes == 2 && c->fuse_b4 && c->x16_b4 && !c->warp_exact && (g.variant & HNET_VARIANT_WARP_FUSE);
     if (c->use_chain) {
         CK(hipMalloc((void**)&c->chain_sync, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
         CK(hipMemset(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
@@ -1958,7 +1958,7 @@ int hnet_debug_layer_output(hnet_ctx* c, int layer, int pair, float* out, size_t
     float* d_t = nullptr;
     HIPCHK(c, t.alloc(&d_t, n));
     if (c->fuse_b4 && layer == 13) {   // the fused kernel keeps block_4_0's output in LDS: recompute it unfused for inspection
-        if (c->b4_in_stale) return fail(c, HNET_ERR_UNSUPPORTED, "layer 13 of a batch > 8: block 4 sampled its input in-kernel (inspect it on a context with HNET_VARIANT_NO_WARP_FUSE)");
+        if (c->b4_in_stale) return fail(c, HNET_ERR_UNSUPPORTED, "layer 13 of a batch > 8: block 4 sampled its input in-kernel (inspect it on a context without HNET_VARIANT_WARP_FUSE)");
         uint16_t* tmp = nullptr;
         HIPCHK(c, t.alloc(&tmp, 3 * n));
         const float* xin = c->x_in[3] + (size_t)pair * NPIX * 2;

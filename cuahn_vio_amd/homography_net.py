@@ -53,7 +53,7 @@ def kernel_selection_from_env():
         variant |= 1 << 11
     if env("HNET_CHAIN_GRID", "") in ("8", "3"):      # tests: the chain launches with 8 / 3 workgroups (HNET_VARIANT_CHAIN_GRID_*)
         variant |= (1 << 12) if env("HNET_CHAIN_GRID") == "8" else (1 << 13)
-    if env("HNET_WARP_FUSE", "1") == "0":   # block 4's warp + concat as a launch of its own (include/hnet.h HNET_VARIANT_NO_WARP_FUSE)
+    if env("HNET_WARP_FUSE", "0") == "1":   # opt-in: block 4's warp + concat sampled inside the block_4_0 + block_4_1 kernel (include/hnet.h HNET_VARIANT_WARP_FUSE)
         variant |= 1 << 14
     graph = {"0": 1, "1": 2}.get(env("HNET_GRAPH", ""), 0)
     return int(env("HNET_WARP_EXACT", "0") != "0"), graph, variant

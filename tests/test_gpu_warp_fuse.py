@@ -1,9 +1,10 @@
-"""Round 6: at batches > 8 (default arithmetic mode, u8 images) block 4's input - cat(img1, warp(img2, H)), model_to_trace.py:261-263 - is sampled INSIDE the
+"""Round 6, opt-in (HNET_WARP_FUSE=1 / include/hnet.h HNET_VARIANT_WARP_FUSE; it measured slower than the two launches and is not the default): at batches > 8
+(default arithmetic mode, u8 images) block 4's input - cat(img1, warp(img2, H)), model_to_trace.py:261-263 - is sampled INSIDE the
 block_4_0 + block_4_1 kernel (csrc/conv_b4_fused.h WARPIN) instead of being written as padded fp16 planes by a prep launch of its own.  The sampler is the prep
 kernel's fast sampler instruction for instruction (csrc/warp_dev.h, kernels.hip warp_sample_box_fast), so wherever both forms take it the two paths must agree
 BIT FOR BIT: on block_4_1's output map and on everything downstream.  Where a patch / tile falls back to the exact sampler (extreme homographies: the two forms
 decide per 25 x 80 patch and per 32 x 64 tile respectively) they agree to the sampler's contract instead, gated through the outputs.
-HNET_WARP_FUSE=0 (include/hnet.h HNET_VARIANT_NO_WARP_FUSE) keeps the prep launch."""
+Without the switch the prep launch stays."""
 import contextlib
 import os
 
