@@ -11,4 +11,7 @@ python tools/determinism_stress.py 2000 > gpurun_out/${R}_determinism.log 2>&1
 python tools/chain_check.py 200 > gpurun_out/${R}_chain_check.log 2>&1
 (tools/trace_chain_plain.bin 1; tools/trace_chain_plain.bin 8; tools/trace_chain.bin 1) > gpurun_out/${R}_chain_trace.log 2>&1
 python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
+# round 6: block 4 sampling its own input (opt-in) against the two launches: A/B of the whole step, the kernel's phases (hipcc ... -DB4_WARPIN=0|1 -DHNET_B4_TRACE tools/trace_b4.hip)
+bash tools/ab_warp_fuse.sh > gpurun_out/${R}_warp_fuse_ab.log 2>&1
+(tools/trace_b4_w0.bin; tools/trace_b4_w1.bin) > gpurun_out/${R}_b4_trace.log 2>&1
 ls -la gpurun_out/${R}_* gpurun_out/prof_$TAG
