@@ -177,6 +177,7 @@ struct hnet_ctx {
     // hipGraph replay of small-batch forwards (29-45 dependent launches: at batch 1 the host launch cost dominates).
     // The sequence number of the MC-dropout masks lives in device memory (d_seq) and is refreshed by a memcpy node
     // from a pinned host word, so one captured graph serves every call.
+    bool graph_zero_copy = false;      // ... whose kernels read {sequence number, prior} from and write {mean, cov, error map, flag} to the pinned host block directly (no memcpy nodes)
     bool use_graph = false;            // hnet_infer replays the forward as one hipGraph (default on; HNET_GRAPH=0: eager launches)
     bool graph_timing = false;         // hnet_time_batch_device too (HNET_GRAPH=1 only: the bare device time is 3 % better eager)
     uint64_t* d_seq = nullptr;
@@ -382,6 +383,7 @@ struct FwdArgs {
     bool use_ws = true;       // may use the context's split-K workspace (false for concurrent chunks)
     const uint64_t* seq_dev = nullptr;   // device addend to seq0 (graph replays)
     int mean_stride = 8, cov_stride = 64;   // floats between consecutive pairs of `mean` / `cov` (72 / 72: the packed [B][72] record)
+    uint32_t* flag = nullptr;               // where the kernels raise the overflow / timeout bits (nullptr: the context's device word; hnet_infer's graph: a word of its pinned block)
 };
 
 #define STAGE(call)                                                                                         \
@@ -412,6 +414,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     // `pend` holds what the next prep has to evaluate; the homographies alternate between Hm and Hm2 (a workgroup stores the new one while
     // others still read the old one).
     const bool small = c->fuse_small && B <= 8;
+    uint32_t* const flagp = a.flag ? a.flag : c->d_flag;
     size_t stage_i = 0;                            // launches so far (index into c->stages when that list describes this forward)
     auto set_kernels = [&](int k) { if (stage_i >= 1 && stage_i <= c->stages.size()) c->stages[stage_i - 1].kernels = k; };
     // the keep bits of the heads depend on the seeds only: on the latency path they are drawn by surplus workgroups of block 4's prep launch (FcArgs::mask)
@@ -475,7 +478,9 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                     if (hipMemsetAsync(c->chain_sync + blk * CH_SYNC_WORDS, 0, CH_SYNC_WORDS * sizeof(uint32_t), s) != hipSuccess) return fail(c, HNET_ERR_DEVICE, "chain area memset");
                     nxt = 0;
                 }
-                STAGE(launch_tail_chain(blk + 1, c->chain_args[blk], c->chain_sync + blk * CH_SYNC_WORDS, c->chain_sync + nxt * CH_SYNC_WORDS, B, s, c->chain_grid));
+                ChainArgs cargs = c->chain_args[blk];
+                cargs.flag = flagp;
+                STAGE(launch_tail_chain(blk + 1, cargs, c->chain_sync + blk * CH_SYNC_WORDS, c->chain_sync + nxt * CH_SYNC_WORDS, B, s, c->chain_grid));
                 l = last[blk];
                 in = c->act[l];
                 in16 = nullptr;
@@ -555,7 +560,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         STAGE(launch_heads_fc1(feat, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w1, c->b1, hidden, s, ws, wsn, a.seq_dev));
     if (a.partial) {
         STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2,
-                               a.mean_s, a.logvar_s, s, a.seq_dev, c->d_flag));
+                               a.mean_s, a.logvar_s, s, a.seq_dev, flagp));
         if (a.h_part1) {
             hipError_t e = hipMemcpyAsync(a.h_part1, Hm, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return fail(c, HNET_ERR_DEVICE, "copy H_part1");
@@ -566,10 +571,10 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
     float* lv = c->logvar_s + P0 * c->n_local * 8;
     if (small && c->n_local <= HEADS_FC2_FINISH_MAX_N) {
         STAGE(launch_heads_fc2_finish(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, Hm, a.mean, a.cov, Htot, s,
-                                      a.seq_dev, c->d_flag, a.mean_stride, a.cov_stride));
+                                      a.seq_dev, flagp, a.mean_stride, a.cov_stride));
     } else {
         STAGE(launch_heads_fc2(hidden, B, c->n_local, c->s_begin, g.dropout_p, g.mc_seed, a.seq0, c->w2, c->b2, ms, lv, s, a.seq_dev));
-        STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, c->d_flag, a.mean_stride, a.cov_stride));
+        STAGE(launch_mc_finish(ms, lv, c->n_local, Hm, B, a.mean, a.cov, Htot, s, flagp, a.mean_stride, a.cov_stride));
     }
     if (g.emit_error_map && (a.err || a.err_u8))                                     // :319-327
         STAGE(launch_errmap(a.prev, a.curr, a.pix_fmt, Htot, a.err, a.err_u8, B, s));
@@ -887,7 +892,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     g.struct_size = sizeof(g);
     if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
     if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
-    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_WARP_FUSE)) return HNET_ERR_INVALID_ARG;
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_WARP_FUSE | HNET_VARIANT_GRAPH_COPIES)) return HNET_ERR_INVALID_ARG;
     {
         const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
         static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
@@ -1027,6 +1032,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     // (device time of the forward 0.289 -> 0.300 ms)
     c->use_graph = g.graph != HNET_GRAPH_OFF;
     c->graph_timing = g.graph == HNET_GRAPH_TIMING;
+    c->graph_zero_copy = !(g.variant & HNET_VARIANT_GRAPH_COPIES);
     CK(hipMalloc((void**)&c->d_seq, 8));
     CK(hipMemset(c->d_seq, 0, 8));
     CK(hipMalloc((void**)&c->d_flag, 4));
@@ -1484,11 +1490,22 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
     if (c->cfg.use_prior && !prior_px) return fail(c, HNET_ERR_INVALID_ARG, "prior required");
     if (src != c) HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_img[src->curr_slot], 0));      // the frame's upload runs on the source's stream
     if (c->use_graph) {
-        // one graph per ring orientation: H2D {seq, prior} from pinned memory -> forward -> D2H {mean, cov, err} to pinned
+        // one graph per ring orientation.  Round 6: no memcpy nodes - the pinned host block is mapped into the device's address space and the kernels read the
+        // sequence number and the prior from it and write mean, covariance, error map and the flag word to it (six copy / memset nodes of 3 - 8 us each in a chain of
+        // 16 launches; HNET_VARIANT_GRAPH_COPIES keeps them: H2D {seq, prior} -> forward -> D2H {mean, cov, err, flag})
         const int slot = src->curr_slot;
         hnet_ctx::Pinned* pin = c->pinned;
         if (!c->g_infer[slot]) {
+            hnet_ctx::Pinned* dpin = nullptr;
+            if (c->graph_zero_copy && hipHostGetDevicePointer((void**)&dpin, pin, 0) != hipSuccess) { (void)hipGetLastError(); c->graph_zero_copy = false; }
             c->g_infer[slot] = capture_graph(c, [&]() -> int {
+                if (c->graph_zero_copy) {
+                    FwdArgs ga = {src->ring[slot ^ 1], src->ring[slot], HNET_PIX_U8, c->cfg.use_prior ? dpin->prior : nullptr, 1, 0, dpin->mean, dpin->cov,
+                                  nullptr, c->cfg.emit_error_map ? dpin->err : nullptr, nullptr, nullptr, nullptr, false};
+                    ga.seq_dev = &dpin->seq;
+                    ga.flag = &dpin->flag;
+                    return forward(c, ga, c->stream);
+                }
                 if (hipMemcpyAsync(c->d_seq, &pin->seq, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 if (c->cfg.use_prior && hipMemcpyAsync(c->d_prior, pin->prior, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) return HNET_ERR_DEVICE;
                 FwdArgs ga = {src->ring[slot ^ 1], src->ring[slot], HNET_PIX_U8, c->cfg.use_prior ? c->d_prior : nullptr, 1, 0, c->d_mean, c->d_cov,
@@ -1511,6 +1528,7 @@ int hnet_infer(hnet_ctx* c, const double* prior_px, int iteration, float mean_ou
             c->H_last = c->g_infer_H[slot];
             pin->seq = (uint64_t)src->timing.n_inferences;
             if (c->cfg.use_prior) for (int i = 0; i < 8; i++) pin->prior[i] = (float)prior_px[i];    // :160-165 toType(kFloat)
+            if (c->graph_zero_copy) pin->flag = 0;                 // (raised by the kernels directly; the memcpy form overwrites it)
             HIPCHK(c, hipEventRecord(c->ev0, c->stream));
             HIPCHK(c, hipGraphLaunch(c->g_infer[slot], c->stream));
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -418,6 +418,7 @@ hipError_t conv_kernels_init_device_np() {
     if constexpr (NP != 2) e = hipFuncSetAttribute((const void*)block4_fused_kernel<7, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<7, 256, NP, true>::LDS_BYTES);
     if constexpr (NP == 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 256, NP, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 256, NP, true>::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)block4_fused_kernel<8, 256, NP, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B4Cfg<8, 256, NP, true>::LDS_BYTES + B4W_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_lean8_kernel<HeadLoaderS3, true, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN8_LDS_BYTES);
 #define HNET_PIPE_ATTR(L_, C_, O_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_s3_pipe_kernel<L_, C_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, C_::LDS_BYTES)
         typedef ConvLoaderS3<128, 3, 2, 32> L1283; typedef ConvLoaderS3<64, 5, 2, 32> L645; typedef ConvLoaderS3<64, 3, 2, 32> L643;

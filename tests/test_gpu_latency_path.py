@@ -258,3 +258,38 @@ def test_tail_chains_many_forwards_back_to_back(blob):
     for i in range(len(sizes), reps):
         b = sizes[i % len(sizes)]
         assert np.array_equal(o[i][:b], o[i % len(sizes)][:b]), i
+
+
+@pytest.mark.parametrize("use_prior", [True, False])
+def test_infer_graph_without_copy_nodes_is_the_graph_with_them(blob, tmp_path, use_prior):
+    """hnet_infer's graph lets the kernels read {sequence number, prior} from and write {mean, covariance, error map, flag} to the pinned host block (round 6:
+    no memcpy / memset nodes in the dependent chain); HNET_VARIANT_GRAPH_COPIES (HNET_GRAPH_COPIES=1 in the mirror) keeps the copy nodes: the same bits, frame by frame"""
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HomographyNet
+    path = str(tmp_path / "w_showError.hnw")
+    with open(path, "wb") as f:
+        f.write(blob)
+    frames = [synth.make_pair(60 + i)[0] for i in range(5)]
+    prior = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.25, 2.0, -0.75])
+    outs = []
+    for copies in ("0", "1"):
+        old = os.environ.get("HNET_GRAPH_COPIES")
+        os.environ["HNET_GRAPH_COPIES"] = copies
+        try:
+            net = HomographyNet(path, "", use_prior=use_prior, num_of_iteration=1, show_imgs=False, dropout_p=0.05, mc_seed=5)
+        finally:
+            if old is None:
+                os.environ.pop("HNET_GRAPH_COPIES", None)
+            else:
+                os.environ["HNET_GRAPH_COPIES"] = old
+        res = []
+        for i, fr in enumerate(frames):
+            net.load_current_img(fr, float(i))
+            if i:
+                net.network_inference(prior + i, 0)
+                res.append((net.get_pred_mean().copy(), net.get_pred_Cov().copy(), None if net.last_error_map is None else net.last_error_map.copy()))
+        net.close()
+        outs.append(res)
+    for (m1, c1, e1), (m0, c0, e0) in zip(*outs):
+        assert np.isfinite(m1).all() and m1.any() and np.array_equal(m1, m0) and np.array_equal(c1, c0)
+        assert (e1 is None and e0 is None) or (e1.any() and np.array_equal(e1, e0))
