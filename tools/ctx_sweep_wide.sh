@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/ctx_sweep.sh beyond four contexts (4 / 5 / 6 / 8 members of an hnet_group): the runtime serves a process with four hardware queues (profiles/r06_ctx_sweep.log)
 cd $GRAFT_REPO_ROOT
 for shape in "prior3 64 16" "prior3 32 16" "full 256 32"; do
   set -- $shape
