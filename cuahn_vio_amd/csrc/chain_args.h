@@ -25,9 +25,15 @@ struct ChainLayer {
     size_t out_plane;
     float* out32;            // fp32 [MB][HO WO][COUT] (last layer of a block: the FC's input)
 };
+constexpr int CH_FC_ITEMS = 32;                    // items of a chain's last layer (ChainL13 / ChainLx6): the partial sums per pair
 struct ChainArgs {
     ChainLayer L[3];
     uint32_t* flag;          // the context's flag word (hnet_overflow_flag)
+    // blocks 1 - 3 (nullptr for block 4): the block-tail Linear(5120, 8) as PARTIAL sums per item of the LAST layer - the item's 8 channels x HO WO pixels times their
+    // slice of the FC weights - summed over the items by the next warp + pool launch (kernels.hip fc_part_dlt_block) instead of every workgroup of that launch
+    // re-reading 184 KB of features and weights
+    const float* fcw;        // [8][5120], NHWC-flatten order (hnet_create's fc_w)
+    float* fc_part;          // [MB][CH_FC_ITEMS][8]
 };
 
 bool chain_layer(int layer);                                                       // a conv layer that belongs to a tail chain (kConvs index)

@@ -84,6 +84,8 @@ struct ChainCfg {
 
 // dynamic LDS: the region (the largest, block_1_2's: 156 672 B; its first bytes double as the reduction buffer), the slot table (<= 528 words), the broadcast words
 constexpr int CH_TABLE_OFF = 153 * 1024, CH_LDS_BYTES = 160 * 1024;
+// last layers (OUT32): the item's slice of the block-tail FC's weights ([8 outputs][HO WO pixels][NCH channels] floats, 5 KB) behind the region, then the two waves' partial sums
+constexpr int CH_FC_OFF = 128 * 1024, CH_FC_RED_OFF = CH_FC_OFF + 8 * 1024;
 
 __device__ __forceinline__ uint32_t ch_load_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // global_load_dword sc1: L1 bypassed
 __device__ __forceinline__ uint32_t ch_local_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // executed in this XCD's L2
@@ -92,6 +94,19 @@ template <int N> __device__ __forceinline__ void ch_wait_vm() { asm volatile("s_
 // i.e. every barrier of a layer would wait for the weight fragments in flight (issued exactly so that they travel DURING the wait for the previous layer and the
 // region copy) and for the acknowledgement of every counter atomic (~1 us each).  Global data is ordered here by explicit vmcnt waits where it matters.
 __device__ __forceinline__ void ch_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// sum over the 16 lanes of a DPP row, in every lane of the row (four cross-lane adds in the vector pipe: quad swaps, then the row's half mirror and mirror - a fixed pairing)
+template <int CTRL> __device__ __forceinline__ float ch_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float ch_row_sum(float v) {
+    v += ch_dpp<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+    v += ch_dpp<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+    v += ch_dpp<0x141>(v);     // row_half_mirror
+    v += ch_dpp<0x140>(v);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ float ch_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 // waits until *p == target (thread 0 polls, the workgroup follows through the barrier); false = gave up
 __device__ __forceinline__ bool ch_wait_eq(const uint32_t* p, uint32_t target, uint32_t* lds_word) {
@@ -180,9 +195,20 @@ struct ChainOps {
             if (piece >= PPP) { piece -= PPP; slot += 1; }
         }
     }
+    // (2c) last layer of blocks 1 - 3: the item's slice of the FC weights, [o][pixel][channel group of 4] x 16 bytes, by LDS-DMA next to the region (no registers)
+    __device__ static __forceinline__ void stage_fc(const float* fcw, const Item& it, uint8_t* smem, int wave, int lane) {
+        constexpr int NPX = C::HO * C::WO, G = NCH / 4, PIECES = 8 * NPX * G, NI = (PIECES + 63) / 64;
+        static_assert(C::MS == 1 && PIECES * 16 <= 8 * 1024 && C::REGION <= CH_FC_OFF && C::ITEMS == CH_FC_ITEMS, "FC slice of a last layer");
+        const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)fcw, 0, 8 * 5120 * 4, 0x00020000);
+        if (wave < NI) {
+            const int q = wave * 64 + lane, o = q / (NPX * G), r = q - o * (NPX * G), px = r / G, h = r - px * G;
+            const uint32_t vo = q < PIECES ? (uint32_t)(((o * 5120 + px * C::COUT + it.tile * NCH + h * 4)) * 4) : S3_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rF, (lds_ptr_t)(smem + CH_FC_OFF + wave * 1024), 16, vo, 0, 0, 0);
+        }
+    }
     // (3) this wave's K steps over every M-tile of the item, the eight K slices added through LDS in wave order, bias + LeakyReLU, store.
     // Entry: the region has landed and the workgroup has met at a barrier.  Exit: the item's stores have been ISSUED.
-    __device__ static __forceinline__ void compute_store(const ChainLayer& L, int pair, const Item& it, W& fw, uint8_t* smem, int tid, int wave, int lane, int tb) {
+    __device__ static __forceinline__ void compute_store(const ChainLayer& L, int pair, const Item& it, W& fw, uint8_t* smem, int tid, int wave, int lane, int tb, const float* fcw = nullptr, float* fc_part = nullptr) {
         const int li = lane & 15, lg = lane >> 4;
         int lb[TM];
 #pragma unroll
@@ -216,6 +242,7 @@ struct ChainOps {
 #pragma unroll
         for (int i = 0; i < TM; i++) *reinterpret_cast<f32x4_m16*>(red + ((wave * TM + i) * 64 + lane) * 4) = hi[i] + lo[i] * S3_F16_INV;
         ch_bar();
+        [[maybe_unused]] float fcp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tid < TM * 64) {
             const int i = tid >> 6;                                            // M-tile (wave-uniform), lane = (pixel li, channel group lg)
             f32x4_m16 s = *reinterpret_cast<const f32x4_m16*>(red + ((0 * TM + i) * 64 + lane) * 4);
@@ -231,12 +258,44 @@ struct ChainOps {
                 const size_t pix = (size_t)pair * (C::HO * C::WO) + it.oy0 * C::WO + m;
                 if constexpr (C::OUT32) {
                     *reinterpret_cast<f32x4_m16*>(L.out32 + pix * C::COUT + n) = x;
+                    if (fcw) {                                                 // (kernel-uniform) this thread's four activations times their FC weights, eight outputs
+                        const float* fw = reinterpret_cast<const float*>(smem + CH_FC_OFF);
+#pragma unroll
+                        for (int o = 0; o < 8; o++) {
+                            const f32x4_m16 w4 = *reinterpret_cast<const f32x4_m16*>(fw + ((o * (C::HO * C::WO) + m) * (NCH / 4) + lg) * 4);
+                            fcp[o] = fmaf(x[3], w4[3], fmaf(x[2], w4[2], fmaf(x[1], w4[1], x[0] * w4[0])));
+                        }
+                    }
                 } else {
                     uint32_t pa[3], pb[3];
                     s3p::split_pair<2>(x[0], x[1], pa);
                     s3p::split_pair<2>(x[2], x[3], pb);
 #pragma unroll
                     for (int pl = 0; pl < 2; pl++) *reinterpret_cast<uint2*>(L.out16 + pl * L.out_plane + pix * C::COUT + n) = make_uint2(pa[pl], pb[pl]);
+                }
+            }
+        }
+        if constexpr (C::OUT32) {
+            if (fcw) {                                                         // (kernel-uniform) the item's partial sums: per wave (= M-tile) by DPP, then wave 0 + wave 1 + ...: a fixed order
+                float* fred = reinterpret_cast<float*>(smem + CH_FC_RED_OFF);
+                if (tid < TM * 64) {
+                    // lanes (pixel li, channel group lg < NCH / 4) hold products, the others zeros: rows 0 .. NCH / 4 - 1 of the wave, each summed by DPP, then added in row order
+                    static_assert(NCH / 4 <= 4, "one DPP row per channel group");
+#pragma unroll
+                    for (int o = 0; o < 8; o++) {
+                        const float r = ch_row_sum(fcp[o]);
+                        float v = ch_lane(r, 0);
+#pragma unroll
+                        for (int g2 = 1; g2 < NCH / 4; g2++) v += ch_lane(r, 16 * g2);
+                        if (lane == 0) fred[wave * 8 + o] = v;
+                    }
+                }
+                ch_bar();
+                if (tid < 8) {
+                    float v = fred[tid];
+#pragma unroll
+                    for (int wv = 1; wv < TM; wv++) v += fred[wv * 8 + tid];
+                    fc_part[((size_t)pair * C::ITEMS + (size_t)(it.tile * C::MS)) * 8 + tid] = v;
                 }
             }
         }
@@ -258,12 +317,16 @@ template <> struct ChainOps<ChainNone> {
 // (nullptr: none).  Returns the next item of this layer that the workgroup drew (>= ITEMS: none), or 0xFFFFFFFF when a bounded spin gave up.
 template <class C>
 __device__ __forceinline__ uint32_t chain_one_item(const ChainLayer& L, int pair, int phase, uint32_t item, typename ChainOps<C>::W& fw, const uint32_t* wait_prev,
-                                                   uint32_t wait_target, uint32_t* slot, uint8_t* smem, uint32_t* table, uint32_t* lds_words, int tb) {
+                                                   uint32_t wait_target, uint32_t* slot, uint8_t* smem, uint32_t* table, uint32_t* lds_words, int tb,
+                                                   const float* fcw, float* fc_part) {
     typedef ChainOps<C> O;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const typename O::Item it = O::item((int)item);
     O::slot_table(pair, it, table, tid);
+    // the item's slice of the block-tail FC's weights (last layer of blocks 1 - 3): requested HERE, before the wait for the previous layer - they come from memory
+    // (only the owner XCD of this launch reads them; its L2 need not hold them), the region comes from the L2: behind the region copy they delayed the MFMAs by ~ 1.5 us
+    if constexpr (C::OUT32) { if (fcw) O::stage_fc(fcw, it, smem, wave, lane); }
     // the next unclaimed item of this layer, if any: drawn now, looked at after the item
     uint32_t drawn = 0;
     if (tid == 0) drawn = ch_local_add(slot, 1u << (10 * phase));
@@ -276,7 +339,8 @@ __device__ __forceinline__ uint32_t chain_one_item(const ChainLayer& L, int pair
     ch_wait_vm<0>();
     ch_bar();
     CHT(tb + 2);
-    O::compute_store(L, pair, it, fw, smem, tid, wave, lane, tb);
+    if constexpr (C::OUT32) O::compute_store(L, pair, it, fw, smem, tid, wave, lane, tb, fcw, fc_part);
+    else O::compute_store(L, pair, it, fw, smem, tid, wave, lane, tb);
     if (tid == 0) lds_words[1] = drawn;
     ch_bar();
     return (lds_words[1] >> (10 * phase)) & 1023u;
@@ -289,7 +353,8 @@ __device__ __forceinline__ uint32_t chain_one_item(const ChainLayer& L, int pair
 // so no copies (a copy waits for the load), and two layers' fragments are never live together (a build that loaded them in front of the arithmetic spilled).
 template <class C, class CPREV, class CN, bool PRE>
 __device__ __forceinline__ bool chain_phase(const ChainLayer& L, const ChainLayer& Ln, int pair, int phase, uint32_t first, typename ChainOps<C>::W& fw, uint32_t fn,
-                                            typename ChainOps<CN>::W& fwn, uint32_t* local, uint32_t* slot, uint8_t* smem, uint32_t* table, uint32_t* lds_words) {
+                                            typename ChainOps<CN>::W& fwn, uint32_t* local, uint32_t* slot, uint8_t* smem, uint32_t* table, uint32_t* lds_words,
+                                            const float* fcw = nullptr, float* fc_part = nullptr) {
     typedef ChainOps<C> O;
     typedef ChainOps<CN> ON;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -299,7 +364,7 @@ __device__ __forceinline__ bool chain_phase(const ChainLayer& L, const ChainLaye
     const uint32_t* wait_prev = phase ? local + 8 + (phase - 1) : nullptr;
     if (have) {
         if constexpr (!PRE) O::load_w(L, O::item((int)first), fw, wave, lane);
-        uint32_t item = chain_one_item<C>(L, pair, phase, first, fw, wait_prev, (uint32_t)CPREV::ITEMS, slot, smem, table, lds_words, tb);
+        uint32_t item = chain_one_item<C>(L, pair, phase, first, fw, wait_prev, (uint32_t)CPREV::ITEMS, slot, smem, table, lds_words, tb, fcw, fc_part);
         if (item == 0xFFFFFFFFu) return false;
         while (item < (uint32_t)C::ITEMS) {                                        // more items than resident workgroups (never under the usual placement)
             ch_wait_vm<0>();                                                       // the previous item's stores are in the L2
@@ -307,7 +372,7 @@ __device__ __forceinline__ bool chain_phase(const ChainLayer& L, const ChainLaye
             if (tid == 0) ch_local_add(local + 8 + phase, 1u);
             typename O::W fw2;
             O::load_w(L, O::item((int)item), fw2, wave, lane);
-            item = chain_one_item<C>(L, pair, phase, item, fw2, nullptr, 0u, slot, smem, table, lds_words, 32);
+            item = chain_one_item<C>(L, pair, phase, item, fw2, nullptr, 0u, slot, smem, table, lds_words, 32, fcw, fc_part);
         }
     }
     // the next layer's fragments: behind the last item's stores (counted wait: the stores are acknowledged, the fragments fly on)
@@ -402,9 +467,11 @@ __global__ __launch_bounds__(CH_NT) void tail_chain_kernel(const ChainArgs a, ui
         typename ChainOps<C2>::W w2;
         typename ChainOps<ChainNone>::W wn;
         ok = chain_phase<C0, ChainNone, C1, false>(args->L[0], args->L[1], pair, 0, f0, w0, f1, w1, local, slot, ch_smem, table, lds_words);
-        if (ok) ok = chain_phase<C1, C0, C2, true>(args->L[1], args->L[2], pair, 1, f1, w1, f2, w2, local, slot, ch_smem, table, lds_words);
         if constexpr (C2::ITEMS != 0) {
-            if (ok) ok = chain_phase<C2, C1, ChainNone, true>(args->L[2], args->L[2], pair, 2, f2, w2, 0u, wn, local, slot, ch_smem, table, lds_words);
+            if (ok) ok = chain_phase<C1, C0, C2, true>(args->L[1], args->L[2], pair, 1, f1, w1, f2, w2, local, slot, ch_smem, table, lds_words);
+            if (ok) ok = chain_phase<C2, C1, ChainNone, true>(args->L[2], args->L[2], pair, 2, f2, w2, 0u, wn, local, slot, ch_smem, table, lds_words, args->fcw, args->fc_part);
+        } else {
+            if (ok) ok = chain_phase<C1, C0, C2, true>(args->L[1], args->L[2], pair, 1, f1, w1, f2, w2, local, slot, ch_smem, table, lds_words, args->fcw, args->fc_part);
         }
     }
     CHT(30);

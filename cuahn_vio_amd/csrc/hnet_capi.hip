@@ -146,6 +146,7 @@ struct hnet_ctx {
     size_t ws_floats = 0;
     // round 6: the tail of every block (its last 2 - 3 stride-2 layers) of a batch <= 8 as ONE launch on one XCD (chain_lat.h); fp16-plane mode, variant bit NO_CHAIN = off
     bool use_chain = false;
+    float* fc_part = nullptr;          // [CH_MAX_PAIRS][32][8]: the block-tail FC as partial sums per item of a tail chain's last layer (chain_lat.h), read by the next warp + pool launch
     bool b4_in_stale = false;          // the last forward's block 4 sampled its input in-kernel: x16_b4 does not hold it (hnet_debug_layer_output(13) refuses)
     bool warp_in = false;              // batch > 8: block 4's warp + concat sampled inside the block_4_0 + block_4_1 kernel (conv_b4_fused.h WARPIN) - no prep_b4 launch
     int chain_grid = 256;              // workgroups of a chain launch (one per CU; HNET_VARIANT_CHAIN_GRID_8 / _3: the tests' small grids)
@@ -471,6 +472,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
         const uint16_t* in16 = nullptr;
         size_t in_plane = 0;
         const size_t MB = (size_t)g.max_batch;
+        bool chain_fc_done = false;                // this block's tail chain left the FC's partial sums in c->fc_part
         for (int l = first[blk]; l <= last[blk]; l++) {
             if (c->use_chain && small && P0 == 0 && l == chain_first[blk] && in16) {      // the block's tail in one launch on one XCD (chain_lat.h)
                 int nxt = blk < 3 ? blk + 1 : fb;                                         // the chain launch that follows this one on the stream: the next block's, or the next forward's first
@@ -480,6 +482,7 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
                 }
                 ChainArgs cargs = c->chain_args[blk];
                 cargs.flag = flagp;
+                chain_fc_done = blk < 3 && cargs.fcw != nullptr;
                 STAGE(launch_tail_chain(blk + 1, cargs, c->chain_sync + blk * CH_SYNC_WORDS, c->chain_sync + nxt * CH_SYNC_WORDS, B, s, c->chain_grid));
                 l = last[blk];
                 in = c->act[l];
@@ -539,7 +542,11 @@ int forward_chunk(hnet_ctx* c, const FwdArgs& a, hipStream_t s) {
             w = c->act_w[l];
         }
         if (blk < 3) {                                                                // :143-150, :163-168, :183-188
-            if (small) { pend = FcArgs{in, c->fc_w[blk], c->fc_b[blk], warp ? Hcur : nullptr, nullptr, nullptr}; have_pend = true; }
+            if (small) {
+                pend = FcArgs{in, c->fc_w[blk], c->fc_b[blk], warp ? Hcur : nullptr, nullptr, nullptr};
+                if (chain_fc_done) pend.fc_part = c->fc_part;      // (the unaligned-image fallback below still computes the FC from `in`)
+                have_pend = true;
+            }
             else STAGE(launch_block_fc_dlt(in, c->fc_w[blk], c->fc_b[blk], warp ? Hcur : nullptr, Hcur, B, s));
         }
     }
@@ -892,7 +899,7 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
     g.struct_size = sizeof(g);
     if (g.max_batch < 1) return HNET_ERR_INVALID_ARG;
     if (g.graph < HNET_GRAPH_DEFAULT || g.graph > HNET_GRAPH_TIMING) return HNET_ERR_INVALID_ARG;      // (unknown values no longer select the defaults silently)
-    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_WARP_FUSE | HNET_VARIANT_GRAPH_COPIES)) return HNET_ERR_INVALID_ARG;
+    if (g.variant & ~(uint32_t)(HNET_VARIANT_GEMM_MASK | HNET_VARIANT_NO_LATENCY_PATH | HNET_VARIANT_UNFUSED_B3 | HNET_VARIANT_UNFUSED_B42 | HNET_VARIANT_NO_CHAIN | HNET_VARIANT_CHAIN_GRID_8 | HNET_VARIANT_CHAIN_GRID_3 | HNET_VARIANT_WARP_FUSE | HNET_VARIANT_GRAPH_COPIES | HNET_VARIANT_CHAIN_NO_FC)) return HNET_ERR_INVALID_ARG;
     {
         const uint32_t code = g.variant & HNET_VARIANT_GEMM_MASK;
         static const uint32_t known[] = {0, 13, 20, 21, 22, 25, 30};
@@ -1057,6 +1064,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
         CK(hipMemset(c->chain_sync, 0, CH_AREAS * CH_SYNC_WORDS * sizeof(uint32_t)));
         static const int chain_first[4] = {1, 4, 10, 17};
         ChainArgs* ca = c->chain_args;
+        const bool chain_fc = !(g.variant & HNET_VARIANT_CHAIN_NO_FC);
+        if (chain_fc) CK(dalloc(&c->fc_part, (size_t)CH_MAX_PAIRS * CH_FC_ITEMS * 8));
         for (int blk = 0; blk < 4; blk++) {
             for (int l = chain_first[blk], j = 0; l <= last[blk]; l++, j++) {
                 ChainLayer& L = ca[blk].L[j];
@@ -1067,6 +1076,8 @@ int create_impl(const hnet_config* cfg_in, const uint8_t* blob, size_t len, hnet
                 if (!L.in || !L.wfrag || !(L.out16 || L.out32)) c->use_chain = false;      // (a layout this build does not expect: the launches)
             }
             ca[blk].flag = c->d_flag;
+            ca[blk].fcw = nullptr; ca[blk].fc_part = nullptr;
+            if (chain_fc && blk < 3 && c->fc_w[blk]) { ca[blk].fcw = c->fc_w[blk]; ca[blk].fc_part = c->fc_part; }      // the block-tail FC as partial sums of the last layer (chain_lat.h)
         }
     }
     c->ws_floats = (size_t)16 << 20;
@@ -1280,7 +1291,7 @@ void hnet_destroy(hnet_ctx* c) {
         if (c->pinned_img[i]) (void)hipHostFree(c->pinned_img[i]);
         if (c->ev_img[i]) (void)hipEventDestroy(c->ev_img[i]);
     }
-    fr(c->d_seq); fr(c->d_flag); fr(c->chain_sync);
+    fr(c->d_seq); fr(c->d_flag); fr(c->chain_sync); fr(c->fc_part);
     for (int l = 0; l < 20; l++) fr(c->chain_w[l]);
     fr(c->und_map[0]); fr(c->und_map[1]); fr(c->raw_dev);
     fr(c->s2_frag[0]); fr(c->s2_frag[3]); fr(c->x16_b4); fr(c->b30_frag); fr(c->b40_frag); fr(c->b41_frag); fr(c->w1_16); fr(c->b3f_w1); fr(c->b42_w2); fr(c->b42_w3); fr(c->feat16); fr(c->head_mask);

@@ -136,6 +136,8 @@ struct FcArgs {
     uint32_t thr;           // hnet_drop_threshold(p)
     uint64_t mc_seed, pair_seq0;
     const uint64_t* seq_dev;
+    // round 6: the FC as 32 partial sums per pair, written by the one-XCD tail chain of the previous block (chain_lat.h): [B][32][8]; feat is then not read
+    const float* fc_part;
 };
 bool prep_fc_supported(const void* img1, const void* img2, int k, bool has_out_s3);
 hipError_t launch_prep_fc(const void* img1, const void* img2, int pix_fmt, const FcArgs& fc, int k, float* out, int batch, hipStream_t s,

@@ -199,6 +199,19 @@ __device__ __forceinline__ float warp_sample_box_fast(float X, float Y, float Z,
 // geometry in double.  Shared by block_fc_dlt_kernel (one workgroup per pair) and by the small-batch prep kernels, every workgroup of
 // which recomputes its pair's homography instead of waiting for a launch of its own (FcArgs below): the same instructions in the same
 // order, so the two paths agree bit for bit.  Result: hout[9] (fp32, in LDS); prior != nullptr: H = DLT(p4 + prior) (the :129-130 case).
+// corner update + DLT + composition from the eight FC outputs (bias included), by one thread; geometry in double
+__device__ __forceinline__ void fc_finish(const float* fc, const float* __restrict__ H_in_b, float* hout) {
+    double dst[8], hb[9], hin[9], ho[9];
+    for (int o = 0; o < 8; o++) dst[o] = (double)(float)(p4(o) + (double)fc[o]);
+    dlt_solve(dst, hb);
+    if (H_in_b) {
+        for (int i = 0; i < 9; i++) hin[i] = (double)H_in_b[i];
+        mat3_mul(hin, hb, ho);
+    } else {
+        for (int i = 0; i < 9; i++) ho[i] = hb[i];
+    }
+    for (int i = 0; i < 9; i++) hout[i] = (float)ho[i];
+}
 __device__ __forceinline__ void fc_dlt_block(const float* __restrict__ f, const float* __restrict__ wfc, const float* __restrict__ bfc,
                                              const float* __restrict__ H_in_b, float (*part)[8], float* hout) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,20 +247,26 @@ __device__ __forceinline__ void fc_dlt_block(const float* __restrict__ f, const 
     }
     __syncthreads();
     if (tid == 0) {
-        double dst[8], hb[9], hin[9], ho[9];
-        for (int o = 0; o < 8; o++) {
-            const float fc = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + bfc[o];
-            dst[o] = (double)(float)(p4(o) + (double)fc);
-        }
-        dlt_solve(dst, hb);
-        if (H_in_b) {
-            for (int i = 0; i < 9; i++) hin[i] = (double)H_in_b[i];
-            mat3_mul(hin, hb, ho);
-        } else {
-            for (int i = 0; i < 9; i++) ho[i] = hb[i];
-        }
-        for (int i = 0; i < 9; i++) hout[i] = (float)ho[i];
+        float fc[8];
+        for (int o = 0; o < 8; o++) fc[o] = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) + bfc[o];
+        fc_finish(fc, H_in_b, hout);
     }
+}
+// the same from the 32 partial sums per output that the previous block's tail chain left (chain_lat.h, one per item of its last layer: 8 channels x 20 pixels each):
+// threads 0 .. 7 add them in item order - 1 KB instead of the 184 KB of features and weights every workgroup of the launch read
+__device__ __forceinline__ void fc_part_dlt_block(const float* __restrict__ part32, const float* __restrict__ bfc, const float* __restrict__ H_in_b, float (*part)[8], float* hout) {
+    const int tid = threadIdx.x;
+    if (tid < 8) {
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = part32[i * 8 + tid];
+        float s = v[0];
+#pragma unroll
+        for (int i = 1; i < 32; i++) s += v[i];
+        part[0][tid] = s + bfc[tid];
+    }
+    __syncthreads();
+    if (tid == 0) fc_finish(part[0], H_in_b, hout);
 }
 __device__ __forceinline__ void prior_dlt_block(const float* __restrict__ prior_b, float* hout) {     // dlt_kernel with add_corners
     if (threadIdx.x == 0) {
@@ -295,11 +314,18 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     const PIX* i2 = img2 + (size_t)b * NPIX;
     const int lane = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
     const int u = u0 + lane;
+    // (round 6: img1's pixels are requested BEFORE the homography is formed - they do not depend on it, and on the latency path the FC / DLT in front of the warp is
+    // a memory round trip + a serial double-precision tail of its own)
+    PIX araw[8];
+    const PIX* p1 = i1 + (v0 + r0) * IMG_W + u;                          // one address, the rows as instruction offsets
+#pragma unroll
+    for (int i = 0; i < 8; i++) araw[i] = p1[i * IMG_W];
     float h[9];
     if constexpr (FC) {
         __shared__ float fc_part[4][8];
         __shared__ float fc_h[9];
-        if (fc.feat) fc_dlt_block(fc.feat + (size_t)b * 5120, fc.wfc, fc.bfc, fc.H_in ? fc.H_in + b * 9 : nullptr, fc_part, fc_h);
+        if (fc.fc_part) fc_part_dlt_block(fc.fc_part + (size_t)b * 256, fc.bfc, fc.H_in ? fc.H_in + b * 9 : nullptr, fc_part, fc_h);
+        else if (fc.feat) fc_dlt_block(fc.feat + (size_t)b * 5120, fc.wfc, fc.bfc, fc.H_in ? fc.H_in + b * 9 : nullptr, fc_part, fc_h);
         else prior_dlt_block(fc.prior + b * 8, fc_h);
         __syncthreads();
 #pragma unroll
@@ -313,10 +339,6 @@ __global__ __launch_bounds__(256) void prep_warp_tiled_kernel(const PIX* __restr
     // round trips in sequence at four workgroups per CU).  A thread's eight img1 pixels (one column of the tile: 64 consecutive bytes per
     // wave and row) are now loaded straight into registers BEFORE the box is staged and are consumed after the barrier: one round trip,
     // no LDS tile for img1 (28 instead of 37 KB per workgroup), no u8 -> f32 table.
-    PIX araw[8];
-    const PIX* p1 = i1 + (v0 + r0) * IMG_W + u;                          // one address, the rows as instruction offsets
-#pragma unroll
-    for (int i = 0; i < 8; i++) araw[i] = p1[i * IMG_W];
     const WarpBox bx = warp_stage_box<PIX>(i2, h, u0, v0, reg);
     __syncthreads();
     float a[8], w[8], fx[8], fy[8];

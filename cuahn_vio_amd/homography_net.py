@@ -31,7 +31,7 @@ IGNORE_ENV = False      # bench.py sets this (unless --honour-env): engines are 
 
 def env_overrides():
     """the HNET_* variables of this process that kernel_selection_from_env / HnetEngine would map onto hnet_config (what bench.py lists in `env_overrides`)"""
-    names = ("HNET_S3_TILE", "HNET_FUSE_SMALL", "HNET_FUSE_B3", "HNET_FUSE_B42", "HNET_CHAIN", "HNET_CHAIN_GRID", "HNET_WARP_FUSE", "HNET_GRAPH_COPIES", "HNET_GRAPH", "HNET_WARP_EXACT", "HNET_PRECISION")
+    names = ("HNET_S3_TILE", "HNET_FUSE_SMALL", "HNET_FUSE_B3", "HNET_FUSE_B42", "HNET_CHAIN", "HNET_CHAIN_GRID", "HNET_CHAIN_FC", "HNET_WARP_FUSE", "HNET_GRAPH_COPIES", "HNET_GRAPH", "HNET_WARP_EXACT", "HNET_PRECISION")
     return {n: os.environ[n] for n in names if n in os.environ}
 
 
@@ -53,6 +53,8 @@ def kernel_selection_from_env():
         variant |= 1 << 11
     if env("HNET_CHAIN_GRID", "") in ("8", "3"):      # tests: the chain launches with 8 / 3 workgroups (HNET_VARIANT_CHAIN_GRID_*)
         variant |= (1 << 12) if env("HNET_CHAIN_GRID") == "8" else (1 << 13)
+    if env("HNET_CHAIN_FC", "1") == "0":    # the block-tail FC recomputed by the next warp + pool launch instead of summed from the chain's partial sums (HNET_VARIANT_CHAIN_NO_FC)
+        variant |= 1 << 16
     if env("HNET_WARP_FUSE", "0") == "1":   # opt-in: block 4's warp + concat sampled inside the block_4_0 + block_4_1 kernel (include/hnet.h HNET_VARIANT_WARP_FUSE)
         variant |= 1 << 14
     if env("HNET_GRAPH_COPIES", "0") == "1":   # hnet_infer's graph with memcpy nodes instead of kernels that read / write the pinned host block (HNET_VARIANT_GRAPH_COPIES)

@@ -100,6 +100,8 @@ enum {
     HNET_VARIANT_CHAIN_GRID_3 = 1u << 13,     /* with 3 (XCDs without a workgroup: pairs are picked up by whoever is done) - the same bits as the 256-workgroup launch */
     HNET_VARIANT_GRAPH_COPIES = 1u << 15,     /* hnet_infer's graph moves {sequence number, prior} and {mean, cov, error map, flag} with memcpy nodes, as until round 6, instead of
                                                   letting the kernels read / write the pinned host block directly (A/B and tests; same results) */
+    HNET_VARIANT_CHAIN_NO_FC = 1u << 16,      /* batch <= 8: the block-tail Linear(5120, 8) recomputed by every workgroup of the next warp + pool launch (rounds 3 - 5) instead of
+                                                  summed from the 32 partial sums the tail chain's last layer leaves (round 6; another summation order: fp32 rounding) */
     HNET_VARIANT_WARP_FUSE = 1u << 14         /* batch > 8: block 4's warp + concat sampled INSIDE the block_4_0 + block_4_1 kernel (csrc/conv_b4_fused.h WARPIN, round 6; fp16-plane
                                                   mode, 4-byte aligned u8 images) instead of a launch of its own that writes the padded fp16 planes.  Same sampler, same bits
                                                   (tests/test_gpu_warp_fuse.py) - and 0.10 ms per 256 pairs SLOWER (the sampling sits in every workgroup's own timeline:

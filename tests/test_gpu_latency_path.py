@@ -293,3 +293,39 @@ def test_infer_graph_without_copy_nodes_is_the_graph_with_them(blob, tmp_path, u
     for (m1, c1, e1), (m0, c0, e0) in zip(*outs):
         assert np.isfinite(m1).all() and m1.any() and np.array_equal(m1, m0) and np.array_equal(c1, c0)
         assert (e1 is None and e0 is None) or (e1.any() and np.array_equal(e1, e0))
+
+
+@pytest.mark.parametrize("variant,n_mc,batch", [("full", 32, 1), ("prior3", 16, 2), ("prior2", 8, 5), ("full", 16, 8)])
+def test_block_tail_fc_from_the_chain_partials(blob, oracle, variant, n_mc, batch):
+    """Round 6: the last layer of a block's tail chain leaves the block-tail Linear(5120, 8) as 32 partial sums per pair (an item's 8 channels x 20 pixels times their
+    slice of the FC weights, csrc/chain_lat.h) and the next warp + pool launch adds them in item order instead of re-reading features and weights in every workgroup
+    (HNET_CHAIN_FC=0 / HNET_VARIANT_CHAIN_NO_FC keeps that form): another order of the 5 120 products - the homographies agree to fp32 rounding, the outputs within
+    the gate of the other cross-order comparisons of this file, both within 1e-4 px of the oracle"""
+    from conftest import TOL_PX_VS_ORACLE
+    from cuahn_vio_amd import synth
+    from cuahn_vio_amd.homography_net import HnetEngine
+    prev, curr, prior, _ = synth.make_batch(800 + batch, batch)
+    pr = None if variant == "full" else prior
+    res = []
+    for fc in ("1", "0"):
+        old = os.environ.get("HNET_CHAIN_FC")
+        os.environ["HNET_CHAIN_FC"] = fc
+        try:
+            e = HnetEngine(blob, variant=variant, mc_samples=n_mc, dropout_p=0.05, mc_seed=9, max_batch=8)
+        finally:
+            if old is None:
+                os.environ.pop("HNET_CHAIN_FC", None)
+            else:
+                os.environ["HNET_CHAIN_FC"] = old
+        outs = [e.infer_batch(prev, curr, pr, pair_seq0=31) for _ in range(3)]
+        assert all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs[1:])      # reproducible forward to forward
+        h1 = np.stack([e.debug_h_part1(b) for b in range(batch)])
+        e.close()
+        res.append((outs[0][0], outs[0][1], h1))
+    (m1, c1, h1), (m0, c0, h0) = res
+    assert float(np.abs(h1 - h0).max() / np.abs(h0).max()) < TOL_H_PATHS
+    assert np.abs(m1 - m0).max() < TOL_PX_PATHS and np.abs(c1 - c0).max() / np.abs(c0).max() < TOL_COV_PATHS
+    btr = {"full": 3, "prior3": 3, "prior2": 2, "prior1": 1}[variant]
+    for b in (0, batch - 1):
+        o = oracle.forward(prev[b], curr[b], None if pr is None else pr[b], btr, n_mc, 0.05, 9, 31 + b)
+        assert np.abs(m1[b] - o["mean"]).max() < TOL_PX_VS_ORACLE
