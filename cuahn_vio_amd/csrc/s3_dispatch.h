@@ -327,12 +327,14 @@ hipError_t launch_heads_fc1_s3_np(const float* feat, int batch, int n_local, int
                 hipLaunchKernelGGL(heads_prep_kernel, dim3((unsigned)((nmw + 255) / 256)), dim3(256), 0, s, feat, batch, n_local, s_begin,
                                    hnet_drop_threshold(p_drop), 1.0f / (1.0f - p_drop), mc_seed, pair_seq0, seq_dev, (uint16_t*)nullptr, f_plane, mask, NP, 0);
             }
+            // pairs per workgroup: two y-groups of 128 workgroups = one round of the 256 CUs (this is a one-workgroup-per-CU kernel), the weights fetched once per workgroup
+            const int ppw = (batch + 1) / 2, gy = (batch + ppw - 1) / ppw;
             if (n_local <= 32)
-                hipLaunchKernelGGL(heads_fc1_lat_kernel<2>, dim3(512 / HL_UN, (unsigned)batch), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
-                                   n_local, 1.0f / (1.0f - p_drop), hidden);
+                hipLaunchKernelGGL(heads_fc1_lat_kernel<2>, dim3(512 / HL_UN, (unsigned)gy), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
+                                   n_local, 1.0f / (1.0f - p_drop), hidden, batch, ppw);
             else
-                hipLaunchKernelGGL(heads_fc1_lat_kernel<HL_MAXG>, dim3(512 / HL_UN, (unsigned)batch), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
-                                   n_local, 1.0f / (1.0f - p_drop), hidden);
+                hipLaunchKernelGGL(heads_fc1_lat_kernel<HL_MAXG>, dim3(512 / HL_UN, (unsigned)gy), dim3(HL_NT), HL_LDS_BYTES, s, feat, w1planes, (size_t)512 * 5120, b1, mask,
+                                   n_local, 1.0f / (1.0f - p_drop), hidden, batch, ppw);
             return hipGetLastError();
         }
     }
