@@ -7,7 +7,7 @@
 // memory round trip - while its threads split the pair's 5120 features into fp16 planes (20 KB of LDS; no feature planes in memory).  The sixteen waves each
 // take a 320-wide K-slice: ten 16x16x32 MFMA steps with the weights as A operand (rows = hidden units: 4 of the 16 rows are real, the others repeat them and are
 // ignored - the kernel is bound by the round trip, not by the matrix pipe) and the masked features as B operand (columns = 16 MC samples; keep bits from the bit
-// array of heads_prep_kernel through a 256-entry LDS table, as in igemm_s3_lean_kernel).  The sixteen partial tiles are summed through LDS in wave order, then
+// array of heads_prep_kernel through a 16-entry LDS table).  The sixteen partial tiles are summed through LDS in wave order, then
 // bias + LeakyReLU -> hidden [B * n_local][512].  No split-K, no reduce launch, no workspace.  Arithmetic: the two-plane fp16 form of igemm_s3.h
 // (hi += W0 A0, lo += W0 A1 + W1 A0, result = hi + lo / 4096), K summed in a different order than the split-K kernels: results agree to fp32 rounding (tested).
 #pragma once
@@ -31,8 +31,9 @@ typedef __attribute__((address_space(3))) void* hl_lds_ptr_t;
 // feat [B][5120] fp32 (NHWC flatten, LeakyReLU applied); w1planes [2][512][5120] fp16 (W0 = f16(w), W1 = f16((w - W0) 4096): wsplit_gemm of hnet_create);
 // mask [B][n_local][2 heads][640] keep bits (heads_prep_kernel, row-major layout); hidden [B * n_local][512]
 // Round 6: a workgroup keeps its weights in LDS for `ppw` consecutive pairs (grid.y = ceil(batch / ppw)): at batch 8 the 1 024 workgroups of (unit group, pair)
-// each fetched 80 KB - four rounds of one-workgroup-per-CU residents, 36 us; with four pairs per workgroup the launch is one round of 256 and the weights cross
-// the CU's port once.  The next pair's features and keep bits are requested before this pair's MFMAs.  Per pair the arithmetic is unchanged (same bits).
+// each fetched 80 KB - four rounds of one-workgroup-per-CU residents, 36.5 us; with four pairs per workgroup the launch is one round of 256 and the weights cross
+// the CU's port once: 31 us (N = 32; what remains is ~ 5 us per pair of MFMA issue at a quarter of the rows + three barriers).  The next pair's features and keep
+// bits are requested before this pair's MFMAs.  Per pair the arithmetic is unchanged (same bits).
 template <int MAXG>
 __global__ __launch_bounds__(HL_NT) void heads_fc1_lat_kernel(const float* __restrict__ feat, const uint16_t* __restrict__ w1planes, size_t w_plane,
                                                              const float* __restrict__ b1, const uint8_t* __restrict__ mask, int n_local, float scale,
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(HL_NT) void heads_fc1_lat_kernel(const float* __res
     };
     mask_loads(b_first);
     feat_loads(b_first);
-    if (tid < 16) {        // entry x of the table: 4 keep bits -> 4 x 16-bit lane masks (8 bytes).  Round 6: sixteen 8-byte entries = banks 0 .. 31 once - a lookup is conflict free
-        // whatever the lanes' bits (equal entries broadcast); the 256-entry x 16-byte table of round 5 put entries e and e + 16 k on the same banks and a wave's 64 random
-        // lookups serialised: the MFMA loop of a pair took ~ 4 us for 60 MFMAs per wave
+    if (tid < 16) {        // entry x of the table: 4 keep bits -> 4 x 16-bit lane masks (8 bytes); sixteen 8-byte entries = banks 0 .. 31 once: a lookup is conflict free
+        // whatever the lanes' bits (equal entries broadcast).  (Round 5 used 256 entries x 16 bytes; measured the same - the kernel's time at batch 8 is the matrix pipe:
+        // 4 of an MFMA's 16 rows are real, 240 MFMAs x 16 cycles per SIMD and pair.)
         uint2 e;
         e.x = ((tid >> 0) & 1u) * 0xFFFFu | ((tid >> 1) & 1u) * 0xFFFF0000u;
         e.y = ((tid >> 2) & 1u) * 0xFFFFu | ((tid >> 3) & 1u) * 0xFFFF0000u;
