@@ -14,4 +14,9 @@ python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_benc
 # round 6: block 4 sampling its own input (opt-in) against the two launches: A/B of the whole step, the kernel's phases (hipcc ... -DB4_WARPIN=0|1 -DHNET_B4_TRACE tools/trace_b4.hip)
 bash tools/ab_warp_fuse.sh > gpurun_out/${R}_warp_fuse_ab.log 2>&1
 (tools/trace_b4_w0.bin; tools/trace_b4_w1.bin) > gpurun_out/${R}_b4_trace.log 2>&1
+# round 6, latency path: the FC partial sums of the chains and the copy-free hnet_infer graph (A/B), the chain soak, the batch-1 kernel trace
+python tools/chain_fc_ab.py 3 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_chain_fc_ab.log
+python tools/e2e_latency_ab.py 3 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_e2e_latency_ab.log
+python tools/soak_chain.py 400000 2>&1 | grep "^soak" > gpurun_out/${R}_chain_soak_raw.log
+(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace -d gpurun_out/lat_tr --output-format csv -- python3 tools/lat_trace.py full 32 100 > /dev/null 2>&1; python3 tools/lat_trace_summary.py gpurun_out/lat_tr 16 > gpurun_out/${R}_lat_trace_summary.log 2>&1; rm -rf gpurun_out/lat_tr)
 ls -la gpurun_out/${R}_* gpurun_out/prof_$TAG
